@@ -1,0 +1,144 @@
+"""Oracle: world -> image projection (test infrastructure only).
+
+Follows /root/reference/src/glimpse/camera.py:
+  * state vector `_vector[20]`            camera.py:101, 128-198
+  * `Camera.R`                            camera.py:239-280
+  * `Camera._xyz_to_xy`                   camera.py:1435-1470
+  * `Camera._radial_distortion`           camera.py:1138-1163
+  * `Camera._tangential_distortion`       camera.py:1165-1178
+  * `Camera._distort`                     camera.py:1180-1196
+  * `Camera._xy_to_uv`                    camera.py:1499-1508
+  * `Camera.inframe`                      camera.py:700-718
+  * `helpers.elevation_corrections`       helpers.py:1771-1790
+
+A camera is a float64 vector of CAM_LEN = 24 values:
+  [0:3]  xyz        [3:6]  viewdir (deg: yaw, pitch, roll)
+  [6:8]  imgsz      [8:10] f        [10:12] c
+  [12:18] k1..k6    [18:20] p1, p2
+  [20] correction flag (0/1)   [21] radius   [22] refraction   [23] unused
+The first 20 entries are exactly the reference's `_vector`.
+"""
+import numpy as np
+
+CAM_LEN = 24
+DEFAULT_RADIUS = 6.3781e6  # camera.py:120
+DEFAULT_REFRACTION = 0.13  # camera.py:120
+
+
+def make_camera(
+    imgsz,
+    f,
+    c=(0, 0),
+    k=(0, 0, 0, 0, 0, 0),
+    p=(0, 0),
+    xyz=(0, 0, 0),
+    viewdir=(0, 0, 0),
+    correction=False,
+):
+    """Pack camera arguments (camera.py:77-123) into a CAM_LEN vector."""
+    v = np.zeros(CAM_LEN, dtype=float)
+    v[0:3] = xyz
+    v[3:6] = viewdir
+    v[6:8] = np.broadcast_to(np.asarray(imgsz, dtype=float), (2,))
+    v[8:10] = np.broadcast_to(np.asarray(f, dtype=float), (2,))
+    v[10:12] = np.broadcast_to(np.asarray(c, dtype=float), (2,))
+    kk = np.zeros(6)
+    kk[: len(k)] = k
+    v[12:18] = kk
+    pp = np.zeros(2)
+    pp[: len(p)] = p
+    v[18:20] = pp
+    if correction is True:
+        correction = {}
+    if isinstance(correction, dict):
+        corr = {"radius": DEFAULT_RADIUS, "refraction": DEFAULT_REFRACTION, **correction}
+        v[20] = 1.0
+        v[21] = corr["radius"]
+        v[22] = corr["refraction"]
+    return v
+
+
+def rotation_matrix(viewdir):
+    """camera.py:263-280."""
+    radians = np.deg2rad(np.asarray(viewdir, dtype=float))
+    C = np.cos(radians)
+    S = np.sin(radians)
+    return np.array(
+        [
+            [
+                C[0] * C[2] + S[0] * S[1] * S[2],
+                C[0] * S[1] * S[2] - C[2] * S[0],
+                -C[1] * S[2],
+            ],
+            [
+                C[2] * S[0] * S[1] - C[0] * S[2],
+                S[0] * S[2] + C[0] * C[2] * S[1],
+                -C[1] * C[2],
+            ],
+            [C[1] * S[0], C[0] * C[1], S[1]],
+        ]
+    )
+
+
+def xyz_to_xy(cam, xyz):
+    """camera.py:1435-1470 (directions=False)."""
+    xyz = np.asarray(xyz, dtype=float)
+    dxyz = xyz - cam[0:3]
+    if cam[20] != 0:
+        # helpers.py:1790
+        sq = np.sum(dxyz[:, 0:2] ** 2, axis=1)
+        dxyz[:, 2] += (cam[22] - 1) * sq / (2 * cam[21])
+    R = rotation_matrix(cam[3:6])
+    xyz_c = np.matmul(R, dxyz.T).T
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xy = xyz_c[:, 0:2] / xyz_c[:, 2:3]
+    behind = xyz_c[:, 2] <= 0
+    xy[behind] = np.nan
+    return xy
+
+
+def distort(cam, xy):
+    """camera.py:1180-1196 with :1138-1163 and :1165-1178."""
+    k = cam[12:18]
+    p = cam[18:20]
+    if not any(k) and not any(p):
+        return xy
+    dxy = xy.copy()
+    r2 = np.sum(xy ** 2, axis=1)
+    if any(k):
+        dr = 1
+        if k[0]:
+            dr = dr + k[0] * r2
+        if k[1]:
+            dr = dr + k[1] * r2 * r2
+        if k[2]:
+            dr = dr + k[2] * r2 * r2 * r2
+        if any(k[3:6]):
+            temp = 1
+            if k[3]:
+                temp = temp + k[3] * r2
+            if k[4]:
+                temp = temp + k[4] * r2 * r2
+            if k[5]:
+                temp = temp + k[5] * r2 * r2 * r2
+            dr = dr / temp
+        dxy *= dr[:, None]
+    if any(p):
+        xty = xy[:, 0] * xy[:, 1]
+        dtx = 2 * xty * p[0] + p[1] * (r2 + 2 * xy[:, 0] ** 2)
+        dty = p[0] * (r2 + 2 * xy[:, 1] ** 2) + 2 * xty * p[1]
+        dxy += np.column_stack((dtx, dty))
+    return dxy
+
+
+def xyz_to_uv(cam, xyz):
+    """camera.py:591-628 / :1499-1508: uv = distort(xy) * f + (imgsz / 2 + c)."""
+    xy = xyz_to_xy(cam, np.atleast_2d(xyz))
+    xy = distort(cam, xy)
+    return xy * cam[8:10] + (cam[6:8] / 2 + cam[10:12])
+
+
+def inframe(cam, uv):
+    """camera.py:700-718."""
+    with np.errstate(invalid="ignore"):
+        return np.all((uv >= 0) & (uv <= cam[6:8]), axis=1)

@@ -1,0 +1,195 @@
+"""Pin the oracle (CPU restatement) against outputs of the reference itself.
+
+The golden files were written by tools/make_golden.py, which imports
+/root/reference under stubs.  These tests never touch the reference.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import camera, motion, resample, spline, ssd, tiles, tracker
+from tests.helpers_golden import draws_from, models_from, observers_from, taus_from
+
+
+def test_projection_matches_reference(golden):
+    g = golden("g1_projection.npz")
+    for cam, xyz, uv, R in zip(g["cams"], g["xyz"], g["uv"], g["R"]):
+        assert np.array_equal(camera.rotation_matrix(cam[3:6]), R)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = camera.xyz_to_uv(cam, xyz)
+        assert np.array_equal(np.isnan(got), np.isnan(uv))
+        assert np.isnan(uv[250:]).all() and not np.isnan(uv[:250]).any()
+        np.testing.assert_array_equal(got[:250], uv[:250])
+
+
+def test_projection_reference_doctests():
+    # camera.py:615-620: default camera projects (0, 10, 0) onto the image centre
+    cam = camera.make_camera(imgsz=10, f=10)
+    np.testing.assert_array_equal(camera.xyz_to_uv(cam, np.array([(0.0, 10.0, 0.0)])), [[5.0, 5.0]])
+    # camera.py:683-694: behind the camera -> NaN; (1000, 10, 0) -> (1005, 5)
+    xyz = np.array([(1000.0, 10, 0), (0, 10, 0), (0, 0, 0), (0, -10, 0)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        uv = camera.xyz_to_uv(cam, xyz)
+    np.testing.assert_array_equal(uv[:2], [[1005.0, 5.0], [5.0, 5.0]])
+    assert np.isnan(uv[2:]).all()
+    # camera.py:712-715 inframe doctest
+    cam = camera.make_camera(imgsz=(10, 12), f=10)
+    uv = np.array([(-1, 1), (0, 0), (9, 11), (10, 15)], dtype=float)
+    assert list(camera.inframe(cam, uv)) == [False, True, True, False]
+
+
+def test_helpers_reference_doctests():
+    # helpers.py:451-456, :482-487
+    v, q = tiles.compute_cdf(np.array([3, 2, 1, 2]))
+    assert list(v) == [1, 2, 3] and list(q) == [0.25, 0.75, 1.0]
+    a = np.array([3, 2, 1, 2])
+    b = np.array([4, 2, 1, 2, 4, 2, 1, 2])
+    assert list(tiles.match_cdf(a, tiles.compute_cdf(b))) == [4.0, 2.0, 1.0, 2.0]
+    # helpers.py:335-342
+    x = tiles.normalize(np.array([0, 1, 2, 3]))
+    assert x.mean() == 0.0 and x.std() == 1.0
+    # helpers.py:827-829
+    pts = np.array([(0, 0), (1, 1), (2, 2), (3, 3)])
+    assert list(spline.in_box(pts, [1, 1, 2.5, 2.5])) == [False, True, True, False]
+
+
+@pytest.mark.parametrize("name,frames_key,channels", [("gray", "gray", 1), ("rgb", "rgb", 3), ("coarse", "coarse", 1)])
+def test_tiles_match_reference(golden, name, frames_key, channels):
+    g = golden("g2_tiles.npz")
+    frames = g[frames_key]
+    for b in range(3):
+        tbox, sbox = g[f"{name}_{b}_tbox"], g[f"{name}_{b}_sbox"]
+        tile, hist = tiles.extract_tile(frames[0], tbox, return_histogram=True)
+        np.testing.assert_array_equal(tile, g[f"{name}_{b}_tile"])
+        np.testing.assert_array_equal(hist[0], g[f"{name}_{b}_hist_v"])
+        np.testing.assert_array_equal(hist[1], g[f"{name}_{b}_hist_q"])
+        search = tiles.extract_tile(frames[1], sbox, histogram=hist)
+        np.testing.assert_array_equal(search, g[f"{name}_{b}_search"])
+        # integer-key / LUT formulation implemented by the HIP kernels: bit-exact too
+        key = tiles.gray_key(tiles.read_box(frames[0], tbox))
+        t2, h2, _, _ = tiles.template_from_key(key, channels)
+        np.testing.assert_array_equal(t2, g[f"{name}_{b}_tile"])
+        np.testing.assert_array_equal(h2[0], g[f"{name}_{b}_hist_v"])
+        np.testing.assert_array_equal(h2[1], g[f"{name}_{b}_hist_q"])
+        skey = tiles.gray_key(tiles.read_box(frames[1], sbox))
+        s2 = tiles.search_from_key(skey, channels, hist)
+        np.testing.assert_array_equal(s2, g[f"{name}_{b}_search"])
+
+
+def test_spline_matches_reference(golden):
+    g = golden("g4_spline.npz")
+    for i in range(8):
+        sse, box, uv, val = g[f"s{i}_sse"], g[f"s{i}_box"], g[f"s{i}_uv"], g[f"s{i}_val"]
+        got = spline.sample_tile(uv, sse, box)
+        np.testing.assert_array_equal(got, val)
+        # closed-form not-a-knot restatement (what the kernels do)
+        cu, cv = spline.cell_centres(box, sse.shape)
+        coef = spline.fit_notaknot(sse.astype(float))
+        got2 = spline.eval_notaknot(coef, cv[0], cu[0], uv[:, 1], uv[:, 0])
+        np.testing.assert_allclose(got2, val, rtol=0, atol=2e-13)
+    with pytest.raises(ValueError):
+        spline.sample_tile(uv + 100.0, sse, box)
+
+
+def test_resample_matches_reference(golden):
+    g = golden("g5_resample.npz")
+    for i, n in enumerate([1, 7, 100, 129, 1000, 2000, 5000, 10000]):
+        w = g[f"r{i}_weights"]
+        assert len(w) == n
+        idx = resample.systematic(w, float(g[f"r{i}_u"]))
+        np.testing.assert_array_equal(idx, g[f"r{i}_idx"])
+        assert resample.numpy_pairwise_sum(w) == w.sum()
+        if n <= 1000:
+            p = g[f"r{i}_particles"]
+            np.testing.assert_array_equal(p[idx], g[f"r{i}_out_particles"])
+            np.testing.assert_array_equal(w[idx], g[f"r{i}_out_weights"])
+            mean = resample.particle_mean(p[idx], w[idx])
+            np.testing.assert_array_equal(mean, g[f"r{i}_mean"])
+            np.testing.assert_array_equal(resample.particle_sigma(p[idx], w[idx], mean), g[f"r{i}_sigma"])
+            if n > 1:
+                np.testing.assert_array_equal(resample.particle_covariance(p[idx], w[idx]), g[f"r{i}_cov"])
+            sidx = resample.stratified(w, g[f"r{i}_strat_u"])
+            np.testing.assert_array_equal(sidx, g[f"r{i}_strat_idx"])
+            if n > 1:
+                np.random.seed(int(g[f"r{i}_resid_seed"]))
+                ridx = resample.residual(w, np.random.random)
+                np.testing.assert_array_equal(p[ridx], g[f"r{i}_resid_out_particles"])
+
+
+def test_motion_matches_reference(golden):
+    g = golden("g7_motion.npz")
+    for i in range(2):
+        p = g[f"m{i}_params"]
+        model = motion.CartesianMotion(
+            xy=p[0:2], xy_sigma=p[2:4], vxyz=p[4:7], vxyz_sigma=p[7:10], axyz=p[10:13],
+            axyz_sigma=p[13:16], dem=p[16], dem_sigma=p[17], n=len(g[f"m{i}_p0"]))
+        p0, _ = model.initialize_particles(g[f"m{i}_init_normals"])
+        np.testing.assert_array_equal(p0, g[f"m{i}_p0"])
+        p1 = p0.copy()
+        model.evolve_particles(p1, g[f"m{i}_taus"][0], g[f"m{i}_evolve_normals"][0])
+        np.testing.assert_array_equal(p1, g[f"m{i}_p1"])
+        p2 = p1.copy()
+        model.evolve_particles(p2, g[f"m{i}_taus"][1], g[f"m{i}_evolve_normals"][1])
+        np.testing.assert_array_equal(p2, g[f"m{i}_p2"])
+        np.testing.assert_array_equal(model.compute_log_likelihoods(p2), g[f"m{i}_ll"])
+
+
+@pytest.mark.parametrize("name", ["g8_c1.npz", "g8_c2mini.npz", "g8_c5mini.npz"])
+def test_end_to_end_matches_reference(golden, name):
+    """Replaying the recorded RNG draws, the oracle reproduces the reference bit for bit."""
+    g = golden(name)
+    observers = observers_from(g)
+    models = models_from(g)
+    draws = draws_from(g)
+    traces = [[] for _ in models]
+    res = tracker.track(
+        models, observers, g["matching"], taus_from(g), tile_size=tuple(g["tile_size"]),
+        draws=draws, return_particles=True,
+    )
+    np.testing.assert_array_equal(res["means"], g["means"])
+    np.testing.assert_array_equal(res["sigmas"], g["out_sigmas"])
+    assert [e is not None for e in res["errors"]] == [bool(e) for e in g["errors"]]
+    for t, r in enumerate(res["results"]):
+        if r["particles"] is not None and not g["errors"][t]:
+            np.testing.assert_array_equal(r["particles"], g["out_particles"][t])
+            np.testing.assert_array_equal(r["weights"], g["out_weights"][t])
+
+
+@pytest.mark.parametrize("name", ["g8_c1.npz", "g8_c5mini.npz"])
+def test_end_to_end_stage_traces(golden, name):
+    """Per-step intermediates (uv, search tile, SSE, sampled ll, weights, indices)."""
+    g = golden(name)
+    observers = observers_from(g)
+    models = models_from(g)
+    draws = draws_from(g)
+    starts = list(g["track_starts"]) + [int(g["n_steps"])]
+    for t, model in enumerate(models):
+        trace = []
+        tracker.track_one(model, observers, g["matching"], taus_from(g), tile_size=tuple(g["tile_size"]),
+                          draws=draws[t], trace=trace)
+        steps = [tr for tr in trace if "weights" in tr]
+        assert len(steps) == starts[t + 1] - starts[t]
+        for k, tr in enumerate(steps):
+            s = starts[t] + k
+            np.testing.assert_array_equal(tr["evolved"], g[f"s{s}_evolved"])
+            np.testing.assert_array_equal(tr["weights"], g[f"s{s}_weights"])
+            np.testing.assert_array_equal(tr["idx"], g[f"s{s}_idx"])
+            for o, ot in enumerate(tr["obs"]):
+                if f"s{s}_o{o}_sse" not in g:
+                    continue
+                np.testing.assert_array_equal(ot["uv"], g[f"s{s}_o{o}_uv"])
+                np.testing.assert_array_equal(ot["search_tile"].astype(np.float32), g[f"s{s}_o{o}_search_f32"])
+                np.testing.assert_array_equal(ot["sse"], g[f"s{s}_o{o}_sse"])
+                np.testing.assert_array_equal(ot["sse_box"], g[f"s{s}_o{o}_sse_box"])
+                np.testing.assert_array_equal(ot["sampled"], g[f"s{s}_o{o}_sampled"])
+
+
+def test_ssd_c_matches_numpy():
+    rng = np.random.default_rng(3)
+    for (hs, ws, th, tw) in [(20, 23, 15, 15), (40, 37, 31, 31), (16, 16, 15, 15), (50, 64, 5, 7)]:
+        s = rng.standard_normal((hs, ws)).astype(np.float32)
+        t = rng.standard_normal((th, tw)).astype(np.float32)
+        np.testing.assert_array_equal(ssd.match_template_sqdiff(s, t), ssd.match_template_sqdiff_numpy(s, t))

@@ -1,0 +1,484 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in this container.
+
+Build-container only: imports /root/reference/src (glimpse 0.1.1) under the
+stub modules of tools/refstubs.py.  The fixtures hold inputs and the
+reference's outputs only (no reference source); the GPU box never sees the
+reference.  Re-run with:  python tools/make_golden.py
+
+Fixtures:
+  g1_projection.npz   Camera.xyz_to_uv for 5 cameras x 256 points
+  g2_tiles.npz        Tracker.extract_tile / initialize_template on gray / RGB tiles
+  g4_spline.npz       Observer.sample_tile on random SSE surfaces
+  g5_resample.npz     Tracker.resample_particles (all four methods) + moments
+  g7_motion.npz       CartesianMotion init / evolve / log-likelihoods
+  g8_c1.npz           end-to-end config 1 (1 pt x 100 particles, 5 frames 512^2, pinhole)
+  g8_c2mini.npz       k1-k3 distortion, 3 pts x 200 particles, 6 frames 256^2
+  g8_c5mini.npz       2 observers (nadir + oblique), dem_sigma > 0, 2 pts x 200 particles
+Every g8 file stores frames, cameras, motion parameters, the recorded legacy
+RNG draws (in the reference's order), per-step traces (uv, box, search tile,
+sse, sampled ll, weights, searchsorted indices, particles) and Tracks.means /
+.sigmas.
+"""
+import datetime
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refstubs  # noqa: E402
+
+glimpse = refstubs.import_reference()
+from glimpse_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def ref_camera(vec):
+    """24-vector -> reference Camera."""
+    corr = False
+    if vec[20]:
+        corr = {"radius": vec[21], "refraction": vec[22]}
+    return glimpse.Camera(
+        imgsz=vec[6:8], f=vec[8:10], c=vec[10:12], k=vec[12:18], p=vec[18:20],
+        xyz=vec[0:3], viewdir=vec[3:6], correction=corr,
+    )
+
+
+def ref_image(frame, vec, when):
+    cam = ref_camera(vec)
+    img = glimpse.Image("synthetic", cam=cam, datetime=when)
+    img.array = frame
+    return img
+
+
+# ---------------------------------------------------------------- G1 projection
+def g1_projection():
+    rng = np.random.default_rng(101)
+    cams = [
+        synth.pack_camera(imgsz=(512, 384), f=(600, 610), xyz=(1, 2, 3), viewdir=(10, -5, 2)),
+        synth.pack_camera(imgsz=(2048, 2048), f=1000, k=(0.05, -0.01, 0.002), xyz=(0, 0, 100),
+                          viewdir=(0, -90, 0)),
+        synth.pack_camera(imgsz=(800, 536), f=(700, 690), c=(3.5, -2.25),
+                          k=(0.1, -0.05, 0.01, 0.02, -0.01, 0.003), p=(0.001, -0.002),
+                          xyz=(-5, 4, 20), viewdir=(30, -40, 5)),
+        synth.pack_camera(imgsz=(1000, 700), f=1200, k=(0.03, 0, 0), xyz=(40, -30, 90),
+                          viewdir=(-53.13, -60.9, 0), correction=True),
+        synth.pack_camera(imgsz=(4288, 2848), f=(3000, 3010), c=(10, -7), k=(-0.1, 0.02, 0),
+                          p=(0.0005, 0.0003), xyz=(499000.5, 6781000.25, 450.0),
+                          viewdir=(120, -12, 1.5), correction={"radius": 6.3e6, "refraction": 0.2}),
+        # only denominator radial terms (k4..k6), exercises the `dr /= temp` branch alone
+        synth.pack_camera(imgsz=(640, 480), f=500, k=(0, 0, 0, 0.05, 0, 0.001), xyz=(0, 0, 0),
+                          viewdir=(0, 0, 0)),
+    ]
+    xyz_all, uv_all = [], []
+    for vec in cams:
+        cam = ref_camera(vec)
+        R = cam.R
+        # points in front of the camera around its optical axis, plus some behind
+        d = np.column_stack((rng.uniform(-0.6, 0.6, 256), rng.uniform(-0.6, 0.6, 256), np.ones(256)))
+        depth = rng.uniform(5, 500, 256)
+        xyz = vec[0:3] + (d * depth[:, None]) @ R
+        xyz[250:] = vec[0:3] - (d[250:] * depth[250:, None]) @ R  # behind -> NaN
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            uv = cam.xyz_to_uv(xyz.copy())
+        xyz_all.append(xyz)
+        uv_all.append(uv)
+    # doctest known answers (camera.py:615-620, :683-694)
+    np.savez_compressed(
+        os.path.join(OUT, "g1_projection.npz"),
+        cams=np.stack(cams), xyz=np.stack(xyz_all), uv=np.stack(uv_all),
+        R=np.stack([ref_camera(v).R for v in cams]),
+    )
+
+
+# ---------------------------------------------------------------- G2 tiles
+def g2_tiles():
+    rng = np.random.default_rng(202)
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0)
+    frames, _ = synth.make_sequence(cam, 2, seed=5)
+    rgb, _ = synth.make_sequence(cam, 2, seed=6, channels=3)
+    obs_imgs = [ref_image(frames[i], cam, datetime.datetime(2020, 1, 1 + i)) for i in range(2)]
+    obs_rgb = [ref_image(rgb[i], cam, datetime.datetime(2020, 1, 1 + i)) for i in range(2)]
+    tracker = glimpse.Tracker([glimpse.Observer(obs_imgs), glimpse.Observer(obs_rgb)])
+    out = {"gray": np.stack(frames), "rgb": np.stack(rgb), "cam": cam}
+    # low-entropy frame (few distinct values, many ties) to stress the CDF / median paths
+    coarse = (frames[0] // 32 * 32).astype(np.uint8)
+    obs_coarse = [ref_image(coarse, cam, datetime.datetime(2020, 1, 1)),
+                  ref_image((frames[1] // 32 * 32).astype(np.uint8), cam, datetime.datetime(2020, 1, 2))]
+    tracker.observers.append(glimpse.Observer(obs_coarse))
+    out["coarse"] = np.stack([coarse, (frames[1] // 32 * 32).astype(np.uint8)])
+    boxes_t = [(100, 90, 115, 105), (20, 30, 51, 61), (200, 10, 215, 31)]
+    boxes_s = [(90, 80, 130, 121), (5, 12, 80, 70), (180, 0, 256, 60)]
+    for o, name in enumerate(["gray", "rgb", "coarse"]):
+        for b, (bt, bs) in enumerate(zip(boxes_t, boxes_s)):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tile, hist = tracker.extract_tile(obs=o, img=0, box=np.array(bt), return_histogram=True)
+                search = tracker.extract_tile(obs=o, img=1, box=np.array(bs), histogram=hist)
+            out[f"{name}_{b}_tbox"] = np.array(bt)
+            out[f"{name}_{b}_sbox"] = np.array(bs)
+            out[f"{name}_{b}_tile"] = tile
+            out[f"{name}_{b}_hist_v"] = hist[0]
+            out[f"{name}_{b}_hist_q"] = hist[1]
+            out[f"{name}_{b}_search"] = search
+    np.savez_compressed(os.path.join(OUT, "g2_tiles.npz"), **out)
+
+
+# ---------------------------------------------------------------- G4 spline
+def g4_spline():
+    rng = np.random.default_rng(404)
+    cam = synth.nadir_camera((64, 64))
+    imgs = [ref_image(np.zeros((64, 64), np.uint8), cam, datetime.datetime(2020, 1, 1 + i)) for i in range(2)]
+    obs = glimpse.Observer(imgs)
+    out = {}
+    for i, (ho, wo) in enumerate([(4, 4), (4, 7), (5, 5), (6, 9), (8, 8), (9, 12), (23, 17), (64, 51)]):
+        sse = rng.random((ho, wo)).astype(np.float32)
+        l, t = rng.integers(0, 1000, 2)
+        duv = rng.uniform(-0.5, 0.5, 2)
+        box = np.array([l + 7.5 - 0.5, t + 7.5 - 0.5, l + 7.5 - 0.5 + wo, t + 7.5 - 0.5 + ho]) + np.tile(duv, 2)
+        n = 300
+        uv = np.column_stack((rng.uniform(box[0], box[2], n), rng.uniform(box[1], box[3], n)))
+        # exact edges and corners too (clamped evaluation)
+        uv[0] = box[0:2]
+        uv[1] = box[2:4]
+        uv[2] = (box[0], box[3])
+        out[f"s{i}_sse"] = sse
+        out[f"s{i}_box"] = box
+        out[f"s{i}_uv"] = uv
+        out[f"s{i}_val"] = obs.sample_tile(uv, tile=sse, box=box, grid=False, kx=3, ky=3)
+    np.savez_compressed(os.path.join(OUT, "g4_spline.npz"), **out)
+
+
+# ---------------------------------------------------------------- G5 resample / moments
+def g5_resample():
+    cam = synth.nadir_camera((64, 64))
+    imgs = [ref_image(np.zeros((64, 64), np.uint8), cam, datetime.datetime(2020, 1, 1 + i)) for i in range(2)]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs)])
+    rng = np.random.default_rng(505)
+    out = {}
+    real_searchsorted = np.searchsorted
+    for i, n in enumerate([1, 7, 100, 129, 1000, 2000, 5000, 10000]):
+        particles = rng.standard_normal((n, 6)) * [1, 1, 0.1, 0.2, 0.2, 0.01] + [5e5, 6.7e6, 400, 0.1, 0, 0]
+        ll = rng.random(n) * rng.choice([1, 5, 40], n)
+        weights = np.exp(-ll) + 1e-300
+        big = n > 1000  # keep the fixture small: large cases store weights + indices only
+        if not big:
+            out[f"r{i}_particles"] = particles
+        out[f"r{i}_weights"] = weights
+        for method in ("systematic", "stratified", "residual"):
+            tracker.particles = particles.copy()
+            tracker.weights = weights.copy()
+            np.random.seed(1000 + i)
+            state = np.random.get_state()
+            log = []
+
+            def spy(a, v, *args, **kw):
+                r = real_searchsorted(a, v, *args, **kw)
+                log.append(np.array(r))
+                return r
+
+            np.searchsorted = spy
+            try:
+                tracker.resample_particles(method=method)
+            finally:
+                np.searchsorted = real_searchsorted
+            np.random.set_state(state)
+            if method == "systematic":
+                out[f"r{i}_u"] = np.random.random()
+                out[f"r{i}_idx"] = log[0]
+                if not big:
+                    out[f"r{i}_out_particles"] = tracker.particles.copy()
+                    out[f"r{i}_out_weights"] = tracker.weights.copy()
+                out[f"r{i}_mean"] = tracker.particle_mean
+                out[f"r{i}_sigma"] = tracker.compute_particle_sigma()
+                out[f"r{i}_cov"] = np.atleast_2d(tracker.particle_covariance) if n > 1 else np.zeros((6, 6))
+            elif method == "stratified":
+                if not big:
+                    out[f"r{i}_strat_u"] = np.random.random(n)
+                    out[f"r{i}_strat_idx"] = log[0]
+            else:
+                out[f"r{i}_resid_seed"] = 1000 + i
+                if not big:
+                    out[f"r{i}_resid_out_particles"] = tracker.particles.copy()
+    np.savez_compressed(os.path.join(OUT, "g5_resample.npz"), **out)
+
+
+# ---------------------------------------------------------------- G7 motion
+def g7_motion():
+    out = {}
+    day = datetime.timedelta(days=1)
+    configs = [
+        dict(xy=(10.0, -4.0), dem=0.0, dem_sigma=0.0, n=300, xy_sigma=(0.2, 0.3), vxyz=(0.15, 0, 0),
+             vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0)),
+        dict(xy=(499000.5, 6781000.25), dem=450.0, dem_sigma=0.5, n=257, xy_sigma=(0.5, 0.5),
+             vxyz=(1.0, -2.0, 0.1), vxyz_sigma=(0.3, 0.2, 0.05), axyz=(0.01, 0.02, 0.0),
+             axyz_sigma=(0.05, 0.05, 0.01)),
+    ]
+    for i, kw in enumerate(configs):
+        model = glimpse.CartesianMotion(time_unit=day, **kw)
+        np.random.seed(700 + i)
+        state = np.random.get_state()
+        p0 = model.initialize_particles()
+        p1 = p0.copy()
+        model.evolve_particles(p1, dt=datetime.timedelta(days=1.5))
+        p2 = p1.copy()
+        model.evolve_particles(p2, dt=datetime.timedelta(days=-0.75))
+        ll = model.compute_log_likelihoods(p2)
+        np.random.set_state(state)
+        n = kw["n"]
+        out[f"m{i}_params"] = np.concatenate([kw["xy"], kw["xy_sigma"], kw["vxyz"], kw["vxyz_sigma"],
+                                              kw["axyz"], kw["axyz_sigma"], [kw["dem"], kw["dem_sigma"]]])
+        out[f"m{i}_init_normals"] = np.column_stack(
+            (np.random.randn(n, 2), np.random.randn(n), np.random.randn(n, 3)))
+        out[f"m{i}_evolve_normals"] = np.stack([np.random.randn(n, 3), np.random.randn(n, 3)])
+        out[f"m{i}_taus"] = np.array([1.5, -0.75])
+        out[f"m{i}_p0"], out[f"m{i}_p1"], out[f"m{i}_p2"], out[f"m{i}_ll"] = p0, p1, p2, ll
+    np.savez_compressed(os.path.join(OUT, "g7_motion.npz"), **out)
+
+
+# ---------------------------------------------------------------- G8 end to end
+class Recorder:
+    """Hooks the reference Tracker to log draws and per-step intermediates."""
+
+    def __init__(self, tracker):
+        self.tracker = tracker
+        self.steps = []
+        self.randn = []
+        self.random = []
+
+    def __enter__(self):
+        t = self.tracker
+        self._randn, self._random = np.random.randn, np.random.random
+        self._searchsorted = np.searchsorted
+        rec = self
+
+        def randn(*shape):
+            r = rec._randn(*shape)
+            rec.randn.append(np.array(r))
+            return r
+
+        def random(*a):
+            r = rec._random(*a)
+            rec.random.append(np.array(r))
+            return r
+
+        def searchsorted(a, v, *args, **kw):
+            r = rec._searchsorted(a, v, *args, **kw)
+            if rec.steps and isinstance(rec.steps[-1], dict) and "weights" in rec.steps[-1] \
+                    and "idx" not in rec.steps[-1] and np.ndim(v) == 1 and len(v) == len(a) \
+                    and len(a) == len(t.particles):
+                rec.steps[-1]["idx"] = np.array(r)
+            return r
+
+        np.random.randn, np.random.random, np.searchsorted = randn, random, searchsorted
+        self._ll = t.compute_observer_log_likelihoods
+        self._update = t.update_weights
+        self._resample = t.resample_particles
+        self._init_t = t.initialize_template
+        self._sample = [o.sample_tile for o in t.observers]
+        self._cv2 = sys.modules["cv2"].matchTemplate
+
+        def update_weights(imgs, motion_model=None):
+            rec.steps.append({"evolved": t.particles.copy(), "imgs": [(-1 if i is None else int(i)) for i in imgs],
+                              "obs": {}})
+            rec._update(imgs=imgs, motion_model=motion_model)
+            rec.steps[-1]["weights"] = t.weights.copy()
+
+        def compute_ll(obs, img):
+            cur = {}
+            rec.steps[-1]["obs"][int(obs)] = cur
+            rec._cur = cur
+            if img is not None:
+                cur["uv"] = t.observers[obs].xyz_to_uv(t.particles[:, 0:3], img=img)
+            r = rec._ll(obs, img)
+            cur["ll"] = None if r is None else np.array(r)
+            return r
+
+        def matchTemplate(image, templ, method=0):
+            r = rec._cv2(image, templ, method)
+            rec._cur["search_f32"] = np.array(image)
+            rec._cur["sse_raw"] = np.array(r)
+            return r
+
+        def make_sample(o, orig):
+            def sample_tile(uv, tile, box, grid=False, **kw):
+                r = orig(uv, tile=tile, box=box, grid=grid, **kw)
+                rec._cur["sse"] = np.array(tile)
+                rec._cur["sse_box"] = np.array(box)
+                rec._cur["sampled"] = np.array(r)
+                return r
+            return sample_tile
+
+        def resample_particles(method=None):
+            rec._resample(method)
+            rec.steps[-1]["particles"] = t.particles.copy()
+            rec.steps[-1]["out_weights"] = t.weights.copy()
+
+        def initialize_template(obs, img, tile_size):
+            rec._init_t(obs=obs, img=img, tile_size=tile_size)
+            rec.templates.setdefault(len(rec.track_starts) - 1, {})[int(obs)] = {
+                k: np.array(v) if k != "histogram" else (np.array(v[0]), np.array(v[1]))
+                for k, v in t.templates[obs].items()
+            }
+
+        self.templates = {}
+        self.track_starts = []
+        t.update_weights = update_weights
+        t.compute_observer_log_likelihoods = compute_ll
+        t.resample_particles = resample_particles
+        t.initialize_template = initialize_template
+        sys.modules["cv2"].matchTemplate = matchTemplate
+        for o, orig in zip(t.observers, self._sample):
+            o.sample_tile = make_sample(o, orig)
+        self._init_w = t.initialize_weights
+
+        def initialize_weights():
+            rec.track_starts.append(len(rec.steps))
+            rec._init_w()
+
+        t.initialize_weights = initialize_weights
+        return self
+
+    def __exit__(self, *a):
+        np.random.randn, np.random.random, np.searchsorted = self._randn, self._random, self._searchsorted
+        sys.modules["cv2"].matchTemplate = self._cv2
+        return False
+
+
+def run_e2e(name, cams_per_obs, frames_per_obs, sigmas, models_kw, tile_size, seed, maxdt_days=0.0,
+            obs_day_offsets=None, observer_mask=None, return_covariances=False):
+    """Run reference Tracker.track and save everything needed to replay it."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    observers = []
+    nobs = len(frames_per_obs)
+    for o in range(nobs):
+        offs = obs_day_offsets[o] if obs_day_offsets is not None else np.arange(len(frames_per_obs[o]))
+        imgs = [ref_image(frames_per_obs[o][i], cams_per_obs[o][i], t0 + float(offs[i]) * day)
+                for i in range(len(frames_per_obs[o]))]
+        observers.append(glimpse.Observer(imgs, sigma=sigmas[o]))
+    tracker = glimpse.Tracker(observers)
+    models = [glimpse.CartesianMotion(time_unit=day, **kw) for kw in models_kw]
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with Recorder(tracker) as rec:
+            tracks = tracker.track(
+                models, maxdt=datetime.timedelta(days=maxdt_days), tile_size=tile_size,
+                return_particles=True, observer_mask=observer_mask,
+                return_covariances=return_covariances,
+            )
+    out = {
+        "seed": seed,
+        "tile_size": np.array(tile_size),
+        "n_obs": nobs,
+        "sigmas": np.array(sigmas, dtype=float),
+        "means": tracks.means,
+        "out_sigmas": tracks.covariances if return_covariances else tracks.sigmas,
+        "out_particles": tracks.particles,
+        "out_weights": tracks.weights,
+        "matching": np.array([[(-1 if v is None else int(v)) for v in row] for row in tracks.images]),
+        "datetimes_days": np.array([(d - t0).total_seconds() / 86400.0 for d in tracks.datetimes]),
+        "errors": np.array([0 if e is None else 1 for e in tracks.errors]),
+        "params": np.stack([np.concatenate([kw["xy"], kw["xy_sigma"], kw["vxyz"], kw["vxyz_sigma"],
+                                             kw["axyz"], kw["axyz_sigma"], [kw["dem"], kw["dem_sigma"]]])
+                            for kw in models_kw]),
+        "n_particles": np.array([kw["n"] for kw in models_kw]),
+        "maxdt_days": maxdt_days,
+    }
+    if observer_mask is not None:
+        out["observer_mask"] = np.asarray(observer_mask)
+    for o in range(nobs):
+        out[f"obs{o}_frames"] = np.stack(frames_per_obs[o])
+        out[f"obs{o}_cams"] = np.stack(cams_per_obs[o])
+        offs = obs_day_offsets[o] if obs_day_offsets is not None else np.arange(len(frames_per_obs[o]))
+        out[f"obs{o}_days"] = np.asarray(offs, dtype=float)
+    # RNG draws in call order
+    out["n_randn"] = len(rec.randn)
+    for i, r in enumerate(rec.randn):
+        out[f"randn{i}"] = r
+    out["random"] = np.array([float(r) for r in rec.random])
+    # per-step traces; steps are grouped per track in order
+    out["track_starts"] = np.array(rec.track_starts)
+    out["n_steps"] = len(rec.steps)
+    for s, st in enumerate(rec.steps):
+        out[f"s{s}_evolved"] = st["evolved"]
+        out[f"s{s}_imgs"] = np.array(st["imgs"])
+        out[f"s{s}_weights"] = st["weights"]
+        if "idx" in st:
+            out[f"s{s}_idx"] = st["idx"]
+        out[f"s{s}_particles"] = st["particles"]
+        out[f"s{s}_out_weights"] = st["out_weights"]
+        for o, cur in st["obs"].items():
+            for k in ("uv", "ll", "search_f32", "sse_raw", "sse", "sse_box", "sampled"):
+                if k in cur and cur[k] is not None:
+                    out[f"s{s}_o{o}_{k}"] = cur[k]
+    for tr, d in rec.templates.items():
+        for o, tpl in d.items():
+            out[f"t{tr}_o{o}_box"] = tpl["box"]
+            out[f"t{tr}_o{o}_duv"] = tpl["duv"]
+            out[f"t{tr}_o{o}_tile"] = tpl["tile"]
+            out[f"t{tr}_o{o}_hist_v"] = tpl["histogram"][0]
+            out[f"t{tr}_o{o}_hist_q"] = tpl["histogram"][1]
+            out[f"t{tr}_o{o}_img"] = tpl["img"]
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    return tracks
+
+
+def g8_c1():
+    cam = synth.nadir_camera((512, 512), f=1000.0, height=100.0)
+    frames, _ = synth.make_sequence(cam, 5, seed=11, velocity=(0.15, 0.0))
+    kw = dict(xy=(0.0, 0.0), dem=0.0, dem_sigma=0.0, n=100, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+              vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0))
+    tr = run_e2e("g8_c1.npz", [[cam] * 5], [frames], [0.3], [kw], (15, 15), seed=42)
+    print("c1 vx:", tr.means[0, :, 3])
+
+
+def g8_c2mini():
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam, 3, border_px=70.0, seed=3)
+    kws = [dict(xy=tuple(p), dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0)) for p in pts]
+    # a 4th track that starts outside the image -> IndexError captured, NaN rows
+    kws.append(dict(kws[0], xy=(100.0, 100.0)))
+    tr = run_e2e("g8_c2mini.npz", [[cam] * 6], [frames], [0.3], kws, (15, 15), seed=43)
+    print("c2mini vx:", tr.means[:, -1, 3], "errors:", [e is not None for e in tr.errors])
+
+
+def g8_c5mini():
+    cam0 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    cam1 = synth.pack_camera(imgsz=(256, 256), f=1200.0, k=(0.03, 0, 0), xyz=(40, -30, 90),
+                             viewdir=(-53.13, -60.9, 0))
+    scene = synth.default_scene(cam1, seed=13, velocity=(0.15, 0.0), n_frames=8, margin=20.0)
+    f0 = [scene.render(cam0, float(t)) for t in range(6)]
+    # second observer starts one frame late and has RGB frames
+    days1 = np.arange(1, 6)
+    f1 = [scene.render(cam1, float(t), channels=3) for t in days1]
+    kws = [dict(xy=xy, dem=0.0, dem_sigma=0.5, n=200, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                vxyz_sigma=(0.2, 0.2, 0.05), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01))
+           for xy in [(0.5, -0.3), (-2.0, 1.5)]]
+    tr = run_e2e("g8_c5mini.npz", [[cam0] * 6, [cam1] * 5], [f0, f1], [0.3, 0.4], kws, (15, 15), seed=44,
+                 obs_day_offsets=[np.arange(6), days1])
+    print("c5mini v:", tr.means[:, -1, 3:6], "sz:", tr.sigmas[:, -1, 2])
+
+
+if __name__ == "__main__":
+    g1_projection()
+    g2_tiles()
+    g4_spline()
+    g5_resample()
+    g7_motion()
+    g8_c1()
+    g8_c2mini()
+    g8_c5mini()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
