@@ -1,0 +1,426 @@
+"""ctypes binding of libglimpse_hip.so (include/glimpse_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, every
+entry point raises.  Build it with `python -m glimpse_amd.build` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libglimpse_hip.so")
+
+CAM_LEN = 24
+MOTION_LEN = 18
+RNG_HOST, RNG_PHILOX = 0, 1
+OK = 0
+PT_NAN, PT_TEMPLATE_OOB, PT_SAMPLE_OUTSIDE, PT_RESAMPLE_CLAMP, PT_CONST_TILE = 1, 2, 4, 8, 16
+OBS_OK, OBS_SKIPPED, OBS_OUT_OF_BOUNDS, OBS_TILE_TOO_LARGE, OBS_NO_TEMPLATE = 0, 1, 2, 3, 4
+NO_ERROR_FRAME = 0x7F7F7F7F
+
+
+class GlhError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libglimpse_hip error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int32),
+        ("max_points", C.c_int32),
+        ("max_particles", C.c_int32),
+        ("n_observers", C.c_int32),
+        ("max_tile", C.c_int32),
+        ("max_search_dim", C.c_int32),
+        ("max_frames", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_D = C.c_double
+_U64 = C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/glimpse_hip.h one to one
+SIGNATURES = {
+    "glh_version": (_I, []),
+    "glh_last_error": (C.c_char_p, []),
+    "glh_device_count": (_I, [_P]),
+    "glh_create": (_I, [_P, _P]),
+    "glh_destroy": (_I, [_P]),
+    "glh_sync": (_I, [_P]),
+    "glh_get_stream": (_I, [_P, _P]),
+    "glh_observer_init": (_I, [_P, _I, _I, _I, _I, _I, _D]),
+    "glh_observer_set_cameras": (_I, [_P, _I, _I, _I, _P]),
+    "glh_observer_upload_frame": (_I, [_P, _I, _I, _P]),
+    "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
+    "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
+    "glh_set_motion_cartesian": (_I, [_P, _P]),
+    "glh_set_observer_mask": (_I, [_P, _P]),
+    "glh_set_active": (_I, [_P, _P]),
+    "glh_set_particles": (_I, [_P, _P]),
+    "glh_get_particles": (_I, [_P, _P]),
+    "glh_set_weights": (_I, [_P, _P]),
+    "glh_get_weights": (_I, [_P, _P]),
+    "glh_get_point_status": (_I, [_P, _P]),
+    "glh_get_point_error_frame": (_I, [_P, _P]),
+    "glh_get_observer_status": (_I, [_P, _P]),
+    "glh_set_frame": (_I, [_P, _I]),
+    "glh_init_particles": (_I, [_P, _I, _P, _U64]),
+    "glh_evolve": (_I, [_P, _D, _I, _P, _U64, _U64]),
+    "glh_init_templates": (_I, [_P, _I, _I]),
+    "glh_update_weights": (_I, [_P, _P]),
+    "glh_resample": (_I, [_P, _I, _P, _U64, _U64]),
+    "glh_record_moments": (_I, [_P, _I]),
+    "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
+    "glh_get_moments": (_I, [_P, _I, _I, _P]),
+    "glh_get_moments_device": (_I, [_P, _P, _P]),
+    "glh_get_template": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "glh_get_likelihood_debug": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "glh_set_debug": (_I, [_P, _I]),
+    "glh_get_resample_indices": (_I, [_P, _P]),
+    "glh_profile_enable": (_I, [_P, _I]),
+    "glh_profile_reset": (_I, [_P]),
+    "glh_stage_count": (_I, []),
+    "glh_stage_name": (C.c_char_p, [_I]),
+    "glh_profile_get": (_I, [_P, _P, _P]),
+    "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
+    "glh_stage_template": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "glh_stage_search_tile": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
+    "glh_stage_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "glh_stage_resample": (_I, [_I, _P, _I, _D, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlhError(
+            -100,
+            f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
+            "Build it with `python -m glimpse_amd.build`.",
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table ever diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise GlhError(rc, load().glh_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().glh_device_count(C.byref(n)))
+    return n.value
+
+
+def stage_names():
+    lib = load()
+    return [lib.glh_stage_name(i).decode() for i in range(lib.glh_stage_count())]
+
+
+class Context:
+    """One device context = one GPU, one HIP stream, resident frames and particle state."""
+
+    def __init__(self, max_points, max_particles, n_observers=1, device_id=0, max_tile=31,
+                 max_search_dim=320, max_frames=128):
+        self.lib = load()
+        self.cfg = Config(device_id, max_points, max_particles, n_observers, max_tile, max_search_dim,
+                          max_frames, 0)
+        self.handle = C.c_void_p()
+        check(self.lib.glh_create(C.byref(self.cfg), C.byref(self.handle)))
+        self.O = n_observers
+        self.P = self.N = 0
+        self.tile = (0, 0)
+        self._keep = []  # device-borrowed frame owners
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.glh_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- observers
+    def observer_init(self, obs, n_images, width, height, channels, sigma):
+        check(self.lib.glh_observer_init(self.handle, obs, n_images, width, height, channels, float(sigma)))
+
+    def observer_set_cameras(self, obs, cams, first=0):
+        cams = _arr(cams, np.float64)
+        assert cams.ndim == 2 and cams.shape[1] == CAM_LEN
+        check(self.lib.glh_observer_set_cameras(self.handle, obs, first, len(cams), _ptr(cams)))
+
+    def observer_upload_frame(self, obs, image, pixels):
+        pixels = _arr(pixels, np.uint8)
+        check(self.lib.glh_observer_upload_frame(self.handle, obs, image, _ptr(pixels)))
+
+    def observer_set_frame_device(self, obs, image, dev_ptr, owner=None):
+        if owner is not None:
+            self._keep.append(owner)
+        check(self.lib.glh_observer_set_frame_device(self.handle, obs, image, C.c_void_p(dev_ptr)))
+
+    # ---- sequence
+    def begin_sequence(self, n_points, n_particles, tile_size):
+        tw, th = int(tile_size[0]), int(tile_size[1])
+        check(self.lib.glh_begin_sequence(self.handle, n_points, n_particles, tw, th))
+        self.P, self.N, self.tile = n_points, n_particles, (tw, th)
+
+    def set_motion_cartesian(self, params):
+        params = _arr(params, np.float64, (self.P, MOTION_LEN))
+        check(self.lib.glh_set_motion_cartesian(self.handle, _ptr(params)))
+
+    def set_observer_mask(self, mask):
+        m = None if mask is None else _arr(mask, np.uint8, (self.P, self.O))
+        check(self.lib.glh_set_observer_mask(self.handle, _ptr(m)))
+
+    def set_active(self, active):
+        a = None if active is None else _arr(active, np.uint8, (self.P,))
+        check(self.lib.glh_set_active(self.handle, _ptr(a)))
+
+    def set_particles(self, p):
+        p = _arr(p, np.float64, (self.P, self.N, 6))
+        check(self.lib.glh_set_particles(self.handle, _ptr(p)))
+
+    def get_particles(self):
+        out = np.empty((self.P, self.N, 6))
+        check(self.lib.glh_get_particles(self.handle, _ptr(out)))
+        return out
+
+    def set_weights(self, w):
+        w = _arr(w, np.float64, (self.P, self.N))
+        check(self.lib.glh_set_weights(self.handle, _ptr(w)))
+
+    def get_weights(self):
+        out = np.empty((self.P, self.N))
+        check(self.lib.glh_get_weights(self.handle, _ptr(out)))
+        return out
+
+    def point_status(self):
+        out = np.empty(self.P, dtype=np.uint32)
+        check(self.lib.glh_get_point_status(self.handle, _ptr(out)))
+        return out
+
+    def point_error_frame(self):
+        out = np.empty(self.P, dtype=np.int32)
+        check(self.lib.glh_get_point_error_frame(self.handle, _ptr(out)))
+        return out
+
+    def observer_status(self):
+        out = np.empty((self.O, self.P), dtype=np.int32)
+        check(self.lib.glh_get_observer_status(self.handle, _ptr(out)))
+        return out
+
+    # ---- stages
+    def set_frame(self, frame):
+        check(self.lib.glh_set_frame(self.handle, int(frame)))
+
+    def init_particles(self, normals=None, seed=0):
+        if normals is None:
+            check(self.lib.glh_init_particles(self.handle, RNG_PHILOX, None, seed))
+        else:
+            n = _arr(normals, np.float64, (self.P, self.N, 6))
+            check(self.lib.glh_init_particles(self.handle, RNG_HOST, _ptr(n), 0))
+
+    def evolve(self, tau, normals=None, seed=0, step=0):
+        if normals is None:
+            check(self.lib.glh_evolve(self.handle, float(tau), RNG_PHILOX, None, seed, step))
+        else:
+            n = _arr(normals, np.float64, (self.P, self.N, 3))
+            check(self.lib.glh_evolve(self.handle, float(tau), RNG_HOST, _ptr(n), 0, step))
+
+    def init_templates(self, obs, image):
+        check(self.lib.glh_init_templates(self.handle, obs, int(image)))
+
+    def _images(self, images):
+        im = np.array([-1 if i is None else int(i) for i in images], dtype=np.int32)
+        assert im.shape == (self.O,)
+        return im
+
+    def update_weights(self, images):
+        im = self._images(images)
+        check(self.lib.glh_update_weights(self.handle, _ptr(im)))
+
+    def resample(self, u=None, seed=0, step=0):
+        if u is None:
+            check(self.lib.glh_resample(self.handle, RNG_PHILOX, None, seed, step))
+        else:
+            uu = _arr(u, np.float64, (self.P,))
+            check(self.lib.glh_resample(self.handle, RNG_HOST, _ptr(uu), 0, step))
+
+    def record_moments(self, frame):
+        check(self.lib.glh_record_moments(self.handle, int(frame)))
+
+    def step(self, frame, tau, images, normals=None, u=None, seed=0):
+        im = self._images(images)
+        if normals is None:
+            check(self.lib.glh_step(self.handle, int(frame), float(tau), _ptr(im), RNG_PHILOX, None, None, seed))
+        else:
+            n = _arr(normals, np.float64, (self.P, self.N, 3))
+            uu = _arr(u, np.float64, (self.P,))
+            check(self.lib.glh_step(self.handle, int(frame), float(tau), _ptr(im), RNG_HOST, _ptr(n), _ptr(uu), 0))
+
+    def sync(self):
+        check(self.lib.glh_sync(self.handle))
+
+    def stream(self):
+        s = C.c_void_p()
+        check(self.lib.glh_get_stream(self.handle, C.byref(s)))
+        return s.value
+
+    # ---- results
+    def get_moments(self, frame0, n_frames):
+        out = np.empty((n_frames, self.P, 12))
+        check(self.lib.glh_get_moments(self.handle, frame0, n_frames, _ptr(out)))
+        return out
+
+    def moments_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(self.lib.glh_get_moments_device(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def get_template(self, obs, point):
+        tw, th = self.tile
+        box = np.empty(4, dtype=np.int32)
+        duv = np.empty(2)
+        tile = np.empty((th, tw))
+        hv = np.empty(tw * th)
+        hq = np.empty(tw * th)
+        hn = C.c_int32()
+        check(self.lib.glh_get_template(self.handle, obs, point, _ptr(box), _ptr(duv), _ptr(tile), _ptr(hv),
+                                        _ptr(hq), C.byref(hn)))
+        return {"box": box, "duv": duv, "tile": tile, "histogram": (hv[: hn.value].copy(), hq[: hn.value].copy())}
+
+    def set_debug(self, keep=True):
+        check(self.lib.glh_set_debug(self.handle, int(bool(keep))))
+
+    def likelihood_debug(self, obs, point, want_sse=True):
+        """uv (N,2), box (4,) or None, search float32 (Hs,Ws), sse float64 (Ho,Wo)."""
+        tw, th = self.tile
+        uv = np.empty((self.N, 2))
+        box = np.empty(4, dtype=np.int32)
+        check(self.lib.glh_get_likelihood_debug(self.handle, obs, point, _ptr(uv), _ptr(box), None, None))
+        if box[0] < 0:
+            return {"uv": uv, "box": None}
+        ws, hs = int(box[2] - box[0]), int(box[3] - box[1])
+        search = np.empty((hs, ws), dtype=np.float32)
+        sse = np.empty((hs - th + 1, ws - tw + 1)) if want_sse else None
+        check(self.lib.glh_get_likelihood_debug(self.handle, obs, point, None, None, _ptr(search), _ptr(sse)))
+        return {"uv": uv, "box": box, "search": search, "sse": sse}
+
+    def resample_indices(self):
+        out = np.empty((self.P, self.N), dtype=np.int32)
+        check(self.lib.glh_get_resample_indices(self.handle, _ptr(out)))
+        return out
+
+    def profile_enable(self, on=True):
+        check(self.lib.glh_profile_enable(self.handle, int(bool(on))))
+
+    def profile_reset(self):
+        check(self.lib.glh_profile_reset(self.handle))
+
+    def profile_get(self):
+        n = self.lib.glh_stage_count()
+        ms = np.zeros(n)
+        launches = np.zeros(n, dtype=np.int64)
+        check(self.lib.glh_profile_get(self.handle, _ptr(ms), _ptr(launches)))
+        return {name: (float(ms[i]), int(launches[i])) for i, name in enumerate(stage_names())}
+
+
+# ---- stateless stage hooks (parity tests) -----------------------------------------------
+def stage_project(cam, xyz, device_id=0):
+    cam = _arr(cam, np.float64, (CAM_LEN,))
+    xyz = _arr(xyz, np.float64)
+    uv = np.empty((len(xyz), 2))
+    check(load().glh_stage_project(device_id, _ptr(cam), _ptr(xyz), len(xyz), _ptr(uv)))
+    return uv
+
+
+def _frame_dims(frame):
+    frame = _arr(frame, np.uint8)
+    h, w = frame.shape[:2]
+    ch = 1 if frame.ndim == 2 else frame.shape[2]
+    return frame, w, h, ch
+
+
+def stage_template(frame, box, device_id=0):
+    frame, w, h, ch = _frame_dims(frame)
+    box = _arr(box, np.int32, (4,))
+    tw, th = int(box[2] - box[0]), int(box[3] - box[1])
+    tile = np.empty((th, tw))
+    hv = np.empty(tw * th)
+    hq = np.empty(tw * th)
+    hn = C.c_int32()
+    check(load().glh_stage_template(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(tile), _ptr(hv), _ptr(hq),
+                                    C.byref(hn)))
+    return tile, (hv[: hn.value].copy(), hq[: hn.value].copy())
+
+
+def stage_search_tile(frame, box, histogram, device_id=0):
+    frame, w, h, ch = _frame_dims(frame)
+    box = _arr(box, np.int32, (4,))
+    hv = _arr(histogram[0], np.float64)
+    hq = _arr(histogram[1], np.float64)
+    out = np.empty((int(box[3] - box[1]), int(box[2] - box[0])), dtype=np.float32)
+    check(load().glh_stage_search_tile(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(hv), _ptr(hq), len(hv),
+                                       _ptr(out)))
+    return out
+
+
+def stage_ssd(search, templ, device_id=0):
+    search = _arr(search, np.float32)
+    templ = _arr(templ, np.float32)
+    hs, ws = search.shape
+    th, tw = templ.shape
+    out = np.empty((hs - th + 1, ws - tw + 1), dtype=np.float32)
+    check(load().glh_stage_ssd(device_id, _ptr(search), hs, ws, _ptr(templ), th, tw, _ptr(out)))
+    return out
+
+
+def stage_sample(sse, box, uv, device_id=0):
+    sse = _arr(sse, np.float32)
+    box = _arr(box, np.float64, (4,))
+    uv = _arr(uv, np.float64)
+    vals = np.empty(len(uv))
+    outside = np.empty(len(uv), dtype=np.uint8)
+    check(load().glh_stage_sample(device_id, _ptr(sse), sse.shape[0], sse.shape[1], _ptr(box), _ptr(uv), len(uv),
+                                  _ptr(vals), _ptr(outside)))
+    return vals, outside.astype(bool)
+
+
+def stage_resample(weights, u, device_id=0):
+    w = _arr(weights, np.float64)
+    idx = np.empty(len(w), dtype=np.int64)
+    check(load().glh_stage_resample(device_id, _ptr(w), len(w), float(u), _ptr(idx)))
+    return idx

@@ -1,0 +1,1061 @@
+// glh_kernels.h -- HIP kernels of the glimpse.Tracker hot path for gfx950 (MI355X, wave64).
+//
+// One batch = all tracked points of one frame.  Work decomposition:
+//   * per-particle kernels  (grid = [ceil(N/256), P]): evolve+project+bbox, sample+weight
+//   * per-point kernels     (grid = [P] or [G, P]):     tile prep, SSD, spline fit, resample,
+//                                                        moments, template init
+// Float64 everywhere the reference is float64; float32 exactly where the reference casts
+// (SSD inputs/outputs, tracker.py:609-614).  No MFMA: the SSD is (s-t)^2, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/glimpse_hip.h"
+#include "glh_math.h"
+#include "glh_median.h"
+
+namespace glh {
+
+constexpr int BLK = 256;
+constexpr int WAVE = 64;
+constexpr int NWAVES = BLK / WAVE;
+constexpr int MAX_OBS = 4;
+constexpr int NBINS = 768;  // >= 766 = 3 * 255 + 1 channel-sum keys (RGB); 256 for gray
+constexpr int BAND_H = 16;  // rows per median band in k_tileprep
+constexpr int SSD_W = 8;    // outputs per thread in k_ssd
+
+struct ObsFrame {
+  const CamDev* cam;     // camera of the image matched to this frame
+  const uint8_t* frame;  // uint8 [H][W][C]
+  int32_t on;            // images[o] >= 0
+  int32_t width, height, channels;
+};
+
+// ------------------------------------------------------------------------------------------
+// wave / block reductions (deterministic order)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+
+// Sum over the block; result valid in every thread.  `red` holds >= NWAVES doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = v;
+  __syncthreads();
+  double t = red[0];
+#pragma unroll
+  for (int w = 1; w < NWAVES; ++w) t += red[w];
+  return t;
+}
+
+__device__ __forceinline__ void flag_point(uint32_t* pt_status, int32_t* pt_err_frame, int pt,
+                                           uint32_t bit, int frame) {
+  atomicOr(&pt_status[pt], bit);
+  atomicMin(&pt_err_frame[pt], frame);
+}
+
+// ------------------------------------------------------------------------------------------
+// normals: host-fed (parity with np.random) or Philox + Box-Muller
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_normals2(uint64_t seed, uint32_t c0, uint32_t c1,
+                                                uint32_t c2, uint32_t c3, double& z0, double& z1) {
+  uint32_t r[4];
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  double u1 = u01_open(r[0], r[1]);
+  double u2 = u01_halfopen(r[2], r[3]);
+  double rad = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  z0 = rad * c;
+  z1 = rad * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0  CartesianMotion.initialize_particles (motion.py:149-163) + initialize_weights
+// ------------------------------------------------------------------------------------------
+struct InitArgs {
+  double* particles;  // [P][N][6]
+  double* weights;    // [P][N]
+  const double* motion;
+  const uint8_t* active;
+  const double* normals;  // [P][N][6] or null
+  uint64_t seed;
+  int32_t rng_mode, N;
+};
+
+__global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
+  const int pt = blockIdx.y;
+  if (a.active && !a.active[pt]) return;
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.N) return;
+  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+  double n[6];
+  if (a.rng_mode == GLH_RNG_HOST) {
+    const double* src = a.normals + ((size_t)pt * a.N + i) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n[k] = src[k];
+  } else {
+    philox_normals2(a.seed, i, pt, 0u, 0x494e4954u, n[0], n[1]);
+    philox_normals2(a.seed, i, pt, 1u, 0x494e4954u, n[2], n[3]);
+    philox_normals2(a.seed, i, pt, 2u, 0x494e4954u, n[4], n[5]);
+  }
+  double* p = a.particles + ((size_t)pt * a.N + i) * 6;
+  p[0] = m[0] + m[2] * n[0];
+  p[1] = m[1] + m[3] * n[1];
+  double z = m[16];
+  z += m[17] * n[2];
+  p[2] = z;
+  p[3] = m[4] + m[7] * n[3];
+  p[4] = m[5] + m[8] * n[4];
+  p[5] = m[6] + m[9] * n[5];
+  a.weights[(size_t)pt * a.N + i] = 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  evolve (motion.py:165-179) + NaN test (tracker.py:118) + project (camera.py:591)
+//     + per-block uv bounding box partials (tracker.py:583).
+// ------------------------------------------------------------------------------------------
+struct EvolveArgs {
+  double* particles;  // [P][N][6] current buffer (updated in place)
+  const double* motion;
+  const uint8_t* active;
+  const uint8_t* obs_mask;  // [P][O] or null
+  const double* normals;    // [P][N][3] or null
+  double* uv;               // [O][P][N][2]
+  double* bbox_part;        // [O][P][NB][5]
+  uint32_t* pt_status;
+  int32_t* pt_err_frame;
+  uint64_t seed, step;
+  double tau;
+  int32_t do_evolve, rng_mode, N, P, O, NB, frame;
+  ObsFrame obs[MAX_OBS];
+};
+
+__global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
+  __shared__ double red[NWAVES][5];
+  const int pt = blockIdx.y;
+  if (a.active && !a.active[pt]) return;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * BLK + tid;
+  const bool valid = i < a.N;
+  double p[6] = {0, 0, 0, 0, 0, 0};
+  double* pp = a.particles + ((size_t)pt * a.N + (valid ? i : 0)) * 6;
+  if (valid) {
+    const double2* src = reinterpret_cast<const double2*>(pp);
+    double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    p[0] = v0.x; p[1] = v0.y; p[2] = v1.x; p[3] = v1.y; p[4] = v2.x; p[5] = v2.y;
+    if (a.do_evolve) {
+      const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+      double n[3];
+      if (a.rng_mode == GLH_RNG_HOST) {
+        const double* src_n = a.normals + ((size_t)pt * a.N + i) * 3;
+        n[0] = src_n[0]; n[1] = src_n[1]; n[2] = src_n[2];
+      } else {
+        double dump;
+        philox_normals2(a.seed, i, pt, (uint32_t)a.step, 0x45564f4cu, n[0], n[1]);
+        philox_normals2(a.seed, i, pt, (uint32_t)a.step, 0x45564f4du, n[2], dump);
+      }
+      const double tau = a.tau, tau2 = a.tau * a.tau;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double acc = m[10 + k] + m[13 + k] * n[k];
+        p[k] += tau * p[3 + k] + 0.5 * acc * tau2;
+        p[3 + k] += tau * acc;
+      }
+      double2* dst = reinterpret_cast<double2*>(pp);
+      dst[0] = make_double2(p[0], p[1]);
+      dst[1] = make_double2(p[2], p[3]);
+      dst[2] = make_double2(p[4], p[5]);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bad |= isnan(p[k]);
+    if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
+  }
+  for (int o = 0; o < a.O; ++o) {
+    if (!a.obs[o].on) continue;
+    if (a.obs_mask && !a.obs_mask[(size_t)pt * a.O + o]) continue;
+    double u = 0.0, v = 0.0;
+    double mnu = INFINITY, mnv = INFINITY, mxu = -INFINITY, mxv = -INFINITY, nanf = 0.0;
+    if (valid) {
+      project(*a.obs[o].cam, p[0], p[1], p[2], u, v);
+      reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * a.N + i] = make_double2(u, v);
+      if (isnan(u) || isnan(v)) {
+        nanf = 1.0;
+      } else {
+        mnu = mxu = u;
+        mnv = mxv = v;
+      }
+    }
+    mnu = wave_min(mnu); mnv = wave_min(mnv);
+    mxu = wave_max(mxu); mxv = wave_max(mxv);
+    nanf = wave_max(nanf);
+    __syncthreads();
+    if ((tid & (WAVE - 1)) == 0) {
+      double* r = red[tid / WAVE];
+      r[0] = mnu; r[1] = mnv; r[2] = mxu; r[3] = mxv; r[4] = nanf;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NWAVES; ++w) {
+        mnu = fmin(mnu, red[w][0]); mnv = fmin(mnv, red[w][1]);
+        mxu = fmax(mxu, red[w][2]); mxv = fmax(mxv, red[w][3]);
+        nanf = fmax(nanf, red[w][4]);
+      }
+      double* out = a.bbox_part + (((size_t)o * a.P + pt) * a.NB + blockIdx.x) * 5;
+      out[0] = mnu; out[1] = mnv; out[2] = mxu; out[3] = mxv; out[4] = nanf;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7  particle_mean / compute_particle_sigma (tracker.py:72-76, :89-104)
+//     mean = sum(p*w)/sum(w);  sigma = sqrt(sum((p-mean)^2 * w)/sum(w)).  One block per point.
+// ------------------------------------------------------------------------------------------
+struct MomentsArgs {
+  const double* particles;
+  const double* weights;
+  const uint8_t* active;
+  double* out;         // row stride `ld` doubles per point: mean(6) [| sigma(6)]
+  int32_t N, ld, with_sigma;
+};
+
+__global__ __launch_bounds__(BLK) void k_moments(MomentsArgs a) {
+  __shared__ double red[NWAVES];
+  const int pt = blockIdx.x;
+  if (a.active && !a.active[pt]) return;
+  const int tid = threadIdx.x;
+  const double* P0 = a.particles + (size_t)pt * a.N * 6;
+  const double* W0 = a.weights + (size_t)pt * a.N;
+  double sw = 0.0, s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < a.N; i += BLK) {
+    double w = W0[i];
+    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
+    double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    sw += w;
+    s[0] += v0.x * w; s[1] += v0.y * w; s[2] += v1.x * w;
+    s[3] += v1.y * w; s[4] += v2.x * w; s[5] += v2.y * w;
+  }
+  sw = block_sum(sw, red);
+  double mean[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mean[k] = block_sum(s[k], red) / sw;
+  double* out = a.out + (size_t)pt * a.ld;
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = mean[k];
+  }
+  if (!a.with_sigma) return;
+  double q[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < a.N; i += BLK) {
+    double w = W0[i];
+    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
+    double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    double d;
+    d = v0.x - mean[0]; q[0] += d * d * w;
+    d = v0.y - mean[1]; q[1] += d * d * w;
+    d = v1.x - mean[2]; q[2] += d * d * w;
+    d = v1.y - mean[3]; q[3] += d * d * w;
+    d = v2.x - mean[4]; q[4] += d * d * w;
+    d = v2.y - mean[5]; q[5] += d * d * w;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double var = block_sum(q[k], red) / sw;
+    if (tid == 0) out[6 + k] = sqrt(var);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pixel keys: gray value, or channel sum for RGB (tile.mean(axis=2) is sum/3, tracker.py:524)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pixel_key(const uint8_t* frame, int width, int channels, int row,
+                                         int col) {
+  const uint8_t* px = frame + ((size_t)row * width + col) * channels;
+  if (channels == 1) return px[0];
+  int s = 0;
+  for (int c = 0; c < channels; ++c) s += px[c];
+  return s;
+}
+__device__ __forceinline__ double key_value(int key, int channels) {
+  return channels == 1 ? (double)key : (double)key / (double)channels;
+}
+
+// ------------------------------------------------------------------------------------------
+// Template tile from an integer box: Tracker.extract_tile(return_histogram=True)
+// (tracker.py:494-534): normalize (helpers.py:344) -> CDF (helpers.py:458-464) ->
+// tile - median5x5(tile).  normalize is affine increasing, so the median is taken on the
+// integer keys.  Whole block cooperates; keys/hist live in LDS.
+// ------------------------------------------------------------------------------------------
+struct TemplateOut {
+  double* tile64;  // [th*tw]
+  float* tile32;   // [th*tw]
+  double* hist_v;  // [th*tw]
+  double* hist_q;  // [th*tw]
+  int32_t* hist_n;
+};
+
+__device__ void template_from_box(const uint8_t* frame, int width, int channels, const int* box,
+                                  uint16_t* keys, uint32_t* hist, double* red, TemplateOut out,
+                                  bool* const_tile) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  for (int b = tid; b < NBINS; b += BLK) hist[b] = 0;
+  __syncthreads();
+  double sx = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    int key = pixel_key(frame, width, channels, box[1] + r, box[0] + c);
+    keys[idx] = (uint16_t)key;
+    atomicAdd(&hist[key], 1u);
+    sx += key_value(key, channels);
+  }
+  const double mean = block_sum(sx, red) / (double)n;  // a.mean()
+  double sq = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    double d = key_value(keys[idx], channels) - mean;
+    sq += d * d;
+  }
+  const double var = block_sum(sq, red) / (double)n;  // a.var()
+  const double inv_std = 1.0 / sqrt(var);             // 1 / a.std()
+  if (tid == 0) {
+    *const_tile = !(var > 0.0);
+    // np.unique + cumsum(counts) / size (helpers.py:459-461), in increasing key order
+    const int nb = channels == 1 ? 256 : 255 * channels + 1;
+    uint32_t cum = 0;
+    int k = 0;
+    for (int b = 0; b < nb && b < NBINS; ++b) {
+      uint32_t cnt = hist[b];
+      if (cnt) {
+        cum += cnt;
+        out.hist_v[k] = (key_value(b, channels) - mean) * inv_std;
+        out.hist_q[k] = (double)cum / (double)n;
+        ++k;
+      }
+    }
+    *out.hist_n = k;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    int v[25];
+#pragma unroll
+    for (int dr = -2; dr <= 2; ++dr) {
+      int rr = reflect_index(r + dr, h);
+#pragma unroll
+      for (int dc = -2; dc <= 2; ++dc) {
+        int cc = reflect_index(c + dc, w);
+        v[(dr + 2) * 5 + (dc + 2)] = keys[rr * w + cc];
+      }
+    }
+    int med = median25(v);
+    double x = (key_value(keys[idx], channels) - mean) * inv_std;
+    double xm = (key_value(med, channels) - mean) * inv_std;
+    double t = x - xm;
+    out.tile64[idx] = t;
+    out.tile32[idx] = (float)t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a  Tracker.initialize_template (tracker.py:536-561) for one observer, one block per point
+// ------------------------------------------------------------------------------------------
+struct TemplateArgs {
+  const double* mean6;  // [P][6] weighted particle mean (tracker.py:548)
+  const uint8_t* active;
+  const uint8_t* obs_mask;
+  ObsFrame obs;
+  int32_t o, O, P, tw, th, tile_cap, frame;  // tile_cap = max_tile^2 (per-template stride)
+  int32_t* tmpl_box;    // [O][P][4]
+  double* tmpl_duv;     // [O][P][2]
+  double* tmpl_tile64;  // [O][P][tile_cap]
+  float* tmpl_tile32;
+  double* tmpl_hist_v;
+  double* tmpl_hist_q;
+  int32_t* tmpl_hist_n;  // [O][P]
+  int32_t* tmpl_valid;   // [O][P]
+  uint32_t* pt_status;
+  int32_t* pt_err_frame;
+};
+
+__global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t hist[NBINS];
+  __shared__ double red[NWAVES];
+  __shared__ int s_box[4];
+  __shared__ int s_ok;
+  __shared__ bool s_const;
+  uint16_t* keys = reinterpret_cast<uint16_t*>(smem);
+  const int pt = blockIdx.x;
+  if (a.active && !a.active[pt]) return;
+  if (a.obs_mask && !a.obs_mask[(size_t)pt * a.O + a.o]) return;
+  const size_t slot = (size_t)a.o * a.P + pt;
+  if (threadIdx.x == 0) {
+    const double* m = a.mean6 + (size_t)pt * 6;
+    double u, v, duv[2];
+    project(*a.obs.cam, m[0], m[1], m[2], u, v);
+    int bad = template_box(u, v, a.tw, a.th, a.obs.cam->imgsz[0], a.obs.cam->imgsz[1], s_box, duv);
+    if (!bad && (s_box[0] < 0 || s_box[1] < 0 || s_box[2] > a.obs.width || s_box[3] > a.obs.height))
+      bad = 1;
+    s_ok = !bad;
+    if (bad) {
+      a.tmpl_valid[slot] = 0;
+      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_TEMPLATE_OOB, a.frame);
+    } else {
+      for (int k = 0; k < 4; ++k) a.tmpl_box[slot * 4 + k] = s_box[k];
+      a.tmpl_duv[slot * 2 + 0] = duv[0];
+      a.tmpl_duv[slot * 2 + 1] = duv[1];
+    }
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  TemplateOut out;
+  out.tile64 = a.tmpl_tile64 + slot * a.tile_cap;
+  out.tile32 = a.tmpl_tile32 + slot * a.tile_cap;
+  out.hist_v = a.tmpl_hist_v + slot * a.tile_cap;
+  out.hist_q = a.tmpl_hist_q + slot * a.tile_cap;
+  out.hist_n = a.tmpl_hist_n + slot;
+  template_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box, keys, hist, red, out, &s_const);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.tmpl_valid[slot] = 1;
+    if (s_const) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_CONST_TILE, a.frame);
+  }
+}
+
+// Test hook: template from an explicit box (glh_stage_template).
+struct TemplateBoxArgs {
+  const uint8_t* frame;
+  int32_t width, channels;
+  int32_t box[4];
+  TemplateOut out;
+};
+__global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t hist[NBINS];
+  __shared__ double red[NWAVES];
+  __shared__ bool s_const;
+  __shared__ int s_box[4];
+  if (threadIdx.x < 4) s_box[threadIdx.x] = a.box[threadIdx.x];
+  __syncthreads();
+  template_from_box(a.frame, a.width, a.channels, s_box, reinterpret_cast<uint16_t*>(smem), hist,
+                    red, a.out, &s_const);
+}
+
+// ------------------------------------------------------------------------------------------
+// Search tile from an integer box: extract_tile(histogram=template CDF) (tracker.py:605-607):
+// match_cdf (helpers.py:489-493; normalize before it is a no-op) via a per-key LUT
+//   LUT[key] = np.interp(cumcount[key]/size, template_q, template_v)
+// then tile - median5x5(tile) == LUT[key] - LUT[median5x5(key)] (LUT is monotone, window odd).
+// Output is the float32 cast of tracker.py:610.  Median runs on LDS row bands of BAND_H rows.
+// ------------------------------------------------------------------------------------------
+__device__ void search_tile_from_box(const uint8_t* frame, int width, int channels, const int* box,
+                                     const double* hist_v, const double* hist_q, int hist_n,
+                                     uint32_t* hist, uint32_t* cum, double* lut, uint16_t* band,
+                                     uint32_t* scan_tmp, float* out) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  for (int b = tid; b < NBINS; b += BLK) hist[b] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    atomicAdd(&hist[pixel_key(frame, width, channels, box[1] + r, box[0] + c)], 1u);
+  }
+  __syncthreads();
+  // inclusive scan of the 768 bins: 3 bins per thread + block scan of the per-thread sums
+  {
+    uint32_t h0 = hist[3 * tid], h1 = hist[3 * tid + 1], h2 = hist[3 * tid + 2];
+    uint32_t local = h0 + h1 + h2;
+    uint32_t incl = local;
+    const int lane = tid & (WAVE - 1);
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off, WAVE);
+      if (lane >= off) incl += t;
+    }
+    if (lane == WAVE - 1) scan_tmp[tid / WAVE] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int wv = 0; wv < tid / WAVE; ++wv) base += scan_tmp[wv];
+    uint32_t excl = base + incl - local;
+    cum[3 * tid] = excl + h0;
+    cum[3 * tid + 1] = excl + h0 + h1;
+    cum[3 * tid + 2] = excl + local;
+  }
+  __syncthreads();
+  for (int b = tid; b < NBINS; b += BLK) {
+    if (hist[b]) {
+      double q = (double)cum[b] / (double)n;  // np.cumsum(counts) / a.size
+      lut[b] = np_interp(q, hist_q, hist_v, hist_n);
+    }
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < h; r0 += BAND_H) {
+    const int rows = min(BAND_H, h - r0);
+    // stage rows r0-2 .. r0+rows+1 (reflected at the tile's top/bottom) as keys
+    for (int idx = tid; idx < (rows + 4) * w; idx += BLK) {
+      int br = idx / w, c = idx - br * w;
+      int rr = reflect_index(r0 + br - 2, h);
+      band[idx] = (uint16_t)pixel_key(frame, width, channels, box[1] + rr, box[0] + c);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * w; idx += BLK) {
+      int br = idx / w, c = idx - br * w;
+      int v[25];
+#pragma unroll
+      for (int dr = 0; dr < 5; ++dr) {
+#pragma unroll
+        for (int dc = -2; dc <= 2; ++dc) {
+          int cc = reflect_index(c + dc, w);
+          v[dr * 5 + (dc + 2)] = band[(br + dr) * w + cc];
+        }
+      }
+      int key = v[12];
+      int med = median25(v);
+      out[(size_t)(r0 + br) * w + c] = (float)(lut[key] - lut[med]);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b  search box (tracker.py:580-603) + search tile (tracker.py:605-607), one block/point
+// ------------------------------------------------------------------------------------------
+struct TilePrepArgs {
+  const uint8_t* active;
+  const uint8_t* obs_mask;
+  ObsFrame obs;
+  int32_t o, O, P, NB, tw, th, tile_cap, search_cap, max_dim;
+  const double* bbox_part;  // [O][P][NB][5]
+  const int32_t* tmpl_valid;
+  const double* tmpl_hist_v;
+  const double* tmpl_hist_q;
+  const int32_t* tmpl_hist_n;
+  int32_t* box;         // [O][P][4]
+  int32_t* obs_status;  // [O][P]
+  float* search;        // [O][P][search_cap]
+};
+
+__global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t hist[NBINS];
+  __shared__ uint32_t cum[NBINS];
+  __shared__ double lut[NBINS];
+  __shared__ uint32_t scan_tmp[NWAVES];
+  __shared__ double red[NWAVES][5];
+  __shared__ int s_box[4];
+  __shared__ int s_status;
+  const int pt = blockIdx.x, tid = threadIdx.x;
+  const size_t slot = (size_t)a.o * a.P + pt;
+  if ((a.active && !a.active[pt]) || (a.obs_mask && !a.obs_mask[(size_t)pt * a.O + a.o])) {
+    if (tid == 0) a.obs_status[slot] = GLH_OBS_SKIPPED;
+    return;
+  }
+  if (!a.tmpl_valid[slot]) {
+    if (tid == 0) a.obs_status[slot] = GLH_OBS_NO_TEMPLATE;
+    return;
+  }
+  double mnu = INFINITY, mnv = INFINITY, mxu = -INFINITY, mxv = -INFINITY, nanf = 0.0;
+  for (int b = tid; b < a.NB; b += BLK) {
+    const double* p = a.bbox_part + (slot * a.NB + b) * 5;
+    mnu = fmin(mnu, p[0]); mnv = fmin(mnv, p[1]);
+    mxu = fmax(mxu, p[2]); mxv = fmax(mxv, p[3]);
+    nanf = fmax(nanf, p[4]);
+  }
+  mnu = wave_min(mnu); mnv = wave_min(mnv); mxu = wave_max(mxu); mxv = wave_max(mxv);
+  nanf = wave_max(nanf);
+  if ((tid & (WAVE - 1)) == 0) {
+    double* r = red[tid / WAVE];
+    r[0] = mnu; r[1] = mnv; r[2] = mxu; r[3] = mxv; r[4] = nanf;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NWAVES; ++w) {
+      mnu = fmin(mnu, red[w][0]); mnv = fmin(mnv, red[w][1]);
+      mxu = fmax(mxu, red[w][2]); mxv = fmax(mxv, red[w][3]);
+      nanf = fmax(nanf, red[w][4]);
+    }
+    int st = GLH_OBS_OK;
+    if (search_box(mnu, mnv, mxu, mxv, nanf != 0.0, a.tw, a.th, a.obs.cam->imgsz[0],
+                   a.obs.cam->imgsz[1], s_box))
+      st = GLH_OBS_OUT_OF_BOUNDS;
+    else if (s_box[2] > a.obs.width || s_box[3] > a.obs.height)
+      st = GLH_OBS_OUT_OF_BOUNDS;
+    else {
+      int w = s_box[2] - s_box[0], h = s_box[3] - s_box[1];
+      if (w > a.max_dim || h > a.max_dim || (long long)w * h > a.search_cap)
+        st = GLH_OBS_TILE_TOO_LARGE;
+    }
+    s_status = st;
+    a.obs_status[slot] = st;
+    if (st == GLH_OBS_OK)
+      for (int k = 0; k < 4; ++k) a.box[slot * 4 + k] = s_box[k];
+  }
+  __syncthreads();
+  if (s_status != GLH_OBS_OK) return;
+  search_tile_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box,
+                       a.tmpl_hist_v + slot * a.tile_cap, a.tmpl_hist_q + slot * a.tile_cap,
+                       a.tmpl_hist_n[slot], hist, cum, lut, reinterpret_cast<uint16_t*>(smem),
+                       scan_tmp, a.search + slot * (size_t)a.search_cap);
+}
+
+// Test hook: search tile from an explicit box (glh_stage_search_tile).
+struct SearchBoxArgs {
+  const uint8_t* frame;
+  int32_t width, channels;
+  int32_t box[4];
+  const double* hist_v;
+  const double* hist_q;
+  int32_t hist_n;
+  float* out;
+};
+__global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint32_t hist[NBINS];
+  __shared__ uint32_t cum[NBINS];
+  __shared__ double lut[NBINS];
+  __shared__ uint32_t scan_tmp[NWAVES];
+  __shared__ int s_box[4];
+  if (threadIdx.x < 4) s_box[threadIdx.x] = a.box[threadIdx.x];
+  __syncthreads();
+  search_tile_from_box(a.frame, a.width, a.channels, s_box, a.hist_v, a.hist_q, a.hist_n, hist, cum,
+                       lut, reinterpret_cast<uint16_t*>(smem), scan_tmp, a.out);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  area-averaged SSD surface (tracker.py:609-614):
+//       sse[r][c] = float32( sum_ij (S[r+i][c+j] - T[i][j])^2 ) * 1/(tw*th)
+//     float32 sub + FMA inside a template row, float64 across rows, one rounding to float32,
+//     then the reference's  float32(float64(sse) * float64(1/(tw*th))).  Stored widened to
+//     float64 because the spline fit that follows works in float64 (observer.py:210).
+//     Each thread owns an 8-wide strip of one output row; a block stages a band of full-width
+//     search rows in LDS (coalesced loads, 1 LDS read per 8 sub+FMA pairs).
+// ------------------------------------------------------------------------------------------
+struct SsdArgs {
+  int32_t o, P, tw, th, tile_cap, search_cap, sse_cap, lds_floats;
+  const int32_t* box;         // [O][P][4]
+  const int32_t* obs_status;  // [O][P]
+  const float* search;        // [O][P][search_cap]
+  const float* tmpl;          // [O][P][tile_cap]
+  double* sse;                // [O][P][sse_cap]
+};
+
+__device__ __forceinline__ int ssd_ld(int ws) { return (ws + 24 + 3) & ~3; }
+
+__global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int pt = blockIdx.y, tid = threadIdx.x;
+  const size_t slot = (size_t)a.o * a.P + pt;
+  if (a.obs_status[slot] != GLH_OBS_OK) return;
+  const int* box = a.box + slot * 4;
+  const int ws = box[2] - box[0], hs = box[3] - box[1];
+  const int tw = a.tw, th = a.th;
+  const int wo = ws - tw + 1, ho = hs - th + 1;
+  const int twp = (tw + 7) & ~7;
+  const int ld = ssd_ld(ws);
+  float* T = reinterpret_cast<float*>(smem);  // [th][twp]
+  float* S = T + th * twp;                    // [rows][ld]
+  const int spr = (wo + SSD_W - 1) / SSD_W;   // strips per output row
+  int rb = BLK / spr;
+  const int fit = (a.lds_floats - th * twp) / ld - (th - 1);
+  if (rb > fit) rb = fit;
+  if (rb < 1) return;  // excluded by k_tileprep's size limits
+  const int nbands = (ho + rb - 1) / rb;
+  if ((int)blockIdx.x >= nbands) return;
+  const float* tg = a.tmpl + slot * a.tile_cap;
+  for (int idx = tid; idx < th * twp; idx += BLK) {
+    int i = idx / twp, j = idx - i * twp;
+    T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
+  }
+  const float* sg = a.search + slot * (size_t)a.search_cap;
+  double* outg = a.sse + slot * (size_t)a.sse_cap;
+  const double inv_area = 1.0 / (double)(tw * th);
+  for (int band = blockIdx.x; band < nbands; band += gridDim.x) {
+    const int r0 = band * rb;
+    const int nrows = min(rb, ho - r0) + th - 1;
+    __syncthreads();
+    for (int idx = tid; idx < nrows * ld; idx += BLK) {
+      int rr = idx / ld, c = idx - rr * ld;
+      S[idx] = c < ws ? sg[(size_t)(r0 + rr) * ws + c] : 0.0f;
+    }
+    __syncthreads();
+    const int rr = tid / spr, cc = (tid - rr * spr) * SSD_W;
+    const int r = r0 + rr;
+    if (rr < rb && r < ho) {
+      double acc64[SSD_W];
+#pragma unroll
+      for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
+      for (int i = 0; i < th; ++i) {
+        const float* rowp = S + (rr + i) * ld + cc;
+        const float* trow = T + i * twp;
+        float acc[SSD_W];
+#pragma unroll
+        for (int k = 0; k < SSD_W; ++k) acc[k] = 0.0f;
+        float w[16];
+        {
+          float4 a0 = *reinterpret_cast<const float4*>(rowp);
+          float4 a1 = *reinterpret_cast<const float4*>(rowp + 4);
+          w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w;
+          w[4] = a1.x; w[5] = a1.y; w[6] = a1.z; w[7] = a1.w;
+        }
+        for (int jj = 0; jj < tw; jj += 8) {
+          float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 8);
+          float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 12);
+          w[8] = b0.x; w[9] = b0.y; w[10] = b0.z; w[11] = b0.w;
+          w[12] = b1.x; w[13] = b1.y; w[14] = b1.z; w[15] = b1.w;
+          float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
+          float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
+          const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          if (jj + 8 <= tw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+              for (int k = 0; k < SSD_W; ++k) {
+                float d = w[j + k] - tv[j];
+                acc[k] = fmaf(d, d, acc[k]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (jj + j < tw) {
+#pragma unroll
+                for (int k = 0; k < SSD_W; ++k) {
+                  float d = w[j + k] - tv[j];
+                  acc[k] = fmaf(d, d, acc[k]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w[k] = w[k + 8];
+        }
+#pragma unroll
+        for (int k = 0; k < SSD_W; ++k) acc64[k] += (double)acc[k];
+      }
+#pragma unroll
+      for (int k = 0; k < SSD_W; ++k) {
+        if (cc + k < wo) {
+          float raw = (float)acc64[k];
+          float val = (float)((double)raw * inv_area);  // sse *= 1/(tw*th) (tracker.py:614)
+          outg[(size_t)r * wo + cc + k] = (double)val;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  spline coefficients: two passes of banded (|i-j| <= 2) not-a-knot collocation solves
+//     with host-precomputed LU factors (they depend only on n).  In place on the SSE surface.
+// ------------------------------------------------------------------------------------------
+struct SplineFitArgs {
+  int32_t o, P, tw, th, sse_cap, max_n;
+  const int32_t* box;
+  const int32_t* obs_status;
+  const double* lu;          // packed factors: for n, 5 arrays of n at lu_off[n]
+  const int64_t* lu_off;     // [max_n + 1]
+  double* sse;               // in: SSE surface, out: B-spline coefficients
+  double* sse_copy;          // optional debug copy of the surface (or null)
+};
+
+__device__ __forceinline__ void solve_line(double* x, int stride, int n, const double* f) {
+  const double *l1 = f, *l2 = f + n, *u0i = f + 2 * n, *u1 = f + 3 * n, *u2 = f + 4 * n;
+  double ym1 = x[0], ym2 = 0.0;
+  for (int i = 1; i < n; ++i) {
+    double y = x[(size_t)i * stride] - l1[i] * ym1;
+    if (i >= 2) y -= l2[i] * ym2;
+    x[(size_t)i * stride] = y;
+    ym2 = ym1;
+    ym1 = y;
+  }
+  double xp1 = 0.0, xp2 = 0.0;
+  for (int i = n - 1; i >= 0; --i) {
+    double acc = x[(size_t)i * stride];
+    if (i + 1 < n) acc -= u1[i] * xp1;
+    if (i + 2 < n) acc -= u2[i] * xp2;
+    acc *= u0i[i];
+    x[(size_t)i * stride] = acc;
+    xp2 = xp1;
+    xp1 = acc;
+  }
+}
+
+__global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
+  const int pt = blockIdx.x, tid = threadIdx.x;
+  const size_t slot = (size_t)a.o * a.P + pt;
+  if (a.obs_status[slot] != GLH_OBS_OK) return;
+  const int* box = a.box + slot * 4;
+  const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
+  double* z = a.sse + slot * (size_t)a.sse_cap;
+  if (a.sse_copy) {
+    double* cp = a.sse_copy + slot * (size_t)a.sse_cap;
+    for (int idx = tid; idx < wo * ho; idx += BLK) cp[idx] = z[idx];
+    __syncthreads();
+  }
+  const double* fh = a.lu + a.lu_off[ho];
+  const double* fw = a.lu + a.lu_off[wo];
+  for (int c = tid; c < wo; c += BLK) solve_line(z + c, wo, ho, fh);
+  __syncthreads();
+  for (int r = tid; r < ho; r += BLK) solve_line(z + (size_t)r * wo, 1, wo, fw);
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  sample the spline at every particle (observer.py:178-214), scale by 1/(2 sigma^2)
+//     (tracker.py:625), add the DEM term (motion.py:181-204), w = exp(-ll) + 1e-300
+//     (tracker.py:146-149).
+// ------------------------------------------------------------------------------------------
+struct WeightArgs {
+  const double* particles;
+  double* weights;
+  const double* motion;
+  const uint8_t* active;
+  const double* uv;
+  const int32_t* box;
+  const int32_t* obs_status;
+  const double* tmpl_duv;
+  const double* coef;
+  uint32_t* pt_status;
+  int32_t* pt_err_frame;
+  double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
+  int32_t on[MAX_OBS];
+  int32_t N, P, O, tw, th, sse_cap, frame;
+};
+
+__device__ __forceinline__ void sse_box_of(const int* box, const double* duv, int tw, int th,
+                                           double* sb) {
+  // tracker.py:617-620
+  double beu = tw * 0.5 - 0.5, bev = th * 0.5 - 0.5;
+  sb[0] = ((double)box[0] + beu) + duv[0];
+  sb[1] = ((double)box[1] + bev) + duv[1];
+  sb[2] = ((double)box[2] + -beu) + duv[0];
+  sb[3] = ((double)box[3] + -bev) + duv[1];
+}
+
+__global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
+  const int pt = blockIdx.y;
+  if (a.active && !a.active[pt]) return;
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.N) return;
+  double ll = 0.0;
+  for (int o = 0; o < a.O; ++o) {
+    if (!a.on[o]) continue;
+    const size_t slot = (size_t)o * a.P + pt;
+    if (a.obs_status[slot] != GLH_OBS_OK) continue;
+    const int* box = a.box + slot * 4;
+    const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
+    double sb[4];
+    sse_box_of(box, a.tmpl_duv + slot * 2, a.tw, a.th, sb);
+    double2 q = reinterpret_cast<const double2*>(a.uv)[slot * a.N + i];
+    if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3]))
+      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
+    double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
+    double val = spline_eval(a.coef + slot * (size_t)a.sse_cap, wo, ho, wo, cv0, cu0, q.x, q.y);
+    ll += val * a.inv2s2[o];
+  }
+  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+  const double zs = m[17];
+  if (zs != 0.0) {
+    double z = a.particles[((size_t)pt * a.N + i) * 6 + 2];
+    double d = m[16] - z;
+    ll += 1.0 / (2.0 * (zs * zs)) * (d * d);
+  }
+  a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
+}
+
+// Test hook: sample a fitted surface (glh_stage_sample); one "point".
+struct SampleArgs {
+  const double* coef;
+  int32_t ho, wo, n;
+  double sb[4];
+  const double* uv;
+  double* values;
+  uint8_t* outside;
+};
+__global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.n) return;
+  double u = a.uv[2 * i], v = a.uv[2 * i + 1];
+  a.outside[i] = !(u >= a.sb[0] && u <= a.sb[2] && v >= a.sb[1] && v <= a.sb[3]);
+  double cu0 = cell_origin(a.sb[0], a.sb[2], a.wo), cv0 = cell_origin(a.sb[1], a.sb[3], a.ho);
+  a.values[i] = spline_eval(a.coef, a.wo, a.ho, a.wo, cv0, cu0, u, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  systematic resampling (tracker.py:168-176, :222-223), one block per point:
+//       wn = w / w.sum()            -- w.sum() reproduces NumPy's pairwise tree bit for bit
+//       c  = cumsum(wn)             -- float64 block scan in LDS
+//       idx_j = #{k : c_k < (j+u)/n} -- binary search (np.searchsorted, side='left')
+//       particles, weights = particles[idx], weights[idx]
+// ------------------------------------------------------------------------------------------
+struct ResampleArgs {
+  const double* particles_in;
+  const double* weights_in;
+  double* particles_out;
+  double* weights_out;
+  const uint8_t* active;
+  const double* u;  // [P] (host mode) or null
+  int32_t* idx_out;  // [P][N] or null
+  uint32_t* pt_status;
+  int32_t* pt_err_frame;
+  const int32_t* leaf_off;  // NumPy pairwise-sum plan (depends only on N)
+  const int32_t* leaf_len;
+  const int16_t* sum_prog;  // >=0: push leaf, -1: add top two, -2: end of 8192-chunk
+  uint64_t seed, step;
+  int32_t N, nleaves, nprog, rng_mode, frame;
+};
+
+__global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double wave_tot[NWAVES];
+  __shared__ double s_total;
+  double* c = reinterpret_cast<double*>(smem);  // [N] cumulative weights
+  double* leaf_sum = c + a.N;                   // [nleaves]
+  const int pt = blockIdx.x, tid = threadIdx.x;
+  if (a.active && !a.active[pt]) return;
+  const int N = a.N;
+  const double* W = a.weights_in + (size_t)pt * N;
+  // --- w.sum(): leaves of <= 128 items, 8 interleaved accumulators each (8 lanes per leaf)
+  {
+    const int sub = tid & 7;
+    for (int L = tid >> 3; L < a.nleaves; L += BLK / 8) {
+      const int off = a.leaf_off[L], len = a.leaf_len[L];
+      double res;
+      if (len < 8) {
+        res = 0.0;
+        if (sub == 0)
+          for (int i = 0; i < len; ++i) res += W[off + i];
+      } else {
+        double r = W[off + sub];
+        const int body = len - (len & 7);
+        for (int i = 8; i < body; i += 8) r += W[off + i + sub];
+        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); float add is commutative, so a butterfly
+        // gives every lane the same bits
+        r += __shfl_xor(r, 1, WAVE);
+        r += __shfl_xor(r, 2, WAVE);
+        r += __shfl_xor(r, 4, WAVE);
+        res = r;
+        if (sub == 0)
+          for (int i = body; i < len; ++i) res += W[off + i];
+      }
+      if (sub == 0) leaf_sum[L] = res;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double stack[24];
+    int sp = 0;
+    double total = 0.0;
+    bool first = true;
+    for (int k = 0; k < a.nprog; ++k) {
+      int op = a.sum_prog[k];
+      if (op >= 0) {
+        stack[sp++] = leaf_sum[op];
+      } else if (op == -1) {
+        double b = stack[--sp];
+        double x = stack[--sp];
+        stack[sp++] = x + b;
+      } else {
+        double v = stack[--sp];
+        total = first ? v : total + v;
+        first = false;
+      }
+    }
+    s_total = total;
+  }
+  __syncthreads();
+  const double total = s_total;
+  // --- cumsum(w / total): contiguous segment per thread, block scan of the segment sums
+  const int seg = (N + BLK - 1) / BLK;
+  const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
+  double run = 0.0;
+  for (int k = k0; k < k1; ++k) {
+    run += W[k] / total;
+    c[k] = run;
+  }
+  double incl = run;
+  const int lane = tid & (WAVE - 1);
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    double t = __shfl_up(incl, off, WAVE);
+    if (lane >= off) incl += t;
+  }
+  if (lane == WAVE - 1) wave_tot[tid / WAVE] = incl;
+  double prev = __shfl_up(incl, 1, WAVE);  // exclusive prefix inside the wave (no subtraction)
+  if (lane == 0) prev = 0.0;
+  __syncthreads();
+  double base = 0.0;
+  for (int w = 0; w < tid / WAVE; ++w) base += wave_tot[w];
+  const double excl = base + prev;
+  if (tid > 0)
+    for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
+  __syncthreads();
+  // --- positions, search, gather
+  double u;
+  if (a.rng_mode == GLH_RNG_HOST) {
+    u = a.u[pt];
+  } else {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)pt, 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+                  (uint32_t)(a.seed >> 32), r);
+    u = u01_halfopen(r[0], r[1]);
+  }
+  const double inv_n = 1.0 / (double)N;
+  const double* Pin = a.particles_in + (size_t)pt * N * 6;
+  double* Pout = a.particles_out + (size_t)pt * N * 6;
+  double* Wout = a.weights_out + (size_t)pt * N;
+  for (int j = tid; j < N; j += BLK) {
+    double pos = ((double)j + u) * inv_n;
+    int lo = 0, hi = N;  // first k with c[k] >= pos
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (c[mid] < pos)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo >= N) {
+      lo = N - 1;
+      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+    }
+    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)lo * 6);
+    double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    double2* dst = reinterpret_cast<double2*>(Pout + (size_t)j * 6);
+    dst[0] = v0; dst[1] = v1; dst[2] = v2;
+    Wout[j] = W[lo];
+    if (a.idx_out) a.idx_out[(size_t)pt * N + j] = lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Test hook: Camera.xyz_to_uv on explicit points
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const double* xyz, int n,
+                                                        double* uv) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  double u, v;
+  project(*cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
+  uv[2 * i] = u;
+  uv[2 * i + 1] = v;
+}
+
+__global__ void k_fill_f64(double* p, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace glh

@@ -1,0 +1,263 @@
+// glh_math.h -- per-element stage math shared by the HIP kernels.
+//
+// Everything here is `__host__ __device__` so that tests/hostcheck can compile the very
+// same arithmetic with g++ and compare it against the oracle on a machine without a GPU.
+// (That harness is test-only; the product never runs this code on the CPU.)
+//
+// Operation order follows the reference expression by expression (citations relative to
+// /root/reference/src/glimpse/), and the library is built with -ffp-contract=off, so the
+// float64 results are bit-identical to NumPy wherever NumPy itself is deterministic.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GLH_HD __host__ __device__ __forceinline__
+#else
+#define GLH_HD inline
+#endif
+
+namespace glh {
+
+// Camera expanded on the host at upload (camera.py:101, :239-280).
+struct CamDev {
+  double xyz[3];
+  double R[9];      // Camera.R, row-major
+  double f[2];
+  double off[2];    // imgsz / 2 + c          (camera.py:1507)
+  double imgsz[2];
+  double k[6];
+  double p[2];
+  double radius;    // correction["radius"]     (camera.py:118-121)
+  double refraction;
+  int32_t has_corr;
+  int32_t any_k;    // any(self.k)              (camera.py:1188)
+  int32_t any_kden; // any(self.k[3:6])         (camera.py:1152)
+  int32_t any_p;    // any(self.p)
+};
+
+// Camera.xyz_to_uv (camera.py:591-628): _xyz_to_xy (:1435-1470), _distort (:1180-1196 with
+// :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).
+GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, double& v) {
+  double dx = x - c.xyz[0];
+  double dy = y - c.xyz[1];
+  double dz = z - c.xyz[2];
+  if (c.has_corr) {
+    // helpers.elevation_corrections (helpers.py:1790)
+    double sq = dx * dx + dy * dy;
+    dz += (c.refraction - 1.0) * sq / (2.0 * c.radius);
+  }
+  double cx = c.R[0] * dx + c.R[1] * dy + c.R[2] * dz;
+  double cy = c.R[3] * dx + c.R[4] * dy + c.R[5] * dz;
+  double cz = c.R[6] * dx + c.R[7] * dy + c.R[8] * dz;
+  if (!(cz > 0.0)) {  // behind the camera (camera.py:1465-1466); NaN depth stays NaN too
+    u = v = NAN;
+    return;
+  }
+  double px = cx / cz;
+  double py = cy / cz;
+  double qx = px, qy = py;
+  if (c.any_k || c.any_p) {
+    double r2 = px * px + py * py;
+    if (c.any_k) {
+      double dr = 1.0;
+      if (c.k[0] != 0.0) dr += c.k[0] * r2;
+      if (c.k[1] != 0.0) dr += c.k[1] * r2 * r2;
+      if (c.k[2] != 0.0) dr += c.k[2] * r2 * r2 * r2;
+      if (c.any_kden) {
+        double t = 1.0;
+        if (c.k[3] != 0.0) t += c.k[3] * r2;
+        if (c.k[4] != 0.0) t += c.k[4] * r2 * r2;
+        if (c.k[5] != 0.0) t += c.k[5] * r2 * r2 * r2;
+        dr /= t;
+      }
+      qx = px * dr;
+      qy = py * dr;
+    }
+    if (c.any_p) {
+      double xty = px * py;
+      double dtx = 2.0 * xty * c.p[0] + c.p[1] * (r2 + 2.0 * (px * px));
+      double dty = c.p[0] * (r2 + 2.0 * (py * py)) + 2.0 * xty * c.p[1];
+      qx += dtx;
+      qy += dty;
+    }
+  }
+  u = qx * c.f[0] + c.off[0];
+  v = qy * c.f[1] + c.off[1];
+}
+
+// Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is
+// inside the image (Camera.inframe, camera.py:700-718), 1 otherwise.  kx = ky = 3.
+GLH_HD int search_box(double minu, double minv, double maxu, double maxv, int has_nan, int tw,
+                      int th, double imgw, double imgh, int* box) {
+  if (has_nan) return 1;  // NaN min/max -> garbage ints -> out of bounds (tracker.py:597)
+  double lo_u = minu - tw * 0.5, hi_u = maxu + tw * 0.5;
+  double lo_v = minv - th * 0.5, hi_v = maxv + th * 0.5;
+  double ncols = 3.0 - ((hi_u - lo_u) - tw);
+  if (ncols > 0.0) {
+    lo_u += -ncols * 0.5;
+    hi_u += ncols * 0.5;
+  }
+  double nrows = 3.0 - ((hi_v - lo_v) - th);
+  if (nrows > 0.0) {
+    lo_v += -nrows * 0.5;
+    hi_v += nrows * 0.5;
+  }
+  double l = floor(lo_u), t = floor(lo_v), r = ceil(hi_u), b = ceil(hi_v);
+  if (!(l >= 0.0 && t >= 0.0 && r <= imgw && b <= imgh && l <= imgw && t <= imgh && r >= 0.0 &&
+        b >= 0.0))
+    return 1;
+  box[0] = (int)l;
+  box[1] = (int)t;
+  box[2] = (int)r;
+  box[3] = (int)b;
+  return 0;
+}
+
+// Grid.snap_box on an image grid (raster.py:414-421, :372-388) + duv (tracker.py:556).
+// Returns 0 when the box is inside the image, 1 otherwise (IndexError in the reference).
+GLH_HD int template_box(double u, double v, int tw, int th, double imgw, double imgh, int* box,
+                        double* duv) {
+  double x0 = u - tw * 0.5, x1 = u + tw * 0.5;
+  double y0 = v - th * 0.5, y1 = v + th * 0.5;
+  if (!(x0 >= 0.0 && x0 <= imgw && x1 >= 0.0 && x1 <= imgw && y0 >= 0.0 && y0 <= imgh &&
+        y1 >= 0.0 && y1 <= imgh))
+    return 1;
+  box[0] = (int)floor(x0 + 0.5);
+  box[1] = (int)floor(y0 + 0.5);
+  box[2] = (int)floor(x1 + 0.5);
+  box[3] = (int)floor(y1 + 0.5);
+  duv[0] = u - (double)(box[0] + box[2]) / 2.0;
+  duv[1] = v - (double)(box[1] + box[3]) / 2.0;
+  return 0;
+}
+
+// np.interp for one x (numpy/_core/src/multiarray/compiled_base.c: arr_interp), with the
+// default left = fp[0], right = fp[n-1].  xp is non-decreasing, n >= 1.
+GLH_HD double np_interp(double x, const double* xp, const double* fp, int n) {
+  if (n == 1) return fp[0];
+  if (x > xp[n - 1]) return fp[n - 1];
+  if (x < xp[0]) return fp[0];
+  int lo = 0, hi = n - 1;  // invariant: xp[lo] <= x, and (hi == n-1 or x < xp[hi])
+  if (x >= xp[n - 1]) {
+    lo = n - 1;
+  } else {
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (x >= xp[mid])
+        lo = mid;
+      else
+        hi = mid;
+    }
+  }
+  int j = lo;
+  if (j == n - 1) return fp[j];
+  if (xp[j] == x) return fp[j];
+  double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  double res = slope * (x - xp[j]) + fp[j];
+  if (isnan(res)) {
+    res = slope * (x - xp[j + 1]) + fp[j + 1];
+    if (isnan(res) && fp[j] == fp[j + 1]) res = fp[j];
+  }
+  return res;
+}
+
+// Index with edge-repeating reflection (scipy.ndimage mode='reflect': d c b a | a b c d | d c b a).
+GLH_HD int reflect_index(int i, int n) {
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return i;
+}
+
+// ---- not-a-knot bicubic spline (observer.py:210 == FITPACK regrid/bispev with s=0) ------
+// knot i (0 <= i < n+4) in unit-spaced local coordinates: [0]*4, 2..n-3, [n-1]*4
+GLH_HD double knot_local(int i, int n) {
+  return i <= 3 ? 0.0 : (i >= n ? (double)(n - 1) : (double)(i - 2));
+}
+
+// interval q (0 <= q <= n-4) that holds local coordinate xl in [0, n-1]
+GLH_HD int spline_interval(double xl, int n) {
+  int m = (int)floor(xl) - 1;
+  if (m < 0) m = 0;
+  if (m > n - 4) m = n - 4;
+  return m;
+}
+
+// The 4 non-zero cubic B-splines on interval q at x (de Boor, as FITPACK's fpbspl);
+// knots are x0 + knot_local(i, n).
+GLH_HD void spline_basis(double x, int q, int n, double x0, double* h) {
+  int l = q + 3;
+  double hh[3];
+  h[0] = 1.0;
+  h[1] = h[2] = h[3] = 0.0;
+  for (int j = 1; j <= 3; ++j) {
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.0;
+    for (int i = 0; i < j; ++i) {
+      int li = l + i + 1;
+      int lj = li - j;
+      double tli = x0 + knot_local(li, n);
+      double tlj = x0 + knot_local(lj, n);
+      double f = hh[i] / (tli - tlj);
+      h[i] = h[i] + f * (tli - x);
+      h[i + 1] = f * (x - tlj);
+    }
+  }
+}
+
+// Cell-centre origin along one axis (observer.py:203-208):
+//   d = (b1 - b0) / n ;  c0 = b0 + d * 0.5   (np.arange start)
+GLH_HD double cell_origin(double b0, double b1, int n) { return b0 + ((b1 - b0) / n) * 0.5; }
+
+// Evaluate the tensor spline with coefficients coef[ho][wo] (row stride ld) at (u, v);
+// arguments are clamped to the outermost cell centres (FITPACK fpbisp).
+GLH_HD double spline_eval(const double* coef, int ld, int ho, int wo, double cv0, double cu0,
+                          double u, double v) {
+  double vmax = cv0 + (double)(ho - 1), umax = cu0 + (double)(wo - 1);
+  double vv = v < cv0 ? cv0 : (v > vmax ? vmax : v);
+  double uu = u < cu0 ? cu0 : (u > umax ? umax : u);
+  int qv = spline_interval(vv - cv0, ho);
+  int qu = spline_interval(uu - cu0, wo);
+  double hv[4], hu[4];
+  spline_basis(vv, qv, ho, cv0, hv);
+  spline_basis(uu, qu, wo, cu0, hu);
+  double sp = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double* row = coef + (size_t)(qv + i) * ld + qu;
+    for (int j = 0; j < 4; ++j) sp += row[j] * hv[i] * hu[j];
+  }
+  return sp;
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: no state in HBM -------------------
+GLH_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+GLH_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                          uint32_t k1, uint32_t* out) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0;
+    k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two uint32 -> uniform double in (0, 1): 53 random bits, never 0 (safe for log)
+GLH_HD double u01_open(uint32_t a, uint32_t b) {
+  uint64_t x = (((uint64_t)a << 32) | b) >> 11;  // 53 bits
+  return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// [0, 1) like np.random.random()
+GLH_HD double u01_halfopen(uint32_t a, uint32_t b) {
+  uint64_t x = (((uint64_t)a << 32) | b) >> 11;
+  return (double)x * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace glh

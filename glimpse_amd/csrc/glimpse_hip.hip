@@ -1,0 +1,1347 @@
+// glimpse_hip.hip -- C ABI (include/glimpse_hip.h) over the kernels in glh_kernels.h.
+// Host side: context, HBM residency, launches on one HIP stream, stage timers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/glimpse_hip.h"
+#include "glh_kernels.h"
+
+using namespace glh;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(GLH_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+#define CHK(expr)          \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_ != GLH_OK) return rc_; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// stages (for the event timers)
+// ------------------------------------------------------------------------------------------
+enum Stage {
+  ST_INIT = 0,
+  ST_EVOLVE_PROJECT,
+  ST_MOMENTS,
+  ST_TEMPLATE,
+  ST_TILEPREP,
+  ST_SSD,
+  ST_SPLINE_FIT,
+  ST_WEIGHTS,
+  ST_RESAMPLE,
+  ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {"init_particles", "evolve_project", "moments",
+                                            "template_init",  "tileprep",       "ssd",
+                                            "spline_fit",     "weights",        "resample"};
+
+// ------------------------------------------------------------------------------------------
+// host-side tables
+// ------------------------------------------------------------------------------------------
+static void expand_camera(const double* v, CamDev* c) {
+  const double d2r = M_PI / 180.0;
+  // np.deg2rad(viewdir); C = cos, S = sin (camera.py:261-263)
+  double C[3], S[3];
+  for (int i = 0; i < 3; ++i) {
+    double r = v[3 + i] * d2r;
+    C[i] = std::cos(r);
+    S[i] = std::sin(r);
+  }
+  for (int i = 0; i < 3; ++i) c->xyz[i] = v[i];
+  // camera.py:264-280
+  c->R[0] = C[0] * C[2] + S[0] * S[1] * S[2];
+  c->R[1] = C[0] * S[1] * S[2] - C[2] * S[0];
+  c->R[2] = -C[1] * S[2];
+  c->R[3] = C[2] * S[0] * S[1] - C[0] * S[2];
+  c->R[4] = S[0] * S[2] + C[0] * C[2] * S[1];
+  c->R[5] = -C[1] * C[2];
+  c->R[6] = C[1] * S[0];
+  c->R[7] = C[0] * C[1];
+  c->R[8] = S[1];
+  for (int i = 0; i < 2; ++i) {
+    c->imgsz[i] = v[6 + i];
+    c->f[i] = v[8 + i];
+    c->off[i] = v[6 + i] / 2 + v[10 + i];  // imgsz / 2 + c (camera.py:1507)
+    c->p[i] = v[18 + i];
+  }
+  c->any_k = c->any_kden = c->any_p = 0;
+  for (int i = 0; i < 6; ++i) {
+    c->k[i] = v[12 + i];
+    if (v[12 + i] != 0.0) {
+      c->any_k = 1;
+      if (i >= 3) c->any_kden = 1;
+    }
+  }
+  if (c->p[0] != 0.0 || c->p[1] != 0.0) c->any_p = 1;
+  c->has_corr = v[20] != 0.0;
+  c->radius = v[21];
+  c->refraction = v[22];
+}
+
+// LU factors (no pivoting) of the not-a-knot collocation matrix of size n, packed as
+// l1[n] l2[n] u0inv[n] u1[n] u2[n].  The matrix is diagonally dominant by rows.
+static void spline_lu(int n, double* out) {
+  std::vector<double> a((size_t)n * 5, 0.0);  // a[i][d] = A[i][i + d - 2]
+  for (int i = 0; i < n; ++i) {
+    int q = spline_interval((double)i, n);
+    double h[4];
+    spline_basis((double)i, q, n, 0.0, h);
+    for (int m = 0; m < 4; ++m) {
+      int d = q + m - i + 2;
+      if (h[m] != 0.0 && d >= 0 && d <= 4) a[(size_t)i * 5 + d] = h[m];
+    }
+  }
+  double *l1 = out, *l2 = out + n, *u0i = out + 2 * n, *u1 = out + 3 * n, *u2 = out + 4 * n;
+  for (int i = 0; i < n; ++i) l1[i] = l2[i] = u1[i] = u2[i] = 0.0;
+  auto A = [&](int i, int j) -> double& { return a[(size_t)i * 5 + (j - i + 2)]; };
+  for (int k = 0; k < n; ++k) {
+    for (int i = k + 1; i < std::min(k + 3, n); ++i) {
+      double m = A(i, k) / A(k, k);
+      (i == k + 1 ? l1[i] : l2[i]) = m;
+      for (int j = k; j < std::min(k + 3, n); ++j)
+        if (j - i + 2 >= 0 && j - i + 2 <= 4) A(i, j) -= m * A(k, j);
+      A(i, k) = 0.0;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    u0i[i] = 1.0 / A(i, i);
+    if (i + 1 < n) u1[i] = A(i, i + 1);
+    if (i + 2 < n) u2[i] = A(i, i + 2);
+  }
+}
+
+// NumPy's pairwise float sum over n contiguous items as a leaf list + postfix program
+// (np.add.reduce: 8192-item chunks; <=128-item leaves; split at n/2 rounded down to 8).
+static void pairwise_plan(int n, std::vector<int32_t>& off, std::vector<int32_t>& len,
+                          std::vector<int16_t>& prog) {
+  struct Rec {
+    static void run(int o, int m, std::vector<int32_t>& off, std::vector<int32_t>& len,
+                    std::vector<int16_t>& prog) {
+      if (m <= 128) {
+        prog.push_back((int16_t)off.size());
+        off.push_back(o);
+        len.push_back(m);
+        return;
+      }
+      int n2 = m / 2;
+      n2 -= n2 % 8;
+      run(o, n2, off, len, prog);
+      run(o + n2, m - n2, off, len, prog);
+      prog.push_back(-1);
+    }
+  };
+  for (int s = 0; s < n; s += 8192) {
+    Rec::run(s, std::min(8192, n - s), off, len, prog);
+    prog.push_back(-2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct Observer {
+  int n_images = 0, width = 0, height = 0, channels = 0;
+  double sigma = 0.3;
+  CamDev* cams = nullptr;               // device [n_images]
+  std::vector<const uint8_t*> frames;   // device pointers (owned or borrowed)
+  std::vector<uint8_t*> owned;          // owned allocations (same indexing; null if borrowed)
+};
+
+struct glh_ctx {
+  glh_config cfg{};
+  hipStream_t stream = nullptr;
+  int P = 0, N = 0, tw = 0, th = 0, NB = 0;
+  int cur = 0;  // current particle/weight buffer
+  int frame = 0;
+  bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false;
+  int tile_cap = 0, search_cap = 0, sse_cap = 0, lds_ssd_bytes = 0;
+  Observer obs[MAX_OBS];
+  // device buffers
+  double *particles[2] = {nullptr, nullptr}, *weights[2] = {nullptr, nullptr};
+  double *motion = nullptr, *uv = nullptr, *bbox_part = nullptr, *normals = nullptr, *u = nullptr;
+  double *mean6 = nullptr, *moments = nullptr;
+  uint8_t *obs_mask = nullptr, *active = nullptr;
+  uint32_t* pt_status = nullptr;
+  int32_t *pt_err_frame = nullptr, *obs_status = nullptr, *box = nullptr, *idx = nullptr;
+  int32_t *tmpl_box = nullptr, *tmpl_hist_n = nullptr, *tmpl_valid = nullptr;
+  double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
+  float *tmpl_tile32 = nullptr, *search = nullptr;
+  double *sse = nullptr, *sse_copy = nullptr;
+  double* lu = nullptr;
+  int64_t* lu_off = nullptr;
+  int32_t *leaf_off = nullptr, *leaf_len = nullptr;
+  int16_t* sum_prog = nullptr;
+  int nleaves = 0, nprog = 0;
+  size_t normals_cap = 0;
+  // profiling
+  bool profiling = false;
+  struct Ev {
+    hipEvent_t a, b;
+    int stage;
+  };
+  std::vector<Ev> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[ST_COUNT] = {0};
+  int64_t launches[ST_COUNT] = {0};
+};
+
+template <typename T>
+static int dalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess)
+    return fail(GLH_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  return GLH_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+  if (p) (void)hipFree((void*)p);
+  p = nullptr;
+}
+
+struct StageTimer {
+  glh_ctx* c;
+  int stage;
+  hipEvent_t a = nullptr, b = nullptr;
+  StageTimer(glh_ctx* ctx, int st) : c(ctx), stage(st) {
+    c->launches[st]++;
+    if (!c->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->pool.empty()) {
+        e = c->pool.back();
+        c->pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~StageTimer() {
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({a, b, stage});
+  }
+};
+
+static int drain_profile(glh_ctx* c) {
+  if (c->pending.empty()) return GLH_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& e : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) c->ms[e.stage] += ms;
+    c->pool.push_back(e.a);
+    c->pool.push_back(e.b);
+  }
+  c->pending.clear();
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// library / context
+// ------------------------------------------------------------------------------------------
+extern "C" int glh_version(void) { return GLH_VERSION; }
+extern "C" const char* glh_last_error(void) { return g_err.c_str(); }
+extern "C" int glh_stage_count(void) { return ST_COUNT; }
+extern "C" const char* glh_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+
+extern "C" int glh_device_count(int* count) {
+  if (!count) return fail(GLH_E_INVALID, "count is null");
+  HIPCHK(hipGetDeviceCount(count));
+  return GLH_OK;
+}
+
+static int ssd_lds_bytes(int max_dim, int max_tile) {
+  // template [th][twp] + at least th rows (one output row) of the widest band; prefer ~8 rows
+  int twp = (max_tile + 7) & ~7;
+  int ld = (max_dim + 24 + 3) & ~3;
+  long need_min = (long)max_tile * twp + (long)ld * max_tile;
+  long want = (long)max_tile * twp + (long)ld * (max_tile - 1 + 8);
+  long cap = 96 * 1024 / 4;
+  long floats = want < cap ? want : cap;
+  if (floats < need_min) floats = need_min;
+  return (int)(floats * 4);
+}
+
+extern "C" int glh_destroy(glh_ctx* c) {
+  if (!c) return GLH_OK;
+  (void)hipSetDevice(c->cfg.device_id);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& e : c->pending) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  for (int o = 0; o < MAX_OBS; ++o) {
+    dfree(c->obs[o].cams);
+    for (auto& p : c->obs[o].owned) dfree(p);
+  }
+  for (int i = 0; i < 2; ++i) {
+    dfree(c->particles[i]);
+    dfree(c->weights[i]);
+  }
+  dfree(c->motion); dfree(c->uv); dfree(c->bbox_part); dfree(c->normals); dfree(c->u);
+  dfree(c->mean6); dfree(c->moments); dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
+  dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
+  dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search);
+  dfree(c->sse); dfree(c->sse_copy); dfree(c->lu); dfree(c->lu_off); dfree(c->leaf_off);
+  dfree(c->leaf_len); dfree(c->sum_prog);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GLH_OK;
+}
+
+extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
+  if (!cfg || !out) return fail(GLH_E_INVALID, "null argument");
+  *out = nullptr;
+  glh_config k = *cfg;
+  if (k.max_tile <= 0) k.max_tile = 31;
+  if (k.max_search_dim <= 0) k.max_search_dim = 320;
+  if (k.max_frames <= 0) k.max_frames = 128;
+  if (k.max_points <= 0 || k.max_particles <= 0 || k.n_observers <= 0 || k.n_observers > MAX_OBS)
+    return fail(GLH_E_INVALID, "max_points/max_particles must be > 0 and 1 <= n_observers <= %d", MAX_OBS);
+  if (k.max_tile < 5 || k.max_tile > 127) return fail(GLH_E_INVALID, "max_tile must be in [5, 127]");
+  if (k.max_search_dim < k.max_tile + 3 || k.max_search_dim > 2000)
+    return fail(GLH_E_INVALID, "max_search_dim must be in [max_tile + 3, 2000]");
+  if ((size_t)k.max_particles * 8 + 1024 > 150 * 1024)
+    return fail(GLH_E_UNSUPPORTED, "max_particles %d exceeds the LDS-resident scan (<= 19000)", k.max_particles);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (k.device_id < 0 || k.device_id >= ndev)
+    return fail(GLH_E_INVALID, "device_id %d out of range (%d devices)", k.device_id, ndev);
+  HIPCHK(hipSetDevice(k.device_id));
+  glh_ctx* c = new (std::nothrow) glh_ctx();
+  if (!c) return fail(GLH_E_NOMEM, "out of host memory");
+  c->cfg = k;
+  const size_t P = k.max_points, N = k.max_particles, O = k.n_observers;
+  c->tile_cap = k.max_tile * k.max_tile;
+  c->search_cap = k.max_search_dim * k.max_search_dim;
+  c->sse_cap = c->search_cap;
+  c->lds_ssd_bytes = ssd_lds_bytes(k.max_search_dim, k.max_tile);
+  const size_t NBmax = (N + BLK - 1) / BLK;
+  int rc = GLH_OK;
+  auto A = [&](int r) {
+    if (rc == GLH_OK) rc = r;
+  };
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(GLH_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < 2; ++i) {
+    A(dalloc(&c->particles[i], P * N * 6));
+    A(dalloc(&c->weights[i], P * N));
+  }
+  A(dalloc(&c->motion, P * GLH_MOTION_LEN));
+  A(dalloc(&c->uv, O * P * N * 2));
+  A(dalloc(&c->bbox_part, O * P * NBmax * 5));
+  A(dalloc(&c->u, P));
+  A(dalloc(&c->mean6, P * 6));
+  A(dalloc(&c->moments, (size_t)k.max_frames * P * 12));
+  A(dalloc(&c->obs_mask, P * O));
+  A(dalloc(&c->active, P));
+  A(dalloc(&c->pt_status, P));
+  A(dalloc(&c->pt_err_frame, P));
+  A(dalloc(&c->obs_status, O * P));
+  A(dalloc(&c->box, O * P * 4));
+  A(dalloc(&c->tmpl_box, O * P * 4));
+  A(dalloc(&c->tmpl_hist_n, O * P));
+  A(dalloc(&c->tmpl_valid, O * P));
+  A(dalloc(&c->tmpl_duv, O * P * 2));
+  A(dalloc(&c->tmpl_tile64, O * P * c->tile_cap));
+  A(dalloc(&c->tmpl_tile32, O * P * c->tile_cap));
+  A(dalloc(&c->tmpl_hist_v, O * P * c->tile_cap));
+  A(dalloc(&c->tmpl_hist_q, O * P * c->tile_cap));
+  A(dalloc(&c->search, O * P * (size_t)c->search_cap));
+  A(dalloc(&c->sse, O * P * (size_t)c->sse_cap));
+  // spline LU table for every surface side 4..max_search_dim
+  if (rc == GLH_OK) {
+    const int maxn = k.max_search_dim;
+    std::vector<int64_t> off(maxn + 1, 0);
+    int64_t total = 0;
+    for (int n = 4; n <= maxn; ++n) {
+      off[n] = total;
+      total += 5 * (int64_t)n;
+    }
+    std::vector<double> lu((size_t)total);
+    for (int n = 4; n <= maxn; ++n) spline_lu(n, lu.data() + off[n]);
+    A(dalloc(&c->lu, (size_t)total));
+    A(dalloc(&c->lu_off, (size_t)maxn + 1));
+    if (rc == GLH_OK) {
+      if (hipMemcpy(c->lu, lu.data(), total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(c->lu_off, off.data(), (maxn + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(GLH_E_HIP, "upload of the spline LU table failed");
+    }
+  }
+  if (rc == GLH_OK) {
+    // kernels that may use more than the default 64 KB of dynamic LDS
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+      rc = fail(GLH_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  }
+  if (rc != GLH_OK) {
+    std::string keep = g_err;
+    glh_destroy(c);
+    g_err = keep;
+    return rc;
+  }
+  *out = c;
+  return GLH_OK;
+}
+
+extern "C" int glh_sync(glh_ctx* c) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return GLH_OK;
+}
+
+extern "C" int glh_get_stream(glh_ctx* c, void** stream) {
+  if (!c || !stream) return fail(GLH_E_INVALID, "null argument");
+  *stream = (void*)c->stream;
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// observers
+// ------------------------------------------------------------------------------------------
+static int check_obs(glh_ctx* c, int o) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (o < 0 || o >= c->cfg.n_observers) return fail(GLH_E_INVALID, "observer %d out of range", o);
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_init(glh_ctx* c, int o, int n_images, int width, int height, int channels,
+                                 double sigma) {
+  CHK(check_obs(c, o));
+  if (n_images <= 0 || width <= 0 || height <= 0) return fail(GLH_E_INVALID, "bad observer geometry");
+  if (channels != 1 && channels != 3)
+    return fail(GLH_E_UNSUPPORTED, "frames must be uint8 with 1 or 3 channels (got %d)", channels);
+  if (!(sigma > 0.0)) return fail(GLH_E_INVALID, "sigma must be > 0");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  Observer& ob = c->obs[o];
+  dfree(ob.cams);
+  for (auto& p : ob.owned) dfree(p);
+  ob.n_images = n_images;
+  ob.width = width;
+  ob.height = height;
+  ob.channels = channels;
+  ob.sigma = sigma;
+  ob.frames.assign(n_images, nullptr);
+  ob.owned.assign(n_images, nullptr);
+  CHK(dalloc(&ob.cams, (size_t)n_images));
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_set_cameras(glh_ctx* c, int o, int first, int n, const double* cams) {
+  CHK(check_obs(c, o));
+  Observer& ob = c->obs[o];
+  if (!cams || first < 0 || n <= 0 || first + n > ob.n_images)
+    return fail(GLH_E_INVALID, "camera range [%d, %d) outside the observer's %d images", first, first + n, ob.n_images);
+  std::vector<CamDev> tmp(n);
+  for (int i = 0; i < n; ++i) {
+    expand_camera(cams + (size_t)i * GLH_CAM_LEN, &tmp[i]);
+    if ((int)tmp[i].imgsz[0] != ob.width || (int)tmp[i].imgsz[1] != ob.height)
+      return fail(GLH_E_INVALID, "camera imgsz (%g, %g) != frame size (%d, %d): resized reads are out of scope",
+                  tmp[i].imgsz[0], tmp[i].imgsz[1], ob.width, ob.height);
+  }
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  HIPCHK(hipMemcpyAsync(ob.cams + first, tmp.data(), n * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_upload_frame(glh_ctx* c, int o, int image, const uint8_t* pixels) {
+  CHK(check_obs(c, o));
+  Observer& ob = c->obs[o];
+  if (!pixels || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  size_t bytes = (size_t)ob.width * ob.height * ob.channels;
+  if (!ob.owned[image]) CHK(dalloc(&ob.owned[image], bytes));
+  HIPCHK(hipMemcpyAsync(ob.owned[image], pixels, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ob.frames[image] = ob.owned[image];
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_set_frame_device(glh_ctx* c, int o, int image, const void* dev) {
+  CHK(check_obs(c, o));
+  Observer& ob = c->obs[o];
+  if (!dev || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
+  dfree(ob.owned[image]);
+  ob.frames[image] = (const uint8_t*)dev;
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sequence state
+// ------------------------------------------------------------------------------------------
+extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (P <= 0 || P > c->cfg.max_points || N <= 0 || N > c->cfg.max_particles)
+    return fail(GLH_E_INVALID, "n_points %d / n_particles %d exceed the context capacity (%d, %d)", P, N,
+                c->cfg.max_points, c->cfg.max_particles);
+  if (tw < 5 || th < 5 || tw > c->cfg.max_tile || th > c->cfg.max_tile)
+    return fail(GLH_E_INVALID, "tile_size (%d, %d) must be in [5, max_tile=%d]", tw, th, c->cfg.max_tile);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  c->P = P;
+  c->N = N;
+  c->tw = tw;
+  c->th = th;
+  c->NB = (N + BLK - 1) / BLK;
+  c->cur = 0;
+  c->frame = 0;
+  c->have_mask = c->have_active = false;
+  const size_t O = c->cfg.n_observers;
+  HIPCHK(hipMemsetAsync(c->pt_status, 0, P * sizeof(uint32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->pt_err_frame, 0x7f, P * sizeof(int32_t), c->stream));
+  HIPCHK(hipMemsetAsync(c->tmpl_valid, 0, O * P * sizeof(int32_t), c->stream));
+  {
+    // GLH_OBS_SKIPPED everywhere
+    std::vector<int32_t> st(O * P, GLH_OBS_SKIPPED);
+    HIPCHK(hipMemcpyAsync(c->obs_status, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  size_t nm = (size_t)c->cfg.max_frames * P * 12;
+  hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->moments, nm, (double)NAN);
+  HIPCHK(hipGetLastError());
+  // NumPy pairwise-sum plan for this N
+  std::vector<int32_t> off, len;
+  std::vector<int16_t> prog;
+  pairwise_plan(N, off, len, prog);
+  dfree(c->leaf_off);
+  dfree(c->leaf_len);
+  dfree(c->sum_prog);
+  CHK(dalloc(&c->leaf_off, off.size()));
+  CHK(dalloc(&c->leaf_len, len.size()));
+  CHK(dalloc(&c->sum_prog, prog.size()));
+  HIPCHK(hipMemcpy(c->leaf_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->leaf_len, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->sum_prog, prog.data(), prog.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  c->nleaves = (int)off.size();
+  c->nprog = (int)prog.size();
+  return GLH_OK;
+}
+
+extern "C" int glh_set_frame(glh_ctx* c, int frame) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
+  c->frame = frame;
+  return GLH_OK;
+}
+
+static int need_seq(glh_ctx* c) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (c->P <= 0) return fail(GLH_E_STATE, "glh_begin_sequence has not been called");
+  return GLH_OK;
+}
+
+#define UPLOAD(dst, src, count, type)                                                                 \
+  do {                                                                                                \
+    HIPCHK(hipSetDevice(c->cfg.device_id));                                                           \
+    HIPCHK(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(type), hipMemcpyHostToDevice, c->stream)); \
+    HIPCHK(hipStreamSynchronize(c->stream));                                                          \
+  } while (0)
+#define DOWNLOAD(dst, src, count, type)                                                               \
+  do {                                                                                                \
+    HIPCHK(hipSetDevice(c->cfg.device_id));                                                           \
+    HIPCHK(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(type), hipMemcpyDeviceToHost, c->stream)); \
+    HIPCHK(hipStreamSynchronize(c->stream));                                                          \
+  } while (0)
+
+extern "C" int glh_set_motion_cartesian(glh_ctx* c, const double* params) {
+  CHK(need_seq(c));
+  if (!params) return fail(GLH_E_INVALID, "params is null");
+  UPLOAD(c->motion, params, (size_t)c->P * GLH_MOTION_LEN, double);
+  return GLH_OK;
+}
+extern "C" int glh_set_observer_mask(glh_ctx* c, const uint8_t* mask) {
+  CHK(need_seq(c));
+  c->have_mask = mask != nullptr;
+  if (mask) UPLOAD(c->obs_mask, mask, (size_t)c->P * c->cfg.n_observers, uint8_t);
+  return GLH_OK;
+}
+extern "C" int glh_set_active(glh_ctx* c, const uint8_t* active) {
+  CHK(need_seq(c));
+  c->have_active = active != nullptr;
+  if (active) UPLOAD(c->active, active, (size_t)c->P, uint8_t);
+  return GLH_OK;
+}
+extern "C" int glh_set_particles(glh_ctx* c, const double* p) {
+  CHK(need_seq(c));
+  if (!p) return fail(GLH_E_INVALID, "particles is null");
+  UPLOAD(c->particles[c->cur], p, (size_t)c->P * c->N * 6, double);
+  return GLH_OK;
+}
+extern "C" int glh_get_particles(glh_ctx* c, double* p) {
+  CHK(need_seq(c));
+  if (!p) return fail(GLH_E_INVALID, "particles is null");
+  DOWNLOAD(p, c->particles[c->cur], (size_t)c->P * c->N * 6, double);
+  return GLH_OK;
+}
+extern "C" int glh_set_weights(glh_ctx* c, const double* w) {
+  CHK(need_seq(c));
+  if (!w) return fail(GLH_E_INVALID, "weights is null");
+  UPLOAD(c->weights[c->cur], w, (size_t)c->P * c->N, double);
+  return GLH_OK;
+}
+extern "C" int glh_get_weights(glh_ctx* c, double* w) {
+  CHK(need_seq(c));
+  if (!w) return fail(GLH_E_INVALID, "weights is null");
+  DOWNLOAD(w, c->weights[c->cur], (size_t)c->P * c->N, double);
+  return GLH_OK;
+}
+extern "C" int glh_get_point_status(glh_ctx* c, uint32_t* st) {
+  CHK(need_seq(c));
+  if (!st) return fail(GLH_E_INVALID, "status is null");
+  DOWNLOAD(st, c->pt_status, (size_t)c->P, uint32_t);
+  return GLH_OK;
+}
+extern "C" int glh_get_point_error_frame(glh_ctx* c, int32_t* fr) {
+  CHK(need_seq(c));
+  if (!fr) return fail(GLH_E_INVALID, "frames is null");
+  DOWNLOAD(fr, c->pt_err_frame, (size_t)c->P, int32_t);
+  return GLH_OK;
+}
+extern "C" int glh_get_observer_status(glh_ctx* c, int32_t* st) {
+  CHK(need_seq(c));
+  if (!st) return fail(GLH_E_INVALID, "status is null");
+  DOWNLOAD(st, c->obs_status, (size_t)c->cfg.n_observers * c->P, int32_t);
+  return GLH_OK;
+}
+extern "C" int glh_get_resample_indices(glh_ctx* c, int32_t* idx) {
+  CHK(need_seq(c));
+  if (!idx || !c->idx) return fail(GLH_E_STATE, "index capture is off (glh_set_debug)");
+  DOWNLOAD(idx, c->idx, (size_t)c->P * c->N, int32_t);
+  return GLH_OK;
+}
+
+extern "C" int glh_set_debug(glh_ctx* c, int keep) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  c->keep_sse = keep != 0;
+  c->keep_idx = keep != 0;
+  if (keep) {
+    if (!c->sse_copy)
+      CHK(dalloc(&c->sse_copy, (size_t)c->cfg.n_observers * c->cfg.max_points * (size_t)c->sse_cap));
+    if (!c->idx) CHK(dalloc(&c->idx, (size_t)c->cfg.max_points * c->cfg.max_particles));
+  }
+  return GLH_OK;
+}
+
+// staging of host-fed random numbers (parity mode)
+static int stage_normals(glh_ctx* c, const double* host, size_t count) {
+  if (count > c->normals_cap) {
+    dfree(c->normals);
+    CHK(dalloc(&c->normals, count));
+    c->normals_cap = count;
+  }
+  HIPCHK(hipMemcpyAsync(c->normals, host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // the host buffer may be reused by the caller right away
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stages
+// ------------------------------------------------------------------------------------------
+extern "C" int glh_init_particles(glh_ctx* c, int rng_mode, const double* normals, uint64_t seed) {
+  CHK(need_seq(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (rng_mode == GLH_RNG_HOST) {
+    if (!normals) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs normals [P][N][6]");
+    CHK(stage_normals(c, normals, (size_t)c->P * c->N * 6));
+  } else if (rng_mode != GLH_RNG_PHILOX) {
+    return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
+  }
+  InitArgs a{};
+  a.particles = c->particles[c->cur];
+  a.weights = c->weights[c->cur];
+  a.motion = c->motion;
+  a.active = c->have_active ? c->active : nullptr;
+  a.normals = c->normals;
+  a.seed = seed;
+  a.rng_mode = rng_mode;
+  a.N = c->N;
+  {
+    StageTimer t(c, ST_INIT);
+    hipLaunchKernelGGL(k_init_particles, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+static void fill_obs(glh_ctx* c, int o, int image, ObsFrame* f) {
+  const Observer& ob = c->obs[o];
+  f->on = image >= 0;
+  f->cam = ob.cams + (image >= 0 ? image : 0);
+  f->frame = image >= 0 ? ob.frames[image] : nullptr;
+  f->width = ob.width;
+  f->height = ob.height;
+  f->channels = ob.channels;
+}
+
+static int check_images(glh_ctx* c, const int32_t* images) {
+  if (!images) return fail(GLH_E_INVALID, "images is null");
+  for (int o = 0; o < c->cfg.n_observers; ++o) {
+    if (images[o] < 0) continue;
+    const Observer& ob = c->obs[o];
+    if (images[o] >= ob.n_images) return fail(GLH_E_INVALID, "observer %d: image %d out of range", o, images[o]);
+    if (!ob.frames[images[o]]) return fail(GLH_E_STATE, "observer %d: image %d has not been uploaded", o, images[o]);
+  }
+  return GLH_OK;
+}
+
+// evolve (optional) + project into the given images + bbox partials
+static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng_mode, uint64_t seed,
+                                 uint64_t step, const int32_t* images) {
+  EvolveArgs a{};
+  a.particles = c->particles[c->cur];
+  a.motion = c->motion;
+  a.active = c->have_active ? c->active : nullptr;
+  a.obs_mask = c->have_mask ? c->obs_mask : nullptr;
+  a.normals = c->normals;
+  a.uv = c->uv;
+  a.bbox_part = c->bbox_part;
+  a.pt_status = c->pt_status;
+  a.pt_err_frame = c->pt_err_frame;
+  a.seed = seed;
+  a.step = step;
+  a.tau = tau;
+  a.do_evolve = do_evolve;
+  a.rng_mode = rng_mode;
+  a.N = c->N;
+  a.P = c->P;
+  a.O = c->cfg.n_observers;
+  a.NB = c->NB;
+  a.frame = c->frame;
+  for (int o = 0; o < a.O; ++o) fill_obs(c, o, images ? images[o] : -1, &a.obs[o]);
+  {
+    StageTimer t(c, ST_EVOLVE_PROJECT);
+    hipLaunchKernelGGL(k_evolve_project, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+extern "C" int glh_evolve(glh_ctx* c, double tau, int rng_mode, const double* normals, uint64_t seed,
+                          uint64_t step) {
+  CHK(need_seq(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (rng_mode == GLH_RNG_HOST) {
+    if (!normals) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs normals [P][N][3]");
+    CHK(stage_normals(c, normals, (size_t)c->P * c->N * 3));
+  } else if (rng_mode != GLH_RNG_PHILOX) {
+    return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
+  }
+  return launch_evolve_project(c, true, tau, rng_mode, seed, step, nullptr);
+}
+
+static int launch_moments(glh_ctx* c, double* out, int ld, int with_sigma) {
+  MomentsArgs a{};
+  a.particles = c->particles[c->cur];
+  a.weights = c->weights[c->cur];
+  a.active = c->have_active ? c->active : nullptr;
+  a.out = out;
+  a.N = c->N;
+  a.ld = ld;
+  a.with_sigma = with_sigma;
+  {
+    StageTimer t(c, ST_MOMENTS);
+    hipLaunchKernelGGL(k_moments, dim3(c->P), dim3(BLK), 0, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
+  CHK(need_seq(c));
+  CHK(check_obs(c, o));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const Observer& ob = c->obs[o];
+  if (image < 0 || image >= ob.n_images || !ob.frames[image])
+    return fail(GLH_E_STATE, "observer %d: image %d is not resident", o, image);
+  CHK(launch_moments(c, c->mean6, 6, 0));  // particle_mean with the carried weights (tracker.py:548)
+  TemplateArgs a{};
+  a.mean6 = c->mean6;
+  a.active = c->have_active ? c->active : nullptr;
+  a.obs_mask = c->have_mask ? c->obs_mask : nullptr;
+  fill_obs(c, o, image, &a.obs);
+  a.o = o;
+  a.O = c->cfg.n_observers;
+  a.P = c->P;
+  a.tw = c->tw;
+  a.th = c->th;
+  a.tile_cap = c->tile_cap;
+  a.frame = c->frame;
+  a.tmpl_box = c->tmpl_box;
+  a.tmpl_duv = c->tmpl_duv;
+  a.tmpl_tile64 = c->tmpl_tile64;
+  a.tmpl_tile32 = c->tmpl_tile32;
+  a.tmpl_hist_v = c->tmpl_hist_v;
+  a.tmpl_hist_q = c->tmpl_hist_q;
+  a.tmpl_hist_n = c->tmpl_hist_n;
+  a.tmpl_valid = c->tmpl_valid;
+  a.pt_status = c->pt_status;
+  a.pt_err_frame = c->pt_err_frame;
+  {
+    StageTimer t(c, ST_TEMPLATE);
+    hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK), (size_t)c->tw * c->th * sizeof(uint16_t),
+                       c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected) {
+  const int O = c->cfg.n_observers;
+  // uv + bbox of the (already evolved) particles in the matched images
+  if (!projected) CHK(launch_evolve_project(c, false, 0.0, GLH_RNG_PHILOX, 0, 0, images));
+  for (int o = 0; o < O; ++o) {
+    if (images[o] < 0) continue;
+    TilePrepArgs tp{};
+    tp.active = c->have_active ? c->active : nullptr;
+    tp.obs_mask = c->have_mask ? c->obs_mask : nullptr;
+    fill_obs(c, o, images[o], &tp.obs);
+    tp.o = o;
+    tp.O = O;
+    tp.P = c->P;
+    tp.NB = c->NB;
+    tp.tw = c->tw;
+    tp.th = c->th;
+    tp.tile_cap = c->tile_cap;
+    tp.search_cap = c->search_cap;
+    tp.max_dim = c->cfg.max_search_dim;
+    tp.bbox_part = c->bbox_part;
+    tp.tmpl_valid = c->tmpl_valid;
+    tp.tmpl_hist_v = c->tmpl_hist_v;
+    tp.tmpl_hist_q = c->tmpl_hist_q;
+    tp.tmpl_hist_n = c->tmpl_hist_n;
+    tp.box = c->box;
+    tp.obs_status = c->obs_status;
+    tp.search = c->search;
+    {
+      StageTimer t(c, ST_TILEPREP);
+      size_t lds = (size_t)(BAND_H + 4) * c->cfg.max_search_dim * sizeof(uint16_t);
+      hipLaunchKernelGGL(k_tileprep, dim3(c->P), dim3(BLK), lds, c->stream, tp);
+    }
+    HIPCHK(hipGetLastError());
+    SsdArgs sa{};
+    sa.o = o;
+    sa.P = c->P;
+    sa.tw = c->tw;
+    sa.th = c->th;
+    sa.tile_cap = c->tile_cap;
+    sa.search_cap = c->search_cap;
+    sa.sse_cap = c->sse_cap;
+    sa.lds_floats = c->lds_ssd_bytes / 4;
+    sa.box = c->box;
+    sa.obs_status = c->obs_status;
+    sa.search = c->search;
+    sa.tmpl = c->tmpl_tile32;
+    sa.sse = c->sse;
+    {
+      StageTimer t(c, ST_SSD);
+      hipLaunchKernelGGL(k_ssd, dim3(8, c->P), dim3(BLK), (size_t)c->lds_ssd_bytes, c->stream, sa);
+    }
+    HIPCHK(hipGetLastError());
+    SplineFitArgs sf{};
+    sf.o = o;
+    sf.P = c->P;
+    sf.tw = c->tw;
+    sf.th = c->th;
+    sf.sse_cap = c->sse_cap;
+    sf.max_n = c->cfg.max_search_dim;
+    sf.box = c->box;
+    sf.obs_status = c->obs_status;
+    sf.lu = c->lu;
+    sf.lu_off = c->lu_off;
+    sf.sse = c->sse;
+    sf.sse_copy = c->keep_sse ? c->sse_copy : nullptr;
+    {
+      StageTimer t(c, ST_SPLINE_FIT);
+      hipLaunchKernelGGL(k_spline_fit, dim3(c->P), dim3(BLK), 0, c->stream, sf);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  WeightArgs wa{};
+  wa.particles = c->particles[c->cur];
+  wa.weights = c->weights[c->cur];
+  wa.motion = c->motion;
+  wa.active = c->have_active ? c->active : nullptr;
+  wa.uv = c->uv;
+  wa.box = c->box;
+  wa.obs_status = c->obs_status;
+  wa.tmpl_duv = c->tmpl_duv;
+  wa.coef = c->sse;
+  wa.pt_status = c->pt_status;
+  wa.pt_err_frame = c->pt_err_frame;
+  for (int o = 0; o < O; ++o) {
+    wa.on[o] = images[o] >= 0;
+    wa.inv2s2[o] = 1.0 / (2.0 * (c->obs[o].sigma * c->obs[o].sigma));  // 1 / (2 * sigma ** 2)
+  }
+  wa.N = c->N;
+  wa.P = c->P;
+  wa.O = O;
+  wa.tw = c->tw;
+  wa.th = c->th;
+  wa.sse_cap = c->sse_cap;
+  wa.frame = c->frame;
+  {
+    StageTimer t(c, ST_WEIGHTS);
+    hipLaunchKernelGGL(k_weights, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, wa);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+extern "C" int glh_update_weights(glh_ctx* c, const int32_t* images) {
+  CHK(need_seq(c));
+  CHK(check_images(c, images));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  return update_weights_impl(c, images, false);
+}
+
+extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t seed, uint64_t step) {
+  CHK(need_seq(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (rng_mode == GLH_RNG_HOST) {
+    if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u [P]");
+    HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  } else if (rng_mode != GLH_RNG_PHILOX) {
+    return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
+  }
+  ResampleArgs a{};
+  a.particles_in = c->particles[c->cur];
+  a.weights_in = c->weights[c->cur];
+  a.particles_out = c->particles[c->cur ^ 1];
+  a.weights_out = c->weights[c->cur ^ 1];
+  a.active = c->have_active ? c->active : nullptr;
+  a.u = c->u;
+  a.idx_out = c->keep_idx ? c->idx : nullptr;
+  a.pt_status = c->pt_status;
+  a.pt_err_frame = c->pt_err_frame;
+  a.leaf_off = c->leaf_off;
+  a.leaf_len = c->leaf_len;
+  a.sum_prog = c->sum_prog;
+  a.seed = seed;
+  a.step = step;
+  a.N = c->N;
+  a.nleaves = c->nleaves;
+  a.nprog = c->nprog;
+  a.rng_mode = rng_mode;
+  a.frame = c->frame;
+  if (c->have_active) {
+    // inactive points keep their state: copy their rows across before swapping buffers
+    HIPCHK(hipMemcpyAsync(c->particles[c->cur ^ 1], c->particles[c->cur], (size_t)c->P * c->N * 6 * sizeof(double),
+                          hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->weights[c->cur ^ 1], c->weights[c->cur], (size_t)c->P * c->N * sizeof(double),
+                          hipMemcpyDeviceToDevice, c->stream));
+  }
+  {
+    StageTimer t(c, ST_RESAMPLE);
+    size_t lds = ((size_t)c->N + c->nleaves) * sizeof(double);
+    hipLaunchKernelGGL(k_resample, dim3(c->P), dim3(BLK), lds, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  c->cur ^= 1;
+  return GLH_OK;
+}
+
+extern "C" int glh_record_moments(glh_ctx* c, int frame) {
+  CHK(need_seq(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
+  return launch_moments(c, c->moments + (size_t)frame * c->P * 12, 12, 1);
+}
+
+extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images, int rng_mode,
+                        const double* normals, const double* u, uint64_t seed) {
+  CHK(need_seq(c));
+  CHK(glh_set_frame(c, frame));
+  CHK(check_images(c, images));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (rng_mode == GLH_RNG_HOST) {
+    if (!normals) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs normals [P][N][3]");
+    CHK(stage_normals(c, normals, (size_t)c->P * c->N * 3));
+  } else if (rng_mode != GLH_RNG_PHILOX) {
+    return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
+  }
+  // one pass over the particle state: evolve, NaN test, project, bbox partials
+  CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images));
+  CHK(update_weights_impl(c, images, true));
+  CHK(glh_resample(c, rng_mode, u, seed, (uint64_t)frame));
+  return glh_record_moments(c, frame);
+}
+
+// ------------------------------------------------------------------------------------------
+// results
+// ------------------------------------------------------------------------------------------
+extern "C" int glh_get_moments(glh_ctx* c, int frame0, int n_frames, double* out) {
+  CHK(need_seq(c));
+  if (!out || frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames)
+    return fail(GLH_E_INVALID, "bad frame range");
+  DOWNLOAD(out, c->moments + (size_t)frame0 * c->P * 12, (size_t)n_frames * c->P * 12, double);
+  return GLH_OK;
+}
+
+extern "C" int glh_get_moments_device(glh_ctx* c, void** p, uint64_t* bytes) {
+  CHK(need_seq(c));
+  if (!p || !bytes) return fail(GLH_E_INVALID, "null argument");
+  *p = c->moments;
+  *bytes = (uint64_t)c->cfg.max_frames * c->P * 12 * sizeof(double);
+  return GLH_OK;
+}
+
+extern "C" int glh_get_template(glh_ctx* c, int o, int pt, int32_t* box, double* duv, double* tile,
+                                double* hv, double* hq, int32_t* hn) {
+  CHK(need_seq(c));
+  CHK(check_obs(c, o));
+  if (pt < 0 || pt >= c->P) return fail(GLH_E_INVALID, "point %d out of range", pt);
+  const size_t slot = (size_t)o * c->P + pt;
+  int32_t valid = 0;
+  DOWNLOAD(&valid, c->tmpl_valid + slot, 1, int32_t);
+  if (!valid) return fail(GLH_E_STATE, "no template for observer %d, point %d", o, pt);
+  int32_t n = 0;
+  DOWNLOAD(&n, c->tmpl_hist_n + slot, 1, int32_t);
+  if (hn) *hn = n;
+  if (box) DOWNLOAD(box, c->tmpl_box + slot * 4, 4, int32_t);
+  if (duv) DOWNLOAD(duv, c->tmpl_duv + slot * 2, 2, double);
+  if (tile) DOWNLOAD(tile, c->tmpl_tile64 + slot * c->tile_cap, (size_t)c->tw * c->th, double);
+  if (hv) DOWNLOAD(hv, c->tmpl_hist_v + slot * c->tile_cap, (size_t)n, double);
+  if (hq) DOWNLOAD(hq, c->tmpl_hist_q + slot * c->tile_cap, (size_t)n, double);
+  return GLH_OK;
+}
+
+extern "C" int glh_get_likelihood_debug(glh_ctx* c, int o, int pt, double* uv, int32_t* box, float* search,
+                                        double* sse) {
+  CHK(need_seq(c));
+  CHK(check_obs(c, o));
+  if (pt < 0 || pt >= c->P) return fail(GLH_E_INVALID, "point %d out of range", pt);
+  const size_t slot = (size_t)o * c->P + pt;
+  int32_t st = 0;
+  DOWNLOAD(&st, c->obs_status + slot, 1, int32_t);
+  if (uv) DOWNLOAD(uv, c->uv + slot * c->N * 2, (size_t)c->N * 2, double);
+  if (st != GLH_OBS_OK) {
+    if (box) box[0] = box[1] = box[2] = box[3] = -1;
+    return GLH_OK;
+  }
+  int32_t b[4];
+  DOWNLOAD(b, c->box + slot * 4, 4, int32_t);
+  if (box) memcpy(box, b, sizeof b);
+  const int ws = b[2] - b[0], hs = b[3] - b[1];
+  if (search) DOWNLOAD(search, c->search + slot * (size_t)c->search_cap, (size_t)ws * hs, float);
+  if (sse) {
+    if (!c->keep_sse || !c->sse_copy) return fail(GLH_E_STATE, "SSE capture is off (glh_set_debug)");
+    DOWNLOAD(sse, c->sse_copy + slot * (size_t)c->sse_cap, (size_t)(ws - c->tw + 1) * (hs - c->th + 1), double);
+  }
+  return GLH_OK;
+}
+
+extern "C" int glh_profile_enable(glh_ctx* c, int on) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  CHK(drain_profile(c));
+  c->profiling = on != 0;
+  return GLH_OK;
+}
+extern "C" int glh_profile_reset(glh_ctx* c) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  CHK(drain_profile(c));
+  for (int i = 0; i < ST_COUNT; ++i) {
+    c->ms[i] = 0;
+    c->launches[i] = 0;
+  }
+  return GLH_OK;
+}
+extern "C" int glh_profile_get(glh_ctx* c, double* ms, int64_t* launches) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  CHK(drain_profile(c));
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (ms) ms[i] = c->ms[i];
+    if (launches) launches[i] = c->launches[i];
+  }
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stateless stage hooks (parity tests): explicit inputs -> one kernel -> outputs
+// ------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(GLH_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GLH_OK;
+  }
+  int up(const void* src, size_t bytes) {
+    CHK(alloc(bytes));
+    HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    return GLH_OK;
+  }
+  int down(void* dst, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+    return GLH_OK;
+  }
+  template <typename T>
+  T* as() {
+    return (T*)p;
+  }
+};
+int finish() {
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return GLH_OK;
+}
+}  // namespace
+
+extern "C" int glh_stage_project(int dev, const double* cam, const double* xyz, int n, double* uv) {
+  if (!cam || !xyz || !uv || n <= 0) return fail(GLH_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(dev));
+  CamDev cd;
+  expand_camera(cam, &cd);
+  DevBuf dc, dx, du;
+  CHK(dc.up(&cd, sizeof cd));
+  CHK(dx.up(xyz, (size_t)n * 3 * sizeof(double)));
+  CHK(du.alloc((size_t)n * 2 * sizeof(double)));
+  hipLaunchKernelGGL(k_project_points, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, dc.as<CamDev>(),
+                     dx.as<double>(), n, du.as<double>());
+  CHK(finish());
+  return du.down(uv, (size_t)n * 2 * sizeof(double));
+}
+
+static int check_box(const int32_t* box, int width, int height) {
+  if (!box || box[0] < 0 || box[1] < 0 || box[2] > width || box[3] > height || box[2] <= box[0] || box[3] <= box[1])
+    return fail(GLH_E_INVALID, "box outside the frame");
+  return GLH_OK;
+}
+
+extern "C" int glh_stage_template(int dev, const uint8_t* frame, int width, int height, int channels,
+                                  const int32_t* box, double* tile, double* hv, double* hq, int32_t* hn) {
+  if (!frame || !tile || !hv || !hq || !hn) return fail(GLH_E_INVALID, "null argument");
+  if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
+  CHK(check_box(box, width, height));
+  HIPCHK(hipSetDevice(dev));
+  const size_t n = (size_t)(box[2] - box[0]) * (box[3] - box[1]);
+  if (n * 2 > 60000) return fail(GLH_E_INVALID, "template too large for the test hook");
+  DevBuf df, t64, t32, dv, dq, dn;
+  CHK(df.up(frame, (size_t)width * height * channels));
+  CHK(t64.alloc(n * 8)); CHK(t32.alloc(n * 4)); CHK(dv.alloc(n * 8)); CHK(dq.alloc(n * 8)); CHK(dn.alloc(4));
+  TemplateBoxArgs a{};
+  a.frame = df.as<uint8_t>();
+  a.width = width;
+  a.channels = channels;
+  for (int k = 0; k < 4; ++k) a.box[k] = box[k];
+  a.out.tile64 = t64.as<double>();
+  a.out.tile32 = t32.as<float>();
+  a.out.hist_v = dv.as<double>();
+  a.out.hist_q = dq.as<double>();
+  a.out.hist_n = dn.as<int32_t>();
+  hipLaunchKernelGGL(k_template_from_box, dim3(1), dim3(BLK), n * sizeof(uint16_t), 0, a);
+  CHK(finish());
+  CHK(dn.down(hn, 4));
+  CHK(t64.down(tile, n * 8));
+  CHK(dv.down(hv, (size_t)*hn * 8));
+  return dq.down(hq, (size_t)*hn * 8);
+}
+
+extern "C" int glh_stage_search_tile(int dev, const uint8_t* frame, int width, int height, int channels,
+                                     const int32_t* box, const double* hv, const double* hq, int hn, float* tile) {
+  if (!frame || !tile || !hv || !hq || hn <= 0) return fail(GLH_E_INVALID, "bad argument");
+  if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
+  CHK(check_box(box, width, height));
+  HIPCHK(hipSetDevice(dev));
+  const int w = box[2] - box[0], h = box[3] - box[1];
+  const size_t n = (size_t)w * h;
+  if ((size_t)(BAND_H + 4) * w * 2 > 60000) return fail(GLH_E_INVALID, "tile too wide for the test hook");
+  DevBuf df, dv, dq, dout;
+  CHK(df.up(frame, (size_t)width * height * channels));
+  CHK(dv.up(hv, (size_t)hn * 8));
+  CHK(dq.up(hq, (size_t)hn * 8));
+  CHK(dout.alloc(n * 4));
+  SearchBoxArgs a{};
+  a.frame = df.as<uint8_t>();
+  a.width = width;
+  a.channels = channels;
+  for (int k = 0; k < 4; ++k) a.box[k] = box[k];
+  a.hist_v = dv.as<double>();
+  a.hist_q = dq.as<double>();
+  a.hist_n = hn;
+  a.out = dout.as<float>();
+  hipLaunchKernelGGL(k_search_from_box, dim3(1), dim3(BLK), (size_t)(BAND_H + 4) * w * sizeof(uint16_t), 0, a);
+  CHK(finish());
+  return dout.down(tile, n * 4);
+}
+
+extern "C" int glh_stage_ssd(int dev, const float* search, int hs, int ws, const float* templ, int th, int tw,
+                             float* sse) {
+  if (!search || !templ || !sse || th <= 0 || tw <= 0 || hs < th || ws < tw) return fail(GLH_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(dev));
+  const int ho = hs - th + 1, wo = ws - tw + 1;
+  if ((wo + SSD_W - 1) / SSD_W > BLK) return fail(GLH_E_INVALID, "surface too wide");
+  DevBuf ds, dt, dbox, dst, dout;
+  CHK(ds.up(search, (size_t)hs * ws * 4));
+  CHK(dt.up(templ, (size_t)th * tw * 4));
+  int32_t box[4] = {0, 0, ws, hs};
+  int32_t st = GLH_OBS_OK;
+  CHK(dbox.up(box, sizeof box));
+  CHK(dst.up(&st, sizeof st));
+  CHK(dout.alloc((size_t)ho * wo * 8));
+  SsdArgs a{};
+  a.o = 0;
+  a.P = 1;
+  a.tw = tw;
+  a.th = th;
+  a.tile_cap = th * tw;
+  a.search_cap = hs * ws;
+  a.sse_cap = ho * wo;
+  int lds = ssd_lds_bytes(ws, th > tw ? th : tw);
+  a.lds_floats = lds / 4;
+  a.box = dbox.as<int32_t>();
+  a.obs_status = dst.as<int32_t>();
+  a.search = ds.as<float>();
+  a.tmpl = dt.as<float>();
+  a.sse = dout.as<double>();
+  hipLaunchKernelGGL(k_ssd, dim3(8, 1), dim3(BLK), (size_t)lds, 0, a);
+  CHK(finish());
+  std::vector<double> tmp((size_t)ho * wo);
+  CHK(dout.down(tmp.data(), tmp.size() * 8));
+  for (size_t i = 0; i < tmp.size(); ++i) sse[i] = (float)tmp[i];  // exact: values are float32 widened
+  return GLH_OK;
+}
+
+extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const double* box, const double* uv, int n,
+                                double* values, uint8_t* outside) {
+  if (!sse || !box || !uv || !values || !outside || ho < 4 || wo < 4 || n <= 0) return fail(GLH_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(dev));
+  const int maxn = ho > wo ? ho : wo;
+  std::vector<int64_t> off(maxn + 1, 0);
+  std::vector<double> lu;
+  for (int m : {ho, wo}) {
+    off[m] = (int64_t)lu.size();
+    lu.resize(lu.size() + 5 * (size_t)m);
+    spline_lu(m, lu.data() + off[m]);
+  }
+  std::vector<double> z((size_t)ho * wo);
+  for (size_t i = 0; i < z.size(); ++i) z[i] = (double)sse[i];
+  DevBuf dz, dlu, doff, dbox, dst, duv, dval, dout;
+  CHK(dz.up(z.data(), z.size() * 8));
+  CHK(dlu.up(lu.data(), lu.size() * 8));
+  CHK(doff.up(off.data(), off.size() * 8));
+  // k_spline_fit derives (wo, ho) from box and (tw, th): use tw = th = 1
+  int32_t ibox[4] = {0, 0, wo, ho};
+  int32_t st = GLH_OBS_OK;
+  CHK(dbox.up(ibox, sizeof ibox));
+  CHK(dst.up(&st, sizeof st));
+  SplineFitArgs sf{};
+  sf.o = 0; sf.P = 1; sf.tw = 1; sf.th = 1; sf.sse_cap = ho * wo; sf.max_n = maxn;
+  sf.box = dbox.as<int32_t>();
+  sf.obs_status = dst.as<int32_t>();
+  sf.lu = dlu.as<double>();
+  sf.lu_off = doff.as<int64_t>();
+  sf.sse = dz.as<double>();
+  sf.sse_copy = nullptr;
+  hipLaunchKernelGGL(k_spline_fit, dim3(1), dim3(BLK), 0, 0, sf);
+  CHK(duv.up(uv, (size_t)n * 16));
+  CHK(dval.alloc((size_t)n * 8));
+  CHK(dout.alloc((size_t)n));
+  SampleArgs sa{};
+  sa.coef = dz.as<double>();
+  sa.ho = ho; sa.wo = wo; sa.n = n;
+  for (int k = 0; k < 4; ++k) sa.sb[k] = box[k];
+  sa.uv = duv.as<double>();
+  sa.values = dval.as<double>();
+  sa.outside = dout.as<uint8_t>();
+  hipLaunchKernelGGL(k_sample, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, sa);
+  CHK(finish());
+  CHK(dval.down(values, (size_t)n * 8));
+  return dout.down(outside, (size_t)n);
+}
+
+extern "C" int glh_stage_resample(int dev, const double* weights, int n, double u, int64_t* idx) {
+  if (!weights || !idx || n <= 0) return fail(GLH_E_INVALID, "bad argument");
+  if ((size_t)n * 8 + 1024 > 150 * 1024) return fail(GLH_E_UNSUPPORTED, "n too large for the LDS-resident scan");
+  HIPCHK(hipSetDevice(dev));
+  std::vector<int32_t> off, len;
+  std::vector<int16_t> prog;
+  pairwise_plan(n, off, len, prog);
+  std::vector<double> pin((size_t)n * 6, 0.0);
+  DevBuf dw, dpi, dpo, dwo, du, didx, dst, def, doff, dlen, dprog;
+  CHK(dw.up(weights, (size_t)n * 8));
+  CHK(dpi.up(pin.data(), pin.size() * 8));
+  CHK(dpo.alloc(pin.size() * 8));
+  CHK(dwo.alloc((size_t)n * 8));
+  CHK(du.up(&u, 8));
+  CHK(didx.alloc((size_t)n * 4));
+  uint32_t st0 = 0;
+  int32_t ef = 0x7f7f7f7f;
+  CHK(dst.up(&st0, 4));
+  CHK(def.up(&ef, 4));
+  CHK(doff.up(off.data(), off.size() * 4));
+  CHK(dlen.up(len.data(), len.size() * 4));
+  CHK(dprog.up(prog.data(), prog.size() * 2));
+  ResampleArgs a{};
+  a.particles_in = dpi.as<double>();
+  a.weights_in = dw.as<double>();
+  a.particles_out = dpo.as<double>();
+  a.weights_out = dwo.as<double>();
+  a.active = nullptr;
+  a.u = du.as<double>();
+  a.idx_out = didx.as<int32_t>();
+  a.pt_status = dst.as<uint32_t>();
+  a.pt_err_frame = def.as<int32_t>();
+  a.leaf_off = doff.as<int32_t>();
+  a.leaf_len = dlen.as<int32_t>();
+  a.sum_prog = dprog.as<int16_t>();
+  a.N = n;
+  a.nleaves = (int)off.size();
+  a.nprog = (int)prog.size();
+  a.rng_mode = GLH_RNG_HOST;
+  a.frame = 0;
+  hipLaunchKernelGGL(k_resample, dim3(1), dim3(BLK), ((size_t)n + off.size()) * 8, 0, a);
+  CHK(finish());
+  std::vector<int32_t> tmp(n);
+  CHK(didx.down(tmp.data(), (size_t)n * 4));
+  for (int i = 0; i < n; ++i) idx[i] = tmp[i];
+  return GLH_OK;
+}

@@ -1,0 +1,214 @@
+/*
+ * glimpse_hip.h -- C ABI of libglimpse_hip.so, the MI355X (gfx950) implementation of
+ * the glimpse.Tracker particle-filter hot path.
+ *
+ * The reference (ezwelty/glimpse 0.1.1) is pure Python and has NO FFI layer; its
+ * replaceable seams are Python duck types.  This header is
+ * therefore the interface a maintainer would bind with ctypes;
+ * every entry point cites the reference function whose work it takes over.
+ * Citations are relative to /root/reference/src/glimpse/.
+ *
+ * Conventions
+ *  - plain C: opaque context, raw pointers and sizes, no C++/torch types;
+ *  - every function returns an int status: GLH_OK (0) or a negative GLH_E_* code;
+ *    `glh_last_error()` returns a human-readable message for the calling thread;
+ *  - host buffers are caller-owned, device buffers are library-owned;
+ *  - one host thread per context; every call enqueues on the context's HIP stream,
+ *    only `glh_get_*`, `glh_sync` and the `glh_stage_*` test hooks block;
+ *  - array layouts are C-contiguous, doubles unless stated:
+ *      particles [P][N][6]  (x, y, z, vx, vy, vz)   -- Tracker.particles, track/tracker.py:35
+ *      weights   [P][N]                              -- Tracker.weights,   track/tracker.py:37
+ *      cameras   [n][GLH_CAM_LEN]                    -- Camera._vector[20] (camera.py:101) + correction
+ *      moments   [P][12] = mean(6) | sigma(6)        -- track/tracker.py:350-354
+ */
+#ifndef GLIMPSE_HIP_H
+#define GLIMPSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLH_VERSION 100
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define GLH_OK 0
+#define GLH_E_INVALID (-1)   /* bad argument / size mismatch                              */
+#define GLH_E_HIP (-2)       /* a HIP runtime call failed                                 */
+#define GLH_E_NOMEM (-3)     /* host or device allocation failed                          */
+#define GLH_E_STATE (-4)     /* call sequence error (e.g. step before templates)          */
+#define GLH_E_UNSUPPORTED (-5)
+
+/* ---- camera vector ------------------------------------------------------------------ */
+/* [0:3] xyz  [3:6] viewdir(deg)  [6:8] imgsz  [8:10] f  [10:12] c  [12:18] k1..k6
+ * [18:20] p1,p2   -- exactly Camera._vector (camera.py:101, :128-198) --
+ * [20] correction flag  [21] radius  [22] refraction (camera.py:118-121)  [23] unused     */
+#define GLH_CAM_LEN 24
+
+/* ---- motion parameters (CartesianMotion, track/motion.py:121-147) ------------------- */
+/* [0:2] xy [2:4] xy_sigma [4:7] vxyz [7:10] vxyz_sigma [10:13] axyz [13:16] axyz_sigma
+ * [16] dem (constant surface) [17] dem_sigma (constant)                                   */
+#define GLH_MOTION_LEN 18
+
+/* ---- per-point status bits (sticky; the Python Tracker turns them into Tracks.errors) */
+#define GLH_PT_NAN 1u            /* ValueError "missing (NaN) values"      tracker.py:118  */
+#define GLH_PT_TEMPLATE_OOB 2u   /* IndexError "Box extends beyond grid"   raster.py:417   */
+#define GLH_PT_SAMPLE_OUTSIDE 4u /* ValueError "sampling points outside"   observer.py:201 */
+#define GLH_PT_RESAMPLE_CLAMP 8u /* searchsorted returned n (IndexError in the reference)  */
+#define GLH_PT_CONST_TILE 16u    /* zero-variance template tile (reference yields NaNs)    */
+
+/* ---- per-(observer, point) status of the last likelihood evaluation ------------------ */
+#define GLH_OBS_OK 0
+#define GLH_OBS_SKIPPED 1      /* img is None or observer masked         tracker.py:577    */
+#define GLH_OBS_OUT_OF_BOUNDS 2 /* warning + skip                        tracker.py:597-601 */
+#define GLH_OBS_TILE_TOO_LARGE 3 /* search tile exceeds the workspace (build limit)        */
+#define GLH_OBS_NO_TEMPLATE 4
+
+/* ---- random-number modes ------------------------------------------------------------- */
+#define GLH_RNG_HOST 0   /* caller supplies the normals / uniforms (parity with np.random)  */
+#define GLH_RNG_PHILOX 1 /* counter-based Philox4x32-10 on the device                       */
+
+typedef struct glh_ctx glh_ctx;
+
+typedef struct glh_config {
+  int32_t device_id;      /* HIP device ordinal                                             */
+  int32_t max_points;     /* P capacity                                                     */
+  int32_t max_particles;  /* N capacity (uniform across points)                             */
+  int32_t n_observers;    /* O                                                              */
+  int32_t max_tile;       /* largest template side, tile_size <= max_tile (default 31)      */
+  int32_t max_search_dim; /* search tiles up to max_search_dim^2 pixels per point           */
+  int32_t max_frames;     /* moments history capacity (frames per sequence)                 */
+  int32_t reserved;
+} glh_config;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int glh_version(void);
+const char* glh_last_error(void);
+int glh_device_count(int* count);
+int glh_create(const glh_config* cfg, glh_ctx** out);
+int glh_destroy(glh_ctx* ctx);
+int glh_sync(glh_ctx* ctx);
+/* The HIP stream (hipStream_t) the context enqueues on, for event timing by the caller.   */
+int glh_get_stream(glh_ctx* ctx, void** stream);
+
+/* ---- observers: images + cameras ------------------------------------------------------ */
+/* Observer(images, sigma) (track/observer.py:50-69).  Declares the image list size, the
+ * frame geometry and `sigma`; frames are resident in HBM for the whole sequence.          */
+int glh_observer_init(glh_ctx* ctx, int obs, int n_images, int width, int height, int channels,
+                      double sigma);
+/* One Camera per image (Image.cam, image.py:110; Camera.R camera.py:239-280 is evaluated
+ * on the host in float64 at upload).  cams: [n_images][GLH_CAM_LEN].                      */
+int glh_observer_set_cameras(glh_ctx* ctx, int obs, int first_image, int n_images,
+                             const double* cams);
+/* Image.read() cached array (image.py:180-186): uint8 [height][width][channels].          */
+int glh_observer_upload_frame(glh_ctx* ctx, int obs, int image, const uint8_t* pixels);
+/* Same, from a buffer that is already on the device (no PCIe in the timed region).        */
+int glh_observer_set_frame_device(glh_ctx* ctx, int obs, int image, const void* dev_pixels);
+
+/* ---- points (tracks) ------------------------------------------------------------------- */
+/* Number of tracked points P and particles per point N for this sequence; clears state
+ * (Tracker.reset, track/tracker.py:419-423).                                               */
+int glh_begin_sequence(glh_ctx* ctx, int n_points, int n_particles, int tile_w, int tile_h);
+/* CartesianMotion parameters per point: [P][GLH_MOTION_LEN] (track/motion.py:121-147).     */
+int glh_set_motion_cartesian(glh_ctx* ctx, const double* params);
+/* observer_mask [P][O] (track/tracker.py:250-252, :289-290); NULL = all ones.              */
+int glh_set_observer_mask(glh_ctx* ctx, const uint8_t* mask);
+/* active [P]: 1 = the point takes part in the following stage calls (frames inside its
+ * [first, last] window, track/tracker.py:321-326); NULL = all active.                      */
+int glh_set_active(glh_ctx* ctx, const uint8_t* active);
+
+int glh_set_particles(glh_ctx* ctx, const double* particles); /* [P][N][6] */
+int glh_get_particles(glh_ctx* ctx, double* particles);
+int glh_set_weights(glh_ctx* ctx, const double* weights); /* [P][N] */
+int glh_get_weights(glh_ctx* ctx, double* weights);
+int glh_get_point_status(glh_ctx* ctx, uint32_t* status);    /* [P]    GLH_PT_* bits        */
+/* Frame index (glh_set_frame) at which each point first raised a status bit, or a large
+ * value if none: the reference aborts the track there, so rows >= this frame are NaN
+ * (track/tracker.py:360-368).                                                               */
+int glh_get_point_error_frame(glh_ctx* ctx, int32_t* frames); /* [P] */
+int glh_get_observer_status(glh_ctx* ctx, int32_t* status);  /* [O][P] GLH_OBS_*            */
+
+/* ---- stages of one frame (track/tracker.py:326-357), in the reference's order ---------- */
+/* Index i of the datetime being processed (track/tracker.py:326); recorded with errors.     */
+int glh_set_frame(glh_ctx* ctx, int frame);
+/* CartesianMotion.initialize_particles (track/motion.py:149-163) + initialize_weights
+ * (track/tracker.py:121-124).  GLH_RNG_HOST: normals [P][N][6] = randn(n,2)|randn(n)|randn(n,3). */
+int glh_init_particles(glh_ctx* ctx, int rng_mode, const double* normals, uint64_t seed);
+/* CartesianMotion.evolve_particles (track/motion.py:165-179) + test_particles NaN check
+ * (track/tracker.py:118-119).  tau = dt / time_unit.  GLH_RNG_HOST: normals [P][N][3].     */
+int glh_evolve(glh_ctx* ctx, double tau, int rng_mode, const double* normals, uint64_t seed,
+               uint64_t step);
+/* Tracker.initialize_template (track/tracker.py:536-561) for observer `obs` at image
+ * `image`, for every active point with the observer enabled: weighted mean -> project ->
+ * Grid.snap_box (raster.py:390-421) -> extract_tile (tracker.py:494-534).                 */
+int glh_init_templates(glh_ctx* ctx, int obs, int image);
+/* Tracker.update_weights (track/tracker.py:126-149): for each observer o with
+ * images[o] >= 0, compute_observer_log_likelihoods (tracker.py:563-625); plus
+ * CartesianMotion.compute_log_likelihoods (motion.py:181-204); w = exp(-sum) + 1e-300.     */
+int glh_update_weights(glh_ctx* ctx, const int32_t* images /* [O], -1 = None */);
+/* Tracker.resample_particles("systematic") (track/tracker.py:168-176, :222-223).
+ * GLH_RNG_HOST: u [P] = the np.random.random() draw of each point.                         */
+int glh_resample(glh_ctx* ctx, int rng_mode, const double* u, uint64_t seed, uint64_t step);
+/* particle_mean + compute_particle_sigma (track/tracker.py:72-76, :89-104) of every active
+ * point into history slot `frame` (rows of inactive points keep NaN).                      */
+int glh_record_moments(glh_ctx* ctx, int frame);
+/* evolve -> update_weights -> resample -> record_moments: the per-frame step i > first of
+ * track/tracker.py:331-357 for all active points, enqueued back to back.                   */
+int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng_mode,
+             const double* normals, const double* u, uint64_t seed);
+
+/* ---- results --------------------------------------------------------------------------- */
+/* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
+int glh_get_moments(glh_ctx* ctx, int frame0, int n_frames, double* out);
+/* Device pointer + byte size of the moments history [max_frames][P][12] (for an RCCL
+ * gather issued by the caller; no copy).                                                    */
+int glh_get_moments_device(glh_ctx* ctx, void** dev_ptr, uint64_t* bytes);
+/* Template of (obs, point): box[4], duv[2], tile [th][tw], histogram (values, quantiles)
+ * (track/tracker.py:552-561).  hist_n receives the number of CDF entries (<= th*tw).       */
+int glh_get_template(glh_ctx* ctx, int obs, int point, int32_t* box, double* duv, double* tile,
+                     double* hist_values, double* hist_quantiles, int32_t* hist_n);
+/* Intermediates of the last glh_update_weights for (obs, point), for parity tests:
+ * uv [N][2], box[4] (l,t,r,b), search tile float32 [Hs][Ws], sse float64 [Ho][Wo] (the
+ * float32 SSE surface widened, before the spline fit).  Any pointer may be NULL.           */
+int glh_get_likelihood_debug(glh_ctx* ctx, int obs, int point, double* uv, int32_t* box,
+                             float* search, double* sse);
+/* Keep a copy of the SSE surface before the in-place spline fit and the resample indices
+ * (costs extra passes; off by default, on for parity tests).                                */
+int glh_set_debug(glh_ctx* ctx, int keep);
+/* np.searchsorted result of the last glh_resample (needs glh_set_debug): idx [P][N].        */
+int glh_get_resample_indices(glh_ctx* ctx, int32_t* idx);
+/* Per-stage device time (ms, HIP events on the context's stream) accumulated since the
+ * last reset: names in glh_stage_name(i), i < glh_stage_count().                            */
+int glh_profile_enable(glh_ctx* ctx, int on);
+int glh_profile_reset(glh_ctx* ctx);
+int glh_stage_count(void);
+const char* glh_stage_name(int stage);
+int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /* [stages] */);
+
+/* ---- stage-level test hooks (stateless; each runs one kernel on explicit inputs) -------- */
+/* Camera.xyz_to_uv (camera.py:591-628): xyz [n][3] -> uv [n][2].                            */
+int glh_stage_project(int device_id, const double* cam, const double* xyz, int n, double* uv);
+/* Tracker.extract_tile(return_histogram=True) (tracker.py:494-534) on a uint8 frame crop
+ * `box` (l,t,r,b): tile float64 [h][w], CDF values/quantiles, n entries.                    */
+int glh_stage_template(int device_id, const uint8_t* frame, int width, int height, int channels,
+                       const int32_t* box, double* tile, double* hist_values,
+                       double* hist_quantiles, int32_t* hist_n);
+/* Tracker.extract_tile(histogram=...) (tracker.py:494-534): search tile float32 [h][w].     */
+int glh_stage_search_tile(int device_id, const uint8_t* frame, int width, int height,
+                          int channels, const int32_t* box, const double* hist_values,
+                          const double* hist_quantiles, int hist_n, float* tile);
+/* cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614): float32 in, float32 out.   */
+int glh_stage_ssd(int device_id, const float* search, int hs, int ws, const float* templ, int th,
+                  int tw, float* sse);
+/* Observer.sample_tile (observer.py:178-214): sse float32 [ho][wo], box (4 doubles),
+ * uv [n][2] -> values [n]; outside [n] flags points outside the box.                         */
+int glh_stage_sample(int device_id, const float* sse, int ho, int wo, const double* box,
+                     const double* uv, int n, double* values, uint8_t* outside);
+/* Tracker.resample_particles("systematic") on one population: idx int64 [n].                 */
+int glh_stage_resample(int device_id, const double* weights, int n, double u, int64_t* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLIMPSE_HIP_H */
