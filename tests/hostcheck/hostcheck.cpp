@@ -1,0 +1,116 @@
+// hostcheck.cpp -- TEST-ONLY harness: compiles the `__host__ __device__` stage math of
+// glimpse_amd/csrc (glh_math.h, glh_median.h, glh_host.h) with g++ so that its logic can be
+// checked against the oracle on a machine without a GPU.  Never loaded by glimpse_amd; the
+// product path has no CPU fallback.
+#include <cstring>
+#include <vector>
+
+#include "../../glimpse_amd/csrc/glh_host.h"
+#include "../../glimpse_amd/csrc/glh_math.h"
+#include "../../glimpse_amd/csrc/glh_median.h"
+
+using namespace glh;
+
+extern "C" {
+
+void hc_project(const double* cam, const double* xyz, int n, double* uv) {
+  CamDev c;
+  expand_camera(cam, &c);
+  for (int i = 0; i < n; ++i) project(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
+}
+
+int hc_search_box(const double* uv, int n, int tw, int th, double imgw, double imgh, int* box) {
+  double mnu = INFINITY, mnv = INFINITY, mxu = -INFINITY, mxv = -INFINITY;
+  int nan = 0;
+  for (int i = 0; i < n; ++i) {
+    double u = uv[2 * i], v = uv[2 * i + 1];
+    if (std::isnan(u) || std::isnan(v)) { nan = 1; continue; }
+    mnu = fmin(mnu, u); mnv = fmin(mnv, v); mxu = fmax(mxu, u); mxv = fmax(mxv, v);
+  }
+  return search_box(mnu, mnv, mxu, mxv, nan, tw, th, imgw, imgh, box);
+}
+
+int hc_template_box(double u, double v, int tw, int th, double imgw, double imgh, int* box, double* duv) {
+  return template_box(u, v, tw, th, imgw, imgh, box, duv);
+}
+
+void hc_interp(const double* x, int nx, const double* xp, const double* fp, int n, double* out) {
+  for (int i = 0; i < nx; ++i) out[i] = np_interp(x[i], xp, fp, n);
+}
+
+void hc_median25(const int* v, int n, int* out) {
+  for (int i = 0; i < n; ++i) {
+    int w[25];
+    memcpy(w, v + 25 * i, sizeof w);
+    out[i] = median25(w);
+  }
+}
+
+int hc_reflect(int i, int n) { return reflect_index(i, n); }
+
+// fit (two passes of banded solves with spline_lu factors) + evaluate
+void hc_spline_sample(const double* z, int ho, int wo, const double* box, const double* uv, int n, double* out) {
+  std::vector<double> c(z, z + (size_t)ho * wo), fh(5 * (size_t)ho), fw(5 * (size_t)wo);
+  spline_lu(ho, fh.data());
+  spline_lu(wo, fw.data());
+  auto solve = [](double* x, int stride, int m, const double* f) {
+    const double *l1 = f, *l2 = f + m, *u0i = f + 2 * m, *u1 = f + 3 * m, *u2 = f + 4 * m;
+    for (int i = 1; i < m; ++i) {
+      double y = x[(size_t)i * stride] - l1[i] * x[(size_t)(i - 1) * stride];
+      if (i >= 2) y -= l2[i] * x[(size_t)(i - 2) * stride];
+      x[(size_t)i * stride] = y;
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double acc = x[(size_t)i * stride];
+      if (i + 1 < m) acc -= u1[i] * x[(size_t)(i + 1) * stride];
+      if (i + 2 < m) acc -= u2[i] * x[(size_t)(i + 2) * stride];
+      x[(size_t)i * stride] = acc * u0i[i];
+    }
+  };
+  for (int cidx = 0; cidx < wo; ++cidx) solve(c.data() + cidx, wo, ho, fh.data());
+  for (int r = 0; r < ho; ++r) solve(c.data() + (size_t)r * wo, 1, wo, fw.data());
+  double cu0 = cell_origin(box[0], box[2], wo), cv0 = cell_origin(box[1], box[3], ho);
+  for (int i = 0; i < n; ++i) out[i] = spline_eval(c.data(), wo, ho, wo, cv0, cu0, uv[2 * i], uv[2 * i + 1]);
+}
+
+// NumPy pairwise sum through the same leaf plan + postfix program the resample kernel runs
+double hc_pairwise_sum(const double* w, int n) {
+  std::vector<int32_t> off, len;
+  std::vector<int16_t> prog;
+  pairwise_plan(n, off, len, prog);
+  std::vector<double> leaf(off.size());
+  for (size_t L = 0; L < off.size(); ++L) {
+    const double* x = w + off[L];
+    int m = len[L];
+    double res;
+    if (m < 8) {
+      res = 0.0;
+      for (int i = 0; i < m; ++i) res += x[i];
+    } else {
+      double r[8];
+      for (int j = 0; j < 8; ++j) r[j] = x[j];
+      int body = m - (m & 7);
+      for (int i = 8; i < body; i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += x[i + j];
+      // butterfly order used on the GPU: xor 1, xor 2, xor 4
+      double a01 = r[0] + r[1], a23 = r[2] + r[3], a45 = r[4] + r[5], a67 = r[6] + r[7];
+      res = (a01 + a23) + (a45 + a67);
+      for (int i = body; i < m; ++i) res += x[i];
+    }
+    leaf[L] = res;
+  }
+  double stack[32], total = 0.0;
+  int sp = 0;
+  bool first = true;
+  for (int16_t op : prog) {
+    if (op >= 0) stack[sp++] = leaf[op];
+    else if (op == -1) { double b = stack[--sp]; double a = stack[--sp]; stack[sp++] = a + b; }
+    else { double v = stack[--sp]; total = first ? v : total + v; first = false; }
+  }
+  return total;
+}
+
+void hc_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
+  philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+}

@@ -1,0 +1,144 @@
+"""Stage math of the HIP kernels, compiled for the CPU (tests/hostcheck) and checked against
+the oracle / the reference goldens.  Test-only: the product never runs this code on the CPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import resample as oresample
+from oracle import tiles as otiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
+OUT = os.path.join(ROOT, "tests", "hostcheck", "_build", "libhostcheck.so")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    deps = [SRC] + [os.path.join(ROOT, "glimpse_amd", "csrc", f) for f in ("glh_math.h", "glh_median.h", "glh_host.h")]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", OUT, SRC], check=True)
+    lib = C.CDLL(OUT)
+    lib.hc_pairwise_sum.restype = C.c_double
+    return lib
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_projection_bit_exact_on_reference_goldens(hc, golden):
+    g = golden("g1_projection.npz")
+    for cam, xyz, uv in zip(g["cams"], g["xyz"], g["uv"]):
+        got = np.empty_like(uv)
+        hc.hc_project(p(np.ascontiguousarray(cam)), p(np.ascontiguousarray(xyz)), len(xyz), p(got))
+        assert np.array_equal(np.isnan(got), np.isnan(uv))
+        ok = ~np.isnan(uv[:, 0])
+        np.testing.assert_allclose(got[ok], uv[ok], rtol=1e-13, atol=1e-9)
+
+
+def test_search_and_template_boxes(hc, golden):
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n = int(rng.integers(1, 50))
+        size = (int(rng.choice([15, 31, 9])), int(rng.choice([15, 31, 11])))
+        uv = rng.uniform(-5, 140, 2) + rng.standard_normal((n, 2)) * rng.choice([0.01, 1.0, 8.0])
+        want = otiles.search_box(uv, size)
+        inb = (want >= 0).all() and (want <= np.array([128.0, 128.0])).all()
+        box = np.zeros(4, dtype=np.int32)
+        rc = hc.hc_search_box(p(np.ascontiguousarray(uv)), n, size[0], size[1], C.c_double(128.0), C.c_double(128.0), p(box))
+        assert (rc == 0) == bool(inb)
+        if inb:
+            np.testing.assert_array_equal(box, want.ravel())
+    uvn = np.array([[10.0, 10.0], [np.nan, 3.0]])
+    assert hc.hc_search_box(p(uvn), 2, 15, 15, C.c_double(128.0), C.c_double(128.0), p(box)) == 1
+    for trial in range(300):
+        uv = rng.uniform(-3, 131, 2)
+        size = (int(rng.choice([15, 31, 8])), int(rng.choice([15, 31, 10])))
+        duv = np.zeros(2)
+        rc = hc.hc_template_box(C.c_double(uv[0]), C.c_double(uv[1]), size[0], size[1], C.c_double(128.0),
+                                C.c_double(128.0), p(box), p(duv))
+        try:
+            want = otiles.snap_box(uv, size, (128, 128))
+        except IndexError:
+            assert rc == 1
+            continue
+        assert rc == 0
+        np.testing.assert_array_equal(box, want)
+        np.testing.assert_array_equal(duv, uv - want.reshape(2, -1).mean(axis=0))
+
+
+def test_np_interp_bit_exact(hc):
+    rng = np.random.default_rng(1)
+    for n in [1, 2, 3, 17, 225, 961]:
+        xp = np.sort(rng.random(n))
+        xp[-1] = 1.0
+        fp = np.sort(rng.standard_normal(n))
+        x = np.concatenate((rng.random(500), xp, [0.0, 1.0, xp[0] - 1e-3, 1.5]))
+        out = np.empty_like(x)
+        hc.hc_interp(p(x), len(x), p(xp), p(fp), n, p(out))
+        np.testing.assert_array_equal(out, np.interp(x, xp, fp))
+
+
+def test_median_and_reflect(hc):
+    import scipy.ndimage
+
+    rng = np.random.default_rng(2)
+    v = rng.integers(0, 766, (5000, 25)).astype(np.int32)
+    v[:100] = rng.integers(0, 3, (100, 25))
+    out = np.empty(len(v), dtype=np.int32)
+    hc.hc_median25(p(v), len(v), p(out))
+    np.testing.assert_array_equal(out, np.sort(v, axis=1)[:, 12])
+    for n in [1, 2, 3, 5, 16]:
+        a = np.arange(n)
+        pad = np.pad(a, 2 * n + 2, mode="symmetric")
+        for i in range(-2 * n - 2, 3 * n + 2):
+            assert hc.hc_reflect(i, n) == pad[i + 2 * n + 2]
+    # scipy's 'reflect' == numpy 'symmetric' (edge-repeating) for the 5x5 window
+    img = rng.integers(0, 255, (9, 7))
+    want = scipy.ndimage.median_filter(img, size=(5, 5), mode="reflect")
+    got = np.empty_like(img)
+    for r in range(9):
+        for c in range(7):
+            w = np.array([[img[hc.hc_reflect(r + dr, 9), hc.hc_reflect(c + dc, 7)] for dc in range(-2, 3)]
+                          for dr in range(-2, 3)], dtype=np.int32).ravel()
+            o = np.empty(1, dtype=np.int32)
+            hc.hc_median25(p(w), 1, p(o))
+            got[r, c] = o[0]
+    np.testing.assert_array_equal(got, want)
+
+
+def test_spline_fit_and_eval_match_reference(hc, golden):
+    g = golden("g4_spline.npz")
+    for i in range(8):
+        sse, box, uv, val = g[f"s{i}_sse"], g[f"s{i}_box"], g[f"s{i}_uv"], g[f"s{i}_val"]
+        z = np.ascontiguousarray(sse, dtype=np.float64)
+        out = np.empty(len(uv))
+        hc.hc_spline_sample(p(z), z.shape[0], z.shape[1], p(np.ascontiguousarray(box)), p(np.ascontiguousarray(uv)),
+                            len(uv), p(out))
+        np.testing.assert_allclose(out, val, rtol=0, atol=5e-13)
+
+
+def test_pairwise_sum_plan_is_numpy_sum(hc):
+    rng = np.random.default_rng(3)
+    for n in [1, 5, 8, 9, 100, 128, 129, 1000, 2000, 5000, 8191, 8192, 8193, 10000, 16000, 19000]:
+        for t in range(5):
+            w = np.exp(-rng.random(n) * 40) + 1e-300
+            assert hc.hc_pairwise_sum(p(w), n) == w.sum() == oresample.numpy_pairwise_sum(w)
+
+
+def test_philox_known_answers(hc):
+    # Random123 known-answer vectors for philox4x32-10
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, want in kat:
+        out = (C.c_uint * 4)()
+        hc.hc_philox(*ctr, *key, out)
+        assert tuple(out) == want
