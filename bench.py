@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Tracker hot path on MI355X (particle-frames/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+
+One "step" = one frame update (evolve -> project -> search tile -> SSD -> spline -> weights ->
+resample -> moments, track/tracker.py:331-357) for ALL tracked points of this GPU, on synthetic
+frames that are already resident in HBM.  Metric (BASELINE.json): particle-frames/s
+= points x particles x steps / wall, summed over GPUs (weak scaling: every GPU tracks its own
+shard of points, no data-path collective; one RCCL gather of the posterior moments at the end).
+
+Prints ONE JSON line on rank 0 (see the keys in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3    # vector FP32 peak (= FP32-input MFMA rate on gfx950)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--points", type=int, default=None, help="override points per GPU")
+    ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented steps after the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+class DevArray:
+    """Zero-copy view of a library-owned device buffer for torch (RCCL gather)."""
+
+    def __init__(self, ptr, shape, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def algorithmic_bytes_per_step(P, N, O, tile, boxes, status):
+    """P*(96 N) state + per observer (Ws*Hs + 20*tw*th + 96) per point."""
+    tw, th = tile
+    total = 96.0 * N * P
+    for o in range(O):
+        ok = status[o] == 0
+        ws = (boxes[o, :, 2] - boxes[o, :, 0])[ok].astype(np.float64)
+        hs = (boxes[o, :, 3] - boxes[o, :, 1])[ok].astype(np.float64)
+        total += float((ws * hs).sum()) + ok.sum() * (20.0 * tw * th + 96.0)
+    return total
+
+
+def ssd_flops_per_step(O, tile, boxes, status):
+    """3*tw*th*Wo*Ho FP32 per point-frame-observer."""
+    tw, th = tile
+    total = 0.0
+    for o in range(O):
+        ok = status[o] == 0
+        wo = (boxes[o, :, 2] - boxes[o, :, 0] - tw + 1)[ok].astype(np.float64)
+        ho = (boxes[o, :, 3] - boxes[o, :, 1] - th + 1)[ok].astype(np.float64)
+        total += 3.0 * tw * th * float((wo * ho).sum())
+    return total
+
+
+def cpu_baseline(wl, frames, steps, target_seconds):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    observers = [otracker.Observer(frames[o], np.tile(wl.cams[o], (len(frames[o]), 1)), wl.sigmas[o])
+                 for o in range(wl.O)]
+    nfr = 1 + steps
+    matching = np.tile(np.arange(nfr)[:, None], (1, wl.O))
+    taus = np.ones(nfr - 1)
+
+    def model(p):
+        q = wl.params[p]
+        return omotion.CartesianMotion(xy=q[0:2], xy_sigma=q[2:4], vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13],
+                                       axyz_sigma=q[13:16], dem=q[16], dem_sigma=q[17], n=wl.N)
+
+    np.random.seed(7)
+    t0 = time.perf_counter()
+    otracker.track([model(0)], observers, matching, taus, tile_size=wl.tile)
+    per_point = time.perf_counter() - t0
+    n_pts = int(max(1, min(wl.P - 1, round(target_seconds / max(per_point, 1e-3)))))
+    t0 = time.perf_counter()
+    otracker.track([model(1 + p) for p in range(n_pts)], observers, matching, taus, tile_size=wl.tile)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_pts * wl.N * steps / dt,
+        "unit": "particle-frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_pts} of {wl.P} points x {wl.N} particles x {steps} steps of the same workload, "
+                  f"oracle/ (NumPy {np.__version__} + SciPy + C SSD), {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from glimpse_amd import _lib, workloads
+
+    K, W, KP = args.steps, args.warmup, max(0, args.profile_steps)
+    T = 1 + W + K + KP
+    wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
+                            seed=0)
+    frames = [wl.frames(o) for o in range(wl.O)]
+    ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=local_rank, max_tile=max(wl.tile), max_search_dim=320,
+                       max_frames=T)
+    workloads.setup_context(ctx, wl, frames)
+    seed = args.seed + rank
+    images = lambda i: [i] * wl.O  # noqa: E731
+
+    # frame 0: initialise particles + templates (tracker.py:327-342), untimed
+    ctx.set_frame(0)
+    ctx.init_particles(seed=seed)
+    for o in range(wl.O):
+        ctx.init_templates(o, 0)
+    ctx.record_moments(0)
+    for i in range(1, 1 + W):
+        ctx.step(i, 1.0, images(i), seed=seed)
+    ctx.sync()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    gather_list = None
+    mom = None
+    if dist is not None:
+        import torch
+
+        ptr, nbytes = ctx.moments_device()
+        mom = torch.as_tensor(DevArray(ptr, (T, wl.P, 12)), device=f"cuda:{local_rank}")
+        if rank == 0:
+            gather_list = [torch.empty_like(mom) for _ in range(world)]
+        dist.gather(mom, gather_list, dst=0)  # warm the communicator up outside the timed region
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(1 + W, 1 + W + K):
+        ctx.step(i, 1.0, images(i), seed=seed)
+    if dist is not None:
+        ctx.sync()
+        dist.gather(mom, gather_list, dst=0)  # the one collective: posterior moments to rank 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # health of the run: every point must still be tracked by every observer
+    status = ctx.observer_status()
+    pt_status = ctx.point_status()
+    frac_ok = float((status == 0).mean())
+    n_err = int((pt_status != 0).sum())
+
+    # instrumented steps (HIP events on the context's stream around every kernel)
+    stage_ms, flops, abytes = {}, 0.0, 0.0
+    if KP > 0:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for i in range(1 + W + K, 1 + W + K + KP):
+            ctx.step(i, 1.0, images(i), seed=seed)
+            st, bx = ctx.observer_status(), ctx.search_boxes()
+            flops += ssd_flops_per_step(wl.O, wl.tile, bx, st)
+            abytes += algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, bx, st)
+        stage_ms = ctx.profile_get()
+        ctx.profile_enable(False)
+
+    if rank == 0:
+        value = world * wl.P * wl.N * K / elapsed
+        out = {
+            "metric": "particle-frames/s",
+            "value": value,
+            "unit": "particle-frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
+                           frames_per_s=K / elapsed),
+            "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err},
+        }
+        if KP > 0:
+            tot = sum(ms for ms, _ in stage_ms.values())
+            dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+            dom_ms, dom_n = stage_ms[dom]
+            per_launch_ms = dom_ms / max(dom_n, 1)
+            launches_per_step = dom_n / KP
+            if dom == "ssd":
+                ach = flops / KP / launches_per_step / (per_launch_ms * 1e-3) / 1e12
+                roof = {"kernel": "k_ssd", "bound": "fp32-valu", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                        "note": "SSD is (s-t)^2 accumulation on the FP32 vector pipe (no MFMA form); "
+                                "algorithmic flops = 3*tw*th*Wo*Ho per point-frame (SURVEY 8(d))"}
+            else:
+                ach = abytes / KP / launches_per_step / (per_launch_ms * 1e-3) / 1e9
+                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roof["avg_launch_ms"] = per_launch_ms
+            out["roofline"] = roof
+            step_ms = tot / KP
+            out["roofline_step"] = {
+                "bound": "hbm", "achieved": abytes / KP / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": abytes / KP / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_particle_frame": abytes / KP / (wl.P * wl.N),
+                "note": "whole step: algorithmic bytes (SURVEY 8(d)) / sum of kernel times",
+            }
+            out["stage_ms_per_step"] = {k: ms / KP for k, (ms, _) in stage_ms.items() if ms > 0}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, frames, min(K, 4), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ SIGNATURES = {
     "glh_get_point_status": (_I, [_P, _P]),
     "glh_get_point_error_frame": (_I, [_P, _P]),
     "glh_get_observer_status": (_I, [_P, _P]),
+    "glh_get_search_boxes": (_I, [_P, _P]),
     "glh_set_frame": (_I, [_P, _I]),
     "glh_init_particles": (_I, [_P, _I, _P, _U64]),
     "glh_evolve": (_I, [_P, _D, _I, _P, _U64, _U64]),
@@ -240,6 +241,11 @@ class Context:
     def observer_status(self):
         out = np.empty((self.O, self.P), dtype=np.int32)
         check(self.lib.glh_get_observer_status(self.handle, _ptr(out)))
+        return out
+
+    def search_boxes(self):
+        out = np.empty((self.O, self.P, 4), dtype=np.int32)
+        check(self.lib.glh_get_search_boxes(self.handle, _ptr(out)))
         return out
 
     # ---- stages

@@ -544,6 +544,12 @@ extern "C" int glh_get_observer_status(glh_ctx* c, int32_t* st) {
   DOWNLOAD(st, c->obs_status, (size_t)c->cfg.n_observers * c->P, int32_t);
   return GLH_OK;
 }
+extern "C" int glh_get_search_boxes(glh_ctx* c, int32_t* boxes) {
+  CHK(need_seq(c));
+  if (!boxes) return fail(GLH_E_INVALID, "boxes is null");
+  DOWNLOAD(boxes, c->box, (size_t)c->cfg.n_observers * c->P * 4, int32_t);
+  return GLH_OK;
+}
 extern "C" int glh_get_resample_indices(glh_ctx* c, int32_t* idx) {
   CHK(need_seq(c));
   if (!idx || !c->idx) return fail(GLH_E_STATE, "index capture is off (glh_set_debug)");

@@ -128,6 +128,9 @@ int glh_get_point_status(glh_ctx* ctx, uint32_t* status);    /* [P]    GLH_PT_* 
  * (track/tracker.py:360-368).                                                               */
 int glh_get_point_error_frame(glh_ctx* ctx, int32_t* frames); /* [P] */
 int glh_get_observer_status(glh_ctx* ctx, int32_t* status);  /* [O][P] GLH_OBS_*            */
+/* Search boxes (l,t,r,b) of the last glh_update_weights (tracker.py:595): [O][P][4];
+ * entries whose observer status is not GLH_OBS_OK are stale.                                */
+int glh_get_search_boxes(glh_ctx* ctx, int32_t* boxes);
 
 /* ---- stages of one frame (track/tracker.py:326-357), in the reference's order ---------- */
 /* Index i of the datetime being processed (track/tracker.py:326); recorded with errors.     */
