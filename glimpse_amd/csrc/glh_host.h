@@ -50,6 +50,74 @@ inline void expand_camera(const double* v, CamDev* c) {
   c->refraction = v[22];
 }
 
+// Cubic coefficients [m][d] of the 4 non-zero B-splines on interval q of an n-site
+// not-a-knot spline, in s = xl - start(q): sampled from the de Boor recursion at 4 points of
+// the interval and interpolated (long double Vandermonde solve; the cubics are exact).
+inline void basis_poly(int n, int q, double* out16) {
+  const double a = spline_interval_start(q);
+  const double b = knot_local(q + 4, n);  // interval end
+  const long double wdt = (long double)(b - a);
+  long double sp[4], V[4][4], rhs[4][4];
+  for (int k = 0; k < 4; ++k) {
+    sp[k] = wdt * k / 3.0L;
+    double h[4];
+    spline_basis_local((double)(a + (double)sp[k]), q, n, h);
+    // evaluate in long double for the fit: redo the recursion with long double arithmetic
+    long double hl[4] = {1, 0, 0, 0}, hh[3];
+    const int l = q + 3;
+    const long double x = (long double)a + sp[k];
+    for (int j = 1; j <= 3; ++j) {
+      for (int i = 0; i < j; ++i) hh[i] = hl[i];
+      hl[0] = 0;
+      for (int i = 0; i < j; ++i) {
+        int li = l + i + 1, lj = li - j;
+        long double tli = knot_local(li, n), tlj = knot_local(lj, n);
+        long double f = hh[i] / (tli - tlj);
+        hl[i] = hl[i] + f * (tli - x);
+        hl[i + 1] = f * (x - tlj);
+      }
+    }
+    for (int mm = 0; mm < 4; ++mm) rhs[k][mm] = hl[mm];
+    long double p = 1;
+    for (int d = 0; d < 4; ++d) {
+      V[k][d] = p;
+      p *= sp[k];
+    }
+  }
+  // Gaussian elimination with partial pivoting on V c = rhs (4 right-hand sides)
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (fabsl(V[r][col]) > fabsl(V[piv][col])) piv = r;
+    for (int d = 0; d < 4; ++d) std::swap(V[col][d], V[piv][d]);
+    for (int mm = 0; mm < 4; ++mm) std::swap(rhs[col][mm], rhs[piv][mm]);
+    for (int r = col + 1; r < 4; ++r) {
+      long double f = V[r][col] / V[col][col];
+      for (int d = col; d < 4; ++d) V[r][d] -= f * V[col][d];
+      for (int mm = 0; mm < 4; ++mm) rhs[r][mm] -= f * rhs[col][mm];
+    }
+  }
+  long double cf[4][4];
+  for (int mm = 0; mm < 4; ++mm) {
+    for (int r = 3; r >= 0; --r) {
+      long double acc = rhs[r][mm];
+      for (int d = r + 1; d < 4; ++d) acc -= V[r][d] * cf[d][mm];
+      cf[r][mm] = acc / V[r][r];
+    }
+  }
+  for (int mm = 0; mm < 4; ++mm)
+    for (int d = 0; d < 4; ++d) out16[4 * mm + d] = (double)cf[d][mm];
+}
+
+// GLH_NPOLY matrices indexed by spline_poly_index(n, q)
+inline void basis_poly_table(double* out) {
+  const int ng = 16;  // any n >= 9 gives the generic end/interior matrices
+  const int qs[7] = {0, 1, 2, 5, ng - 6, ng - 5, ng - 4};
+  for (int k = 0; k < 7; ++k) basis_poly(ng, qs[k], out + 16 * k);
+  for (int n = 4; n <= 8; ++n)
+    for (int q = 0; q <= n - 4; ++q) basis_poly(n, q, out + 16 * spline_poly_index(n, q));
+}
+
 // LU factors (no pivoting) of the not-a-knot collocation matrix of size n, packed as
 // l1[n] l2[n] u0inv[n] u1[n] u2[n].  The matrix is diagonally dominant by rows.
 inline void spline_lu(int n, double* out) {
@@ -82,31 +150,75 @@ inline void spline_lu(int n, double* out) {
   }
 }
 
-// NumPy's pairwise float sum over n contiguous items as a leaf list + postfix program
-// (np.add.reduce: 8192-item chunks; <=128-item leaves; split at n/2 rounded down to 8).
-inline void pairwise_plan(int n, std::vector<int32_t>& off, std::vector<int32_t>& len,
-                          std::vector<int16_t>& prog) {
+// NumPy's pairwise float sum over n contiguous items (np.add.reduce: 8192-item chunks;
+// <= 128-item leaves with 8 interleaved accumulators; split at n/2 rounded down to 8) as a
+// tree the resample kernel can evaluate level by level:
+//   nodes 0 .. nleaves-1 are the leaves (leaf_off/leaf_len);
+//   ops[k] = (dst, a, b): node dst = node a + node b, sorted by level (level_off[l] .. [l+1]);
+//   roots = the root node of every 8192-chunk, added left to right.
+struct PairwisePlan {
+  std::vector<int32_t> leaf_off, leaf_len;
+  std::vector<int32_t> ops;        // 3 ints per op
+  std::vector<int32_t> level_off;  // nlevels + 1
+  std::vector<int32_t> roots;
+  int nnodes = 0;
+};
+
+inline void pairwise_plan(int n, PairwisePlan& pl) {
+  struct Op {
+    int dst, a, b, level;
+  };
+  std::vector<Op> ops;
+  std::vector<int> level_of;
   struct Rec {
-    static void run(int o, int m, std::vector<int32_t>& off, std::vector<int32_t>& len,
-                    std::vector<int16_t>& prog) {
+    // leaves first: number them in order of appearance
+    static int leaves(int o, int m, PairwisePlan& pl) {
       if (m <= 128) {
-        prog.push_back((int16_t)off.size());
-        off.push_back(o);
-        len.push_back(m);
-        return;
+        pl.leaf_off.push_back(o);
+        pl.leaf_len.push_back(m);
+        return 1;
       }
       int n2 = m / 2;
       n2 -= n2 % 8;
-      run(o, n2, off, len, prog);
-      run(o + n2, m - n2, off, len, prog);
-      prog.push_back(-1);
+      return leaves(o, n2, pl) + leaves(o + n2, m - n2, pl);
     }
   };
-  for (int s = 0; s < n; s += 8192) {
-    Rec::run(s, std::min(8192, n - s), off, len, prog);
-    prog.push_back(-2);
+  for (int s = 0; s < n; s += 8192) Rec::leaves(s, std::min(8192, n - s), pl);
+  const int nleaves = (int)pl.leaf_off.size();
+  level_of.assign(nleaves, 0);
+  int next_leaf = 0, next_node = nleaves;
+  // second walk in the same order builds the internal nodes
+  struct Build {
+    static int run(int m, int& next_leaf, int& next_node, std::vector<Op>& ops, std::vector<int>& level_of) {
+      if (m <= 128) return next_leaf++;
+      int n2 = m / 2;
+      n2 -= n2 % 8;
+      int a = run(n2, next_leaf, next_node, ops, level_of);
+      int b = run(m - n2, next_leaf, next_node, ops, level_of);
+      int dst = next_node++;
+      int lvl = 1 + std::max(level_of[a], level_of[b]);
+      level_of.push_back(lvl);
+      ops.push_back({dst, a, b, lvl});
+      return dst;
+    }
+  };
+  for (int s = 0; s < n; s += 8192)
+    pl.roots.push_back(Build::run(std::min(8192, n - s), next_leaf, next_node, ops, level_of));
+  pl.nnodes = next_node;
+  int maxl = 0;
+  for (auto& o : ops) maxl = std::max(maxl, o.level);
+  pl.level_off.assign(maxl + 1, 0);
+  std::stable_sort(ops.begin(), ops.end(), [](const Op& x, const Op& y) { return x.level < y.level; });
+  int cur = 1;
+  for (size_t k = 0; k < ops.size(); ++k) {
+    while (cur < ops[k].level) pl.level_off[cur++] = (int)k;
+    pl.ops.push_back(ops[k].dst);
+    pl.ops.push_back(ops[k].a);
+    pl.ops.push_back(ops[k].b);
   }
+  while (cur <= maxl) pl.level_off[cur++] = (int)ops.size();
+  // level_off[l-1] .. level_off[l] are the ops of level l (l = 1 .. maxl); level_off[0] = 0
+  pl.level_off[0] = 0;
 }
-
 
 }  // namespace glh

@@ -21,7 +21,6 @@ constexpr int NWAVES = BLK / WAVE;
 constexpr int MAX_OBS = 4;
 constexpr int NBINS = 768;  // >= 766 = 3 * 255 + 1 channel-sum keys (RGB); 256 for gray
 constexpr int BAND_H = 16;  // rows per median band in k_tileprep
-constexpr int SSD_W = 8;    // outputs per thread in k_ssd
 
 struct ObsFrame {
   const CamDev* cam;     // camera of the image matched to this frame
@@ -70,17 +69,19 @@ __device__ __forceinline__ void flag_point(uint32_t* pt_status, int32_t* pt_err_
 // ------------------------------------------------------------------------------------------
 // normals: host-fed (parity with np.random) or Philox + Box-Muller
 // ------------------------------------------------------------------------------------------
+// Two standard normals from one Philox4x32-10 block.  Bench-mode process noise does not need
+// float64 transcendentals: the Box-Muller radius/angle run on the float32 hardware units
+// (v_log_f32, v_sqrt_f32, v_sin/cos_f32 in revolutions), |z| <= 6.6, then widen to float64.
 __device__ __forceinline__ void philox_normals2(uint64_t seed, uint32_t c0, uint32_t c1,
                                                 uint32_t c2, uint32_t c3, double& z0, double& z1) {
   uint32_t r[4];
   philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  double u1 = u01_open(r[0], r[1]);
-  double u2 = u01_halfopen(r[2], r[3]);
-  double rad = sqrt(-2.0 * log(u1));
-  double s, c;
-  sincospi(2.0 * u2, &s, &c);
-  z0 = rad * c;
-  z1 = rad * s;
+  const float u1 = ((float)r[0] + 0.5f) * 2.3283064365386963e-10f;   // (0, 1]
+  const float u2 = (float)(r[1] >> 8) * 5.9604644775390625e-08f;      // [0, 1) revolutions
+  const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+  z0 = (double)(rad * __builtin_amdgcn_cosf(u2));
+  z1 = (double)(rad * __builtin_amdgcn_sinf(u2));
+  (void)r[2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -641,11 +642,20 @@ __global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
 //     float32 sub + FMA inside a template row, float64 across rows, one rounding to float32,
 //     then the reference's  float32(float64(sse) * float64(1/(tw*th))).  Stored widened to
 //     float64 because the spline fit that follows works in float64 (observer.py:210).
-//     Each thread owns an 8-wide strip of one output row; a block stages a band of full-width
-//     search rows in LDS (coalesced loads, 1 LDS read per 8 sub+FMA pairs).
+//
+//     Work decomposition: a block owns output tiles of SSD_TOH x SSD_TOW cells and stages the
+//     matching (TOH+th-1) x (TOW+tw-1) search window in LDS (fixed footprint, independent of
+//     the search-tile size).  A thread owns a 4-wide strip of one output row; when a tile has
+//     fewer strips than threads (small surfaces are the common case: clouds of ~2 px sigma
+//     give 13x13 .. 20x20 surfaces) the template rows are split G ways across adjacent lanes
+//     and the float64 partials are combined with wave shuffles.
 // ------------------------------------------------------------------------------------------
+constexpr int SSD_W = 4;     // outputs per thread
+constexpr int SSD_TOW = 32;  // output tile width
+constexpr int SSD_TOH = 16;  // output tile height
+
 struct SsdArgs {
-  int32_t o, P, tw, th, tile_cap, search_cap, sse_cap, lds_floats;
+  int32_t o, P, tw, th, tile_cap, search_cap, sse_cap, reserved;
   const int32_t* box;         // [O][P][4]
   const int32_t* obs_status;  // [O][P]
   const float* search;        // [O][P][search_cap]
@@ -653,7 +663,17 @@ struct SsdArgs {
   double* sse;                // [O][P][sse_cap]
 };
 
-__device__ __forceinline__ int ssd_ld(int ws) { return (ws + 24 + 3) & ~3; }
+__host__ __device__ __forceinline__ int ssd_twp(int tw) { return (tw + 7) & ~7; }
+// LDS row stride of the search window: >= TOW + twp + 4 and == 8 (mod 64) floats so that the
+// G row-split lanes of neighbouring strips land on distinct banks
+__host__ __device__ __forceinline__ int ssd_ld(int tw) {
+  int need = SSD_TOW + ssd_twp(tw) + 4;
+  int ld = ((need - 8 + 63) / 64) * 64 + 8;
+  return ld;
+}
+__host__ __device__ __forceinline__ size_t ssd_lds_bytes(int tw, int th) {
+  return (size_t)(th * ssd_twp(tw) + (SSD_TOH + th - 1) * ssd_ld(tw)) * sizeof(float);
+}
 
 __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -664,17 +684,13 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   const int ws = box[2] - box[0], hs = box[3] - box[1];
   const int tw = a.tw, th = a.th;
   const int wo = ws - tw + 1, ho = hs - th + 1;
-  const int twp = (tw + 7) & ~7;
-  const int ld = ssd_ld(ws);
+  const int tiles_x = (wo + SSD_TOW - 1) / SSD_TOW, tiles_y = (ho + SSD_TOH - 1) / SSD_TOH;
+  const int ntiles = tiles_x * tiles_y;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int twp = ssd_twp(tw);
+  const int ld = ssd_ld(tw);
   float* T = reinterpret_cast<float*>(smem);  // [th][twp]
-  float* S = T + th * twp;                    // [rows][ld]
-  const int spr = (wo + SSD_W - 1) / SSD_W;   // strips per output row
-  int rb = BLK / spr;
-  const int fit = (a.lds_floats - th * twp) / ld - (th - 1);
-  if (rb > fit) rb = fit;
-  if (rb < 1) return;  // excluded by k_tileprep's size limits
-  const int nbands = (ho + rb - 1) / rb;
-  if ((int)blockIdx.x >= nbands) return;
+  float* S = T + th * twp;                    // [TOH + th - 1][ld]
   const float* tg = a.tmpl + slot * a.tile_cap;
   for (int idx = tid; idx < th * twp; idx += BLK) {
     int i = idx / twp, j = idx - i * twp;
@@ -683,39 +699,45 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   const float* sg = a.search + slot * (size_t)a.search_cap;
   double* outg = a.sse + slot * (size_t)a.sse_cap;
   const double inv_area = 1.0 / (double)(tw * th);
-  for (int band = blockIdx.x; band < nbands; band += gridDim.x) {
-    const int r0 = band * rb;
-    const int nrows = min(rb, ho - r0) + th - 1;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * SSD_TOH, x0 = tx * SSD_TOW;
+    const int oh = min(SSD_TOH, ho - y0), ow = min(SSD_TOW, wo - x0);
+    const int rows = oh + th - 1, cols = min(ld, ws - x0);
     __syncthreads();
-    for (int idx = tid; idx < nrows * ld; idx += BLK) {
+    for (int idx = tid; idx < rows * ld; idx += BLK) {
       int rr = idx / ld, c = idx - rr * ld;
-      S[idx] = c < ws ? sg[(size_t)(r0 + rr) * ws + c] : 0.0f;
+      S[idx] = c < cols ? sg[(size_t)(y0 + rr) * ws + x0 + c] : 0.0f;
     }
     __syncthreads();
-    const int rr = tid / spr, cc = (tid - rr * spr) * SSD_W;
-    const int r = r0 + rr;
-    if (rr < rb && r < ho) {
-      double acc64[SSD_W];
+    const int spr = (ow + SSD_W - 1) / SSD_W;
+    const int nstrips = spr * oh;  // <= 8 * 16 = 128
+    int G = 1;                     // template-row split: largest power of two with nstrips * G <= BLK, <= 8
+    while (G < 8 && nstrips * (G * 2) <= BLK) G *= 2;
+    const int strip = tid / G, g = tid - strip * G;
+    const bool live = strip < nstrips;
+    const int rr = live ? strip / spr : 0;
+    const int cc = live ? (strip - rr * spr) * SSD_W : 0;
+    double acc64[SSD_W];
 #pragma unroll
-      for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
-      for (int i = 0; i < th; ++i) {
+    for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
+    if (live) {
+      for (int i = g; i < th; i += G) {
         const float* rowp = S + (rr + i) * ld + cc;
         const float* trow = T + i * twp;
         float acc[SSD_W];
 #pragma unroll
         for (int k = 0; k < SSD_W; ++k) acc[k] = 0.0f;
-        float w[16];
+        float w[12];
         {
           float4 a0 = *reinterpret_cast<const float4*>(rowp);
-          float4 a1 = *reinterpret_cast<const float4*>(rowp + 4);
           w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w;
-          w[4] = a1.x; w[5] = a1.y; w[6] = a1.z; w[7] = a1.w;
         }
         for (int jj = 0; jj < tw; jj += 8) {
-          float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 8);
-          float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 12);
-          w[8] = b0.x; w[9] = b0.y; w[10] = b0.z; w[11] = b0.w;
-          w[12] = b1.x; w[13] = b1.y; w[14] = b1.z; w[15] = b1.w;
+          float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 4);
+          float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 8);
+          w[4] = b0.x; w[5] = b0.y; w[6] = b0.z; w[7] = b0.w;
+          w[8] = b1.x; w[9] = b1.y; w[10] = b1.z; w[11] = b1.w;
           float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
           float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
           const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
@@ -741,17 +763,25 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) w[k] = w[k + 8];
+          for (int k = 0; k < 4; ++k) w[k] = w[k + 8];
         }
 #pragma unroll
         for (int k = 0; k < SSD_W; ++k) acc64[k] += (double)acc[k];
       }
+    }
+    // combine the G row-split partials (adjacent lanes of one wave; G divides 64)
+    for (int off = 1; off < G; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < SSD_W; ++k) acc64[k] += __shfl_xor(acc64[k], off, WAVE);
+    }
+    if (live && g == 0) {
+      const int r = y0 + rr;
 #pragma unroll
       for (int k = 0; k < SSD_W; ++k) {
-        if (cc + k < wo) {
+        if (cc + k < ow) {
           float raw = (float)acc64[k];
           float val = (float)((double)raw * inv_area);  // sse *= 1/(tw*th) (tracker.py:614)
-          outg[(size_t)r * wo + cc + k] = (double)val;
+          outg[(size_t)r * wo + x0 + cc + k] = (double)val;
         }
       }
     }
@@ -828,6 +858,7 @@ struct WeightArgs {
   const int32_t* obs_status;
   const double* tmpl_duv;
   const double* coef;
+  const double* poly;  // [GLH_NPOLY][16] basis polynomials (glh_host.h)
   uint32_t* pt_status;
   int32_t* pt_err_frame;
   double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
@@ -845,35 +876,43 @@ __device__ __forceinline__ void sse_box_of(const int* box, const double* duv, in
   sb[3] = ((double)box[3] + -bev) + duv[1];
 }
 
+constexpr int WEIGHTS_PER_THREAD = 4;
+
 __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
+  __shared__ double tab[16 * GLH_NPOLY];
   const int pt = blockIdx.y;
   if (a.active && !a.active[pt]) return;
-  const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= a.N) return;
-  double ll = 0.0;
-  for (int o = 0; o < a.O; ++o) {
-    if (!a.on[o]) continue;
-    const size_t slot = (size_t)o * a.P + pt;
-    if (a.obs_status[slot] != GLH_OBS_OK) continue;
-    const int* box = a.box + slot * 4;
-    const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
-    double sb[4];
-    sse_box_of(box, a.tmpl_duv + slot * 2, a.tw, a.th, sb);
-    double2 q = reinterpret_cast<const double2*>(a.uv)[slot * a.N + i];
-    if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3]))
-      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
-    double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
-    double val = spline_eval(a.coef + slot * (size_t)a.sse_cap, wo, ho, wo, cv0, cu0, q.x, q.y);
-    ll += val * a.inv2s2[o];
-  }
+  for (int k = threadIdx.x; k < 16 * GLH_NPOLY; k += BLK) tab[k] = a.poly[k];
+  __syncthreads();
   const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
   const double zs = m[17];
-  if (zs != 0.0) {
-    double z = a.particles[((size_t)pt * a.N + i) * 6 + 2];
-    double d = m[16] - z;
-    ll += 1.0 / (2.0 * (zs * zs)) * (d * d);
+  const double dem_scale = zs != 0.0 ? 1.0 / (2.0 * (zs * zs)) : 0.0;
+  for (int it = 0; it < WEIGHTS_PER_THREAD; ++it) {
+    const int i = (blockIdx.x * WEIGHTS_PER_THREAD + it) * BLK + threadIdx.x;
+    if (i >= a.N) break;
+    double ll = 0.0;
+    for (int o = 0; o < a.O; ++o) {
+      if (!a.on[o]) continue;
+      const size_t slot = (size_t)o * a.P + pt;
+      if (a.obs_status[slot] != GLH_OBS_OK) continue;
+      const int* box = a.box + slot * 4;
+      const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
+      double sb[4];
+      sse_box_of(box, a.tmpl_duv + slot * 2, a.tw, a.th, sb);
+      double2 q = reinterpret_cast<const double2*>(a.uv)[slot * a.N + i];
+      if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3]))
+        flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
+      double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
+      double val = spline_eval_poly(tab, a.coef + slot * (size_t)a.sse_cap, wo, ho, wo, cv0, cu0, q.x, q.y);
+      ll += val * a.inv2s2[o];
+    }
+    if (zs != 0.0) {
+      double z = a.particles[((size_t)pt * a.N + i) * 6 + 2];
+      double d = m[16] - z;
+      ll += dem_scale * (d * d);
+    }
+    a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
   }
-  a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
 }
 
 // Test hook: sample a fitted surface (glh_stage_sample); one "point".
@@ -895,11 +934,15 @@ __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K6  systematic resampling (tracker.py:168-176, :222-223), one block per point:
+// K6  systematic resampling (tracker.py:168-176, :222-223) + posterior moments
+//     (tracker.py:72-76, :89-104), one block per point:
 //       wn = w / w.sum()            -- w.sum() reproduces NumPy's pairwise tree bit for bit
 //       c  = cumsum(wn)             -- float64 block scan in LDS
 //       idx_j = #{k : c_k < (j+u)/n} -- binary search (np.searchsorted, side='left')
 //       particles, weights = particles[idx], weights[idx]
+//       mean = sum(w p)/sum(w), sigma = sqrt(sum(w (p-mean)^2)/sum(w)) of the gathered set,
+//       accumulated in one pass around a pivot particle K (shifted moments: no cancellation
+//       at UTM-scale coordinates).
 // ------------------------------------------------------------------------------------------
 struct ResampleArgs {
   const double* particles_in;
@@ -907,27 +950,33 @@ struct ResampleArgs {
   double* particles_out;
   double* weights_out;
   const uint8_t* active;
-  const double* u;  // [P] (host mode) or null
+  const double* u;   // [P] (host mode) or null
   int32_t* idx_out;  // [P][N] or null
+  double* moments;   // [P][12] mean | sigma of the resampled set, or null
   uint32_t* pt_status;
   int32_t* pt_err_frame;
-  const int32_t* leaf_off;  // NumPy pairwise-sum plan (depends only on N)
+  const int32_t* leaf_off;  // NumPy pairwise-sum plan (depends only on N), see glh_host.h
   const int32_t* leaf_len;
-  const int16_t* sum_prog;  // >=0: push leaf, -1: add top two, -2: end of 8192-chunk
+  const int32_t* ops;        // (dst, a, b) per internal node, sorted by level
+  const int32_t* level_off;  // [nlevels + 1]
+  const int32_t* roots;      // chunk roots, summed left to right
   uint64_t seed, step;
-  int32_t N, nleaves, nprog, rng_mode, frame;
+  int32_t N, nleaves, nnodes, nlevels, nroots, rng_mode, frame;
 };
 
 __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double wave_tot[NWAVES];
-  __shared__ double s_total;
+  __shared__ double red[NWAVES];
   double* c = reinterpret_cast<double*>(smem);  // [N] cumulative weights
-  double* leaf_sum = c + a.N;                   // [nleaves]
+  double* node = c + a.N;                       // [nnodes] pairwise-sum tree
   const int pt = blockIdx.x, tid = threadIdx.x;
   if (a.active && !a.active[pt]) return;
   const int N = a.N;
   const double* W = a.weights_in + (size_t)pt * N;
+  // --- stage the weights in LDS with coalesced loads; everything below reads LDS
+  for (int k = tid; k < N; k += BLK) c[k] = W[k];
+  __syncthreads();
   // --- w.sum(): leaves of <= 128 items, 8 interleaved accumulators each (8 lanes per leaf)
   {
     const int sub = tid & 7;
@@ -937,11 +986,11 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       if (len < 8) {
         res = 0.0;
         if (sub == 0)
-          for (int i = 0; i < len; ++i) res += W[off + i];
+          for (int i = 0; i < len; ++i) res += c[off + i];
       } else {
-        double r = W[off + sub];
+        double r = c[off + sub];
         const int body = len - (len & 7);
-        for (int i = 8; i < body; i += 8) r += W[off + i + sub];
+        for (int i = 8; i < body; i += 8) r += c[off + i + sub];
         // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); float add is commutative, so a butterfly
         // gives every lane the same bits
         r += __shfl_xor(r, 1, WAVE);
@@ -949,41 +998,27 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
         r += __shfl_xor(r, 4, WAVE);
         res = r;
         if (sub == 0)
-          for (int i = body; i < len; ++i) res += W[off + i];
+          for (int i = body; i < len; ++i) res += c[off + i];
       }
-      if (sub == 0) leaf_sum[L] = res;
+      if (sub == 0) node[L] = res;
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    double stack[24];
-    int sp = 0;
-    double total = 0.0;
-    bool first = true;
-    for (int k = 0; k < a.nprog; ++k) {
-      int op = a.sum_prog[k];
-      if (op >= 0) {
-        stack[sp++] = leaf_sum[op];
-      } else if (op == -1) {
-        double b = stack[--sp];
-        double x = stack[--sp];
-        stack[sp++] = x + b;
-      } else {
-        double v = stack[--sp];
-        total = first ? v : total + v;
-        first = false;
-      }
+  for (int l = 0; l < a.nlevels; ++l) {
+    for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += BLK) {
+      const int32_t* op = a.ops + 3 * k;
+      node[op[0]] = node[op[1]] + node[op[2]];
     }
-    s_total = total;
+    __syncthreads();
   }
-  __syncthreads();
-  const double total = s_total;
-  // --- cumsum(w / total): contiguous segment per thread, block scan of the segment sums
+  double total = node[a.roots[0]];
+  for (int r = 1; r < a.nroots; ++r) total += node[a.roots[r]];
+  // --- cumsum(w / total) in place: contiguous segment per thread, block scan of segment sums
   const int seg = (N + BLK - 1) / BLK;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   double run = 0.0;
   for (int k = k0; k < k1; ++k) {
-    run += W[k] / total;
+    run += c[k] / total;
     c[k] = run;
   }
   double incl = run;
@@ -1003,7 +1038,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
   if (tid > 0)
     for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
   __syncthreads();
-  // --- positions, search, gather
+  // --- positions (tracker.py:173): pos_j = (j + u) * (1 / n)
   double u;
   if (a.rng_mode == GLH_RNG_HOST) {
     u = a.u[pt];
@@ -1014,29 +1049,89 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     u = u01_halfopen(r[0], r[1]);
   }
   const double inv_n = 1.0 / (double)N;
+  // --- np.searchsorted(c, pos) by its inverse: source k serves the positions with
+  //     c[k-1] < pos_j <= c[k], i.e. j in [f(k-1), f(k)) with f(k) = #{j : pos_j <= c[k]}.
+  //     f is guessed arithmetically and fixed up with the exact float comparison, so the
+  //     indices are exactly searchsorted's; each thread scatters the runs of its own k range.
+  uint16_t* sidx = reinterpret_cast<uint16_t*>(node + a.nnodes);  // [N], N < 65536
+  {
+    auto count_le = [&](double ck) -> int {
+      double g = floor(ck * (double)N - u) + 1.0;
+      int f = g < 0.0 ? 0 : (g > (double)N ? N : (int)g);
+      while (f < N && ((double)f + u) * inv_n <= ck) ++f;
+      while (f > 0 && ((double)(f - 1) + u) * inv_n > ck) --f;
+      return f;
+    };
+    int f_prev = k0 > 0 ? count_le(c[k0 - 1]) : 0;
+    for (int k = k0; k < k1; ++k) {
+      int f = count_le(c[k]);
+      for (int j = f_prev; j < f; ++j) sidx[j] = (uint16_t)k;
+      f_prev = f;
+    }
+    if (k1 == N && k0 < N) {
+      // positions beyond c[N-1] (searchsorted == N: IndexError in the reference): clamp + flag
+      if (f_prev < N) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+      for (int j = f_prev; j < N; ++j) sidx[j] = (uint16_t)(N - 1);
+    }
+  }
+  __syncthreads();
+  // --- gather + moments
   const double* Pin = a.particles_in + (size_t)pt * N * 6;
   double* Pout = a.particles_out + (size_t)pt * N * 6;
   double* Wout = a.weights_out + (size_t)pt * N;
-  for (int j = tid; j < N; j += BLK) {
-    double pos = ((double)j + u) * inv_n;
-    int lo = 0, hi = N;  // first k with c[k] >= pos
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (c[mid] < pos)
-        lo = mid + 1;
-      else
-        hi = mid;
+  double K[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) K[k] = Pin[k];  // pivot: the point's first particle
+  double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+  constexpr int GU = 4;  // independent gathers in flight per thread
+  for (int j0 = tid; j0 < N; j0 += GU * BLK) {
+    int lo[GU];
+    double2 v0[GU], v1[GU], v2[GU];
+    double w[GU];
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      const int j = j0 + g * BLK;
+      lo[g] = j < N ? sidx[j] : 0;
     }
-    if (lo >= N) {
-      lo = N - 1;
-      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)lo[g] * 6);
+      v0[g] = src[0]; v1[g] = src[1]; v2[g] = src[2];
+      w[g] = W[lo[g]];
     }
-    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)lo * 6);
-    double2 v0 = src[0], v1 = src[1], v2 = src[2];
-    double2* dst = reinterpret_cast<double2*>(Pout + (size_t)j * 6);
-    dst[0] = v0; dst[1] = v1; dst[2] = v2;
-    Wout[j] = W[lo];
-    if (a.idx_out) a.idx_out[(size_t)pt * N + j] = lo;
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      const int j = j0 + g * BLK;
+      if (j < N) {
+        double2* dst = reinterpret_cast<double2*>(Pout + (size_t)j * 6);
+        dst[0] = v0[g]; dst[1] = v1[g]; dst[2] = v2[g];
+        Wout[j] = w[g];
+        if (a.idx_out) a.idx_out[(size_t)pt * N + j] = lo[g];
+        const double x[6] = {v0[g].x, v0[g].y, v1[g].x, v1[g].y, v2[g].x, v2[g].y};
+        s0 += w[g];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double d = x[k] - K[k];
+          double wd = w[g] * d;
+          s1[k] += wd;
+          s2[k] += wd * d;
+        }
+      }
+    }
+  }
+  if (a.moments) {
+    s0 = block_sum(s0, red);
+    double* out = a.moments + (size_t)pt * 12;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double m1 = block_sum(s1[k], red) / s0;
+      double m2 = block_sum(s2[k], red) / s0;
+      if (tid == 0) {
+        double var = m2 - m1 * m1;
+        out[k] = K[k] + m1;
+        out[6 + k] = sqrt(var > 0.0 ? var : 0.0);
+      }
+    }
   }
 }
 

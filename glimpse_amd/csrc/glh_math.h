@@ -211,18 +211,83 @@ GLH_HD void spline_basis(double x, int q, int n, double x0, double* h) {
 //   d = (b1 - b0) / n ;  c0 = b0 + d * 0.5   (np.arange start)
 GLH_HD double cell_origin(double b0, double b1, int n) { return b0 + ((b1 - b0) / n) * 0.5; }
 
+// Same basis in local coordinates xl = x - x0 (sites at 0..n-1).  The knot differences are
+// small integers (1..4, and 5 only when n == 6: the first and last not-a-knot intervals are
+// 2 wide), so the de Boor divisions become multiplications by exact (1, 1/2, 1/4) or
+// correctly rounded (1/3, 1/5) reciprocals: <= 1 ulp from the division form.
+GLH_HD void spline_basis_local(double xl, int q, int n, double* h) {
+  const int l = q + 3;
+  const double rcp[6] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2};
+  double hh[3];
+  h[0] = 1.0;
+  h[1] = h[2] = h[3] = 0.0;
+  for (int j = 1; j <= 3; ++j) {
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.0;
+    for (int i = 0; i < j; ++i) {
+      const int li = l + i + 1, lj = li - j;
+      const int ki = li <= 3 ? 0 : (li >= n ? n - 1 : li - 2);
+      const int kj = lj <= 3 ? 0 : (lj >= n ? n - 1 : lj - 2);
+      const double f = hh[i] * rcp[ki - kj];
+      h[i] = h[i] + f * ((double)ki - xl);
+      h[i + 1] = f * (xl - (double)kj);
+    }
+  }
+}
+
+// ---- piecewise-polynomial form of the same basis -------------------------------------------
+// On knot interval q the 4 non-zero B-splines are cubics in s = xl - start(q).  Their
+// coefficient matrices depend on n only near the ends: for n >= 9 there are 7 distinct
+// matrices (3 at the left end, 1 uniform interior, 3 at the right end); n = 4..8 have their
+// own (1 + 2 + 3 + 4 + 5).  GLH_NPOLY matrices of 16 doubles, built on the host
+// (glh_host.h: basis_poly_table) from the de Boor recursion above.
+#define GLH_NPOLY 22
+GLH_HD int spline_poly_index(int n, int q) {
+  if (n >= 9) return q <= 2 ? q : (q >= n - 6 ? 4 + q - (n - 6) : 3);
+  // n = 4: 7 | 5: 8..9 | 6: 10..12 | 7: 13..16 | 8: 17..21
+  return 7 + ((n - 4) * (n - 3)) / 2 + q;
+}
+GLH_HD double spline_interval_start(int q) { return q == 0 ? 0.0 : (double)(q + 1); }
+
+// h[m] = ((c3 s + c2) s + c1) s + c0 with the matrix laid out [m][d]
+GLH_HD void spline_basis_poly(const double* tab, double xl, int q, int n, double* h) {
+  const double* c = tab + 16 * spline_poly_index(n, q);
+  const double s = xl - spline_interval_start(q);
+  for (int m2 = 0; m2 < 4; ++m2) h[m2] = ((c[4 * m2 + 3] * s + c[4 * m2 + 2]) * s + c[4 * m2 + 1]) * s + c[4 * m2];
+}
+
+GLH_HD double spline_eval_poly(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,
+                               double cu0, double u, double v) {
+  double vl = v - cv0, ul = u - cu0;
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  vl = vl < 0.0 ? 0.0 : (vl > vmax ? vmax : vl);
+  ul = ul < 0.0 ? 0.0 : (ul > umax ? umax : ul);
+  const int qv = spline_interval(vl, ho);
+  const int qu = spline_interval(ul, wo);
+  double hv[4], hu[4];
+  spline_basis_poly(tab, vl, qv, ho, hv);
+  spline_basis_poly(tab, ul, qu, wo, hu);
+  double sp = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double* row = coef + (size_t)(qv + i) * ld + qu;
+    for (int j = 0; j < 4; ++j) sp += row[j] * hv[i] * hu[j];
+  }
+  return sp;
+}
+
 // Evaluate the tensor spline with coefficients coef[ho][wo] (row stride ld) at (u, v);
 // arguments are clamped to the outermost cell centres (FITPACK fpbisp).
 GLH_HD double spline_eval(const double* coef, int ld, int ho, int wo, double cv0, double cu0,
                           double u, double v) {
-  double vmax = cv0 + (double)(ho - 1), umax = cu0 + (double)(wo - 1);
-  double vv = v < cv0 ? cv0 : (v > vmax ? vmax : v);
-  double uu = u < cu0 ? cu0 : (u > umax ? umax : u);
-  int qv = spline_interval(vv - cv0, ho);
-  int qu = spline_interval(uu - cu0, wo);
+  double vl = v - cv0, ul = u - cu0;
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  vl = vl < 0.0 ? 0.0 : (vl > vmax ? vmax : vl);
+  ul = ul < 0.0 ? 0.0 : (ul > umax ? umax : ul);
+  const int qv = spline_interval(vl, ho);
+  const int qu = spline_interval(ul, wo);
   double hv[4], hu[4];
-  spline_basis(vv, qv, ho, cv0, hv);
-  spline_basis(uu, qu, wo, cu0, hu);
+  spline_basis_local(vl, qv, ho, hv);
+  spline_basis_local(ul, qu, wo, hu);
   double sp = 0.0;
   for (int i = 0; i < 4; ++i) {
     const double* row = coef + (size_t)(qv + i) * ld + qu;

@@ -83,7 +83,7 @@ struct glh_ctx {
   int cur = 0;  // current particle/weight buffer
   int frame = 0;
   bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false;
-  int tile_cap = 0, search_cap = 0, sse_cap = 0, lds_ssd_bytes = 0;
+  int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
   double *particles[2] = {nullptr, nullptr}, *weights[2] = {nullptr, nullptr};
@@ -97,10 +97,11 @@ struct glh_ctx {
   float *tmpl_tile32 = nullptr, *search = nullptr;
   double *sse = nullptr, *sse_copy = nullptr;
   double* lu = nullptr;
+  double* poly = nullptr;
   int64_t* lu_off = nullptr;
-  int32_t *leaf_off = nullptr, *leaf_len = nullptr;
-  int16_t* sum_prog = nullptr;
-  int nleaves = 0, nprog = 0;
+  int32_t *leaf_off = nullptr, *leaf_len = nullptr, *sum_ops = nullptr, *level_off = nullptr, *roots = nullptr;
+  int nleaves = 0, nnodes = 0, nlevels = 0, nroots = 0;
+  int moments_frame = -1;  // history slot already filled by the fused resample kernel
   size_t normals_cap = 0;
   // profiling
   bool profiling = false;
@@ -184,18 +185,6 @@ extern "C" int glh_device_count(int* count) {
   return GLH_OK;
 }
 
-static int ssd_lds_bytes(int max_dim, int max_tile) {
-  // template [th][twp] + at least th rows (one output row) of the widest band; prefer ~8 rows
-  int twp = (max_tile + 7) & ~7;
-  int ld = (max_dim + 24 + 3) & ~3;
-  long need_min = (long)max_tile * twp + (long)ld * max_tile;
-  long want = (long)max_tile * twp + (long)ld * (max_tile - 1 + 8);
-  long cap = 96 * 1024 / 4;
-  long floats = want < cap ? want : cap;
-  if (floats < need_min) floats = need_min;
-  return (int)(floats * 4);
-}
-
 extern "C" int glh_destroy(glh_ctx* c) {
   if (!c) return GLH_OK;
   (void)hipSetDevice(c->cfg.device_id);
@@ -218,8 +207,8 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search);
-  dfree(c->sse); dfree(c->sse_copy); dfree(c->lu); dfree(c->lu_off); dfree(c->leaf_off);
-  dfree(c->leaf_len); dfree(c->sum_prog);
+  dfree(c->sse); dfree(c->sse_copy); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->leaf_off);
+  dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GLH_OK;
@@ -237,8 +226,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   if (k.max_tile < 5 || k.max_tile > 127) return fail(GLH_E_INVALID, "max_tile must be in [5, 127]");
   if (k.max_search_dim < k.max_tile + 3 || k.max_search_dim > 2000)
     return fail(GLH_E_INVALID, "max_search_dim must be in [max_tile + 3, 2000]");
-  if ((size_t)k.max_particles * 8 + 1024 > 150 * 1024)
-    return fail(GLH_E_UNSUPPORTED, "max_particles %d exceeds the LDS-resident scan (<= 19000)", k.max_particles);
+  if ((size_t)k.max_particles * 10 + 4096 > 150 * 1024)
+    return fail(GLH_E_UNSUPPORTED, "max_particles %d exceeds the LDS-resident scan (<= 14900)", k.max_particles);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (k.device_id < 0 || k.device_id >= ndev)
@@ -251,7 +240,6 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   c->tile_cap = k.max_tile * k.max_tile;
   c->search_cap = k.max_search_dim * k.max_search_dim;
   c->sse_cap = c->search_cap;
-  c->lds_ssd_bytes = ssd_lds_bytes(k.max_search_dim, k.max_tile);
   const size_t NBmax = (N + BLK - 1) / BLK;
   int rc = GLH_OK;
   auto A = [&](int r) {
@@ -306,6 +294,13 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
           hipMemcpy(c->lu_off, off.data(), (maxn + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(GLH_E_HIP, "upload of the spline LU table failed");
     }
+  }
+  if (rc == GLH_OK) {
+    std::vector<double> tab(16 * GLH_NPOLY);
+    basis_poly_table(tab.data());
+    A(dalloc(&c->poly, tab.size()));
+    if (rc == GLH_OK && hipMemcpy(c->poly, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(GLH_E_HIP, "upload of the spline basis table failed");
   }
   if (rc == GLH_OK) {
     // kernels that may use more than the default 64 KB of dynamic LDS
@@ -441,20 +436,24 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->moments, nm, (double)NAN);
   HIPCHK(hipGetLastError());
   // NumPy pairwise-sum plan for this N
-  std::vector<int32_t> off, len;
-  std::vector<int16_t> prog;
-  pairwise_plan(N, off, len, prog);
-  dfree(c->leaf_off);
-  dfree(c->leaf_len);
-  dfree(c->sum_prog);
-  CHK(dalloc(&c->leaf_off, off.size()));
-  CHK(dalloc(&c->leaf_len, len.size()));
-  CHK(dalloc(&c->sum_prog, prog.size()));
-  HIPCHK(hipMemcpy(c->leaf_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->leaf_len, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->sum_prog, prog.data(), prog.size() * sizeof(int16_t), hipMemcpyHostToDevice));
-  c->nleaves = (int)off.size();
-  c->nprog = (int)prog.size();
+  PairwisePlan pl;
+  pairwise_plan(N, pl);
+  dfree(c->leaf_off); dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
+  CHK(dalloc(&c->leaf_off, pl.leaf_off.size()));
+  CHK(dalloc(&c->leaf_len, pl.leaf_len.size()));
+  CHK(dalloc(&c->sum_ops, pl.ops.size()));
+  CHK(dalloc(&c->level_off, pl.level_off.size()));
+  CHK(dalloc(&c->roots, pl.roots.size()));
+  HIPCHK(hipMemcpy(c->leaf_off, pl.leaf_off.data(), pl.leaf_off.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->leaf_len, pl.leaf_len.data(), pl.leaf_len.size() * 4, hipMemcpyHostToDevice));
+  if (!pl.ops.empty()) HIPCHK(hipMemcpy(c->sum_ops, pl.ops.data(), pl.ops.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->level_off, pl.level_off.data(), pl.level_off.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->roots, pl.roots.data(), pl.roots.size() * 4, hipMemcpyHostToDevice));
+  c->nleaves = (int)pl.leaf_off.size();
+  c->nnodes = pl.nnodes;
+  c->nlevels = (int)pl.level_off.size() - 1;
+  c->nroots = (int)pl.roots.size();
+  c->moments_frame = -1;
   return GLH_OK;
 }
 
@@ -504,6 +503,7 @@ extern "C" int glh_set_active(glh_ctx* c, const uint8_t* active) {
 }
 extern "C" int glh_set_particles(glh_ctx* c, const double* p) {
   CHK(need_seq(c));
+  c->moments_frame = -1;
   if (!p) return fail(GLH_E_INVALID, "particles is null");
   UPLOAD(c->particles[c->cur], p, (size_t)c->P * c->N * 6, double);
   return GLH_OK;
@@ -516,6 +516,7 @@ extern "C" int glh_get_particles(glh_ctx* c, double* p) {
 }
 extern "C" int glh_set_weights(glh_ctx* c, const double* w) {
   CHK(need_seq(c));
+  c->moments_frame = -1;
   if (!w) return fail(GLH_E_INVALID, "weights is null");
   UPLOAD(c->weights[c->cur], w, (size_t)c->P * c->N, double);
   return GLH_OK;
@@ -595,6 +596,7 @@ extern "C" int glh_init_particles(glh_ctx* c, int rng_mode, const double* normal
   } else if (rng_mode != GLH_RNG_PHILOX) {
     return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
   }
+  c->moments_frame = -1;
   InitArgs a{};
   a.particles = c->particles[c->cur];
   a.weights = c->weights[c->cur];
@@ -636,6 +638,7 @@ static int check_images(glh_ctx* c, const int32_t* images) {
 // evolve (optional) + project into the given images + bbox partials
 static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng_mode, uint64_t seed,
                                  uint64_t step, const int32_t* images) {
+  if (do_evolve) c->moments_frame = -1;
   EvolveArgs a{};
   a.particles = c->particles[c->cur];
   a.motion = c->motion;
@@ -775,7 +778,6 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
     sa.tile_cap = c->tile_cap;
     sa.search_cap = c->search_cap;
     sa.sse_cap = c->sse_cap;
-    sa.lds_floats = c->lds_ssd_bytes / 4;
     sa.box = c->box;
     sa.obs_status = c->obs_status;
     sa.search = c->search;
@@ -783,7 +785,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
     sa.sse = c->sse;
     {
       StageTimer t(c, ST_SSD);
-      hipLaunchKernelGGL(k_ssd, dim3(8, c->P), dim3(BLK), (size_t)c->lds_ssd_bytes, c->stream, sa);
+      hipLaunchKernelGGL(k_ssd, dim3(c->ssd_blocks, c->P), dim3(BLK), ssd_lds_bytes(c->tw, c->th), c->stream, sa);
     }
     HIPCHK(hipGetLastError());
     SplineFitArgs sf{};
@@ -805,6 +807,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
     }
     HIPCHK(hipGetLastError());
   }
+  c->moments_frame = -1;
   WeightArgs wa{};
   wa.particles = c->particles[c->cur];
   wa.weights = c->weights[c->cur];
@@ -815,6 +818,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.obs_status = c->obs_status;
   wa.tmpl_duv = c->tmpl_duv;
   wa.coef = c->sse;
+  wa.poly = c->poly;
   wa.pt_status = c->pt_status;
   wa.pt_err_frame = c->pt_err_frame;
   for (int o = 0; o < O; ++o) {
@@ -830,7 +834,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.frame = c->frame;
   {
     StageTimer t(c, ST_WEIGHTS);
-    hipLaunchKernelGGL(k_weights, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, wa);
+    hipLaunchKernelGGL(k_weights, dim3((c->NB + WEIGHTS_PER_THREAD - 1) / WEIGHTS_PER_THREAD, c->P), dim3(BLK), 0, c->stream, wa);
   }
   HIPCHK(hipGetLastError());
   return GLH_OK;
@@ -863,14 +867,19 @@ extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t 
   a.idx_out = c->keep_idx ? c->idx : nullptr;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
+  a.moments = c->moments + (size_t)c->frame * c->P * 12;  // fused particle_mean / sigma of frame c->frame
   a.leaf_off = c->leaf_off;
   a.leaf_len = c->leaf_len;
-  a.sum_prog = c->sum_prog;
+  a.ops = c->sum_ops;
+  a.level_off = c->level_off;
+  a.roots = c->roots;
   a.seed = seed;
   a.step = step;
   a.N = c->N;
   a.nleaves = c->nleaves;
-  a.nprog = c->nprog;
+  a.nnodes = c->nnodes;
+  a.nlevels = c->nlevels;
+  a.nroots = c->nroots;
   a.rng_mode = rng_mode;
   a.frame = c->frame;
   if (c->have_active) {
@@ -882,11 +891,12 @@ extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t 
   }
   {
     StageTimer t(c, ST_RESAMPLE);
-    size_t lds = ((size_t)c->N + c->nleaves) * sizeof(double);
+    size_t lds = ((size_t)c->N + c->nnodes) * sizeof(double) + (size_t)c->N * sizeof(uint16_t);
     hipLaunchKernelGGL(k_resample, dim3(c->P), dim3(BLK), lds, c->stream, a);
   }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
+  c->moments_frame = c->frame;
   return GLH_OK;
 }
 
@@ -894,6 +904,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
   CHK(need_seq(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
+  if (c->moments_frame == frame) return GLH_OK;  // already written by the fused resample kernel
   return launch_moments(c, c->moments + (size_t)frame * c->P * 12, 12, 1);
 }
 
@@ -1124,7 +1135,6 @@ extern "C" int glh_stage_ssd(int dev, const float* search, int hs, int ws, const
   if (!search || !templ || !sse || th <= 0 || tw <= 0 || hs < th || ws < tw) return fail(GLH_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(dev));
   const int ho = hs - th + 1, wo = ws - tw + 1;
-  if ((wo + SSD_W - 1) / SSD_W > BLK) return fail(GLH_E_INVALID, "surface too wide");
   DevBuf ds, dt, dbox, dst, dout;
   CHK(ds.up(search, (size_t)hs * ws * 4));
   CHK(dt.up(templ, (size_t)th * tw * 4));
@@ -1141,14 +1151,14 @@ extern "C" int glh_stage_ssd(int dev, const float* search, int hs, int ws, const
   a.tile_cap = th * tw;
   a.search_cap = hs * ws;
   a.sse_cap = ho * wo;
-  int lds = ssd_lds_bytes(ws, th > tw ? th : tw);
-  a.lds_floats = lds / 4;
+  size_t lds = ssd_lds_bytes(tw, th);
+  HIPCHK(hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   a.box = dbox.as<int32_t>();
   a.obs_status = dst.as<int32_t>();
   a.search = ds.as<float>();
   a.tmpl = dt.as<float>();
   a.sse = dout.as<double>();
-  hipLaunchKernelGGL(k_ssd, dim3(8, 1), dim3(BLK), (size_t)lds, 0, a);
+  hipLaunchKernelGGL(k_ssd, dim3(4, 1), dim3(BLK), lds, 0, a);
   CHK(finish());
   std::vector<double> tmp((size_t)ho * wo);
   CHK(dout.down(tmp.data(), tmp.size() * 8));
@@ -1206,13 +1216,12 @@ extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const
 
 extern "C" int glh_stage_resample(int dev, const double* weights, int n, double u, int64_t* idx) {
   if (!weights || !idx || n <= 0) return fail(GLH_E_INVALID, "bad argument");
-  if ((size_t)n * 8 + 1024 > 150 * 1024) return fail(GLH_E_UNSUPPORTED, "n too large for the LDS-resident scan");
+  if ((size_t)n * 10 + 4096 > 150 * 1024) return fail(GLH_E_UNSUPPORTED, "n too large for the LDS-resident scan");
   HIPCHK(hipSetDevice(dev));
-  std::vector<int32_t> off, len;
-  std::vector<int16_t> prog;
-  pairwise_plan(n, off, len, prog);
+  PairwisePlan pl;
+  pairwise_plan(n, pl);
   std::vector<double> pin((size_t)n * 6, 0.0);
-  DevBuf dw, dpi, dpo, dwo, du, didx, dst, def, doff, dlen, dprog;
+  DevBuf dw, dpi, dpo, dwo, du, didx, dst, def, doff, dlen, dops, dlev, droot;
   CHK(dw.up(weights, (size_t)n * 8));
   CHK(dpi.up(pin.data(), pin.size() * 8));
   CHK(dpo.alloc(pin.size() * 8));
@@ -1223,9 +1232,11 @@ extern "C" int glh_stage_resample(int dev, const double* weights, int n, double 
   int32_t ef = 0x7f7f7f7f;
   CHK(dst.up(&st0, 4));
   CHK(def.up(&ef, 4));
-  CHK(doff.up(off.data(), off.size() * 4));
-  CHK(dlen.up(len.data(), len.size() * 4));
-  CHK(dprog.up(prog.data(), prog.size() * 2));
+  CHK(doff.up(pl.leaf_off.data(), pl.leaf_off.size() * 4));
+  CHK(dlen.up(pl.leaf_len.data(), pl.leaf_len.size() * 4));
+  CHK(dops.up(pl.ops.data(), pl.ops.size() * 4));
+  CHK(dlev.up(pl.level_off.data(), pl.level_off.size() * 4));
+  CHK(droot.up(pl.roots.data(), pl.roots.size() * 4));
   ResampleArgs a{};
   a.particles_in = dpi.as<double>();
   a.weights_in = dw.as<double>();
@@ -1234,17 +1245,23 @@ extern "C" int glh_stage_resample(int dev, const double* weights, int n, double 
   a.active = nullptr;
   a.u = du.as<double>();
   a.idx_out = didx.as<int32_t>();
+  a.moments = nullptr;
   a.pt_status = dst.as<uint32_t>();
   a.pt_err_frame = def.as<int32_t>();
   a.leaf_off = doff.as<int32_t>();
   a.leaf_len = dlen.as<int32_t>();
-  a.sum_prog = dprog.as<int16_t>();
+  a.ops = dops.as<int32_t>();
+  a.level_off = dlev.as<int32_t>();
+  a.roots = droot.as<int32_t>();
   a.N = n;
-  a.nleaves = (int)off.size();
-  a.nprog = (int)prog.size();
+  a.nleaves = (int)pl.leaf_off.size();
+  a.nnodes = pl.nnodes;
+  a.nlevels = (int)pl.level_off.size() - 1;
+  a.nroots = (int)pl.roots.size();
   a.rng_mode = GLH_RNG_HOST;
   a.frame = 0;
-  hipLaunchKernelGGL(k_resample, dim3(1), dim3(BLK), ((size_t)n + off.size()) * 8, 0, a);
+  HIPCHK(hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+  hipLaunchKernelGGL(k_resample, dim3(1), dim3(BLK), ((size_t)n + pl.nnodes) * 8 + (size_t)n * 2, 0, a);
   CHK(finish());
   std::vector<int32_t> tmp(n);
   CHK(didx.down(tmp.data(), (size_t)n * 4));

@@ -73,15 +73,14 @@ void hc_spline_sample(const double* z, int ho, int wo, const double* box, const 
   for (int i = 0; i < n; ++i) out[i] = spline_eval(c.data(), wo, ho, wo, cv0, cu0, uv[2 * i], uv[2 * i + 1]);
 }
 
-// NumPy pairwise sum through the same leaf plan + postfix program the resample kernel runs
+// NumPy pairwise sum through the same leaf plan + level-sorted tree the resample kernel runs
 double hc_pairwise_sum(const double* w, int n) {
-  std::vector<int32_t> off, len;
-  std::vector<int16_t> prog;
-  pairwise_plan(n, off, len, prog);
-  std::vector<double> leaf(off.size());
-  for (size_t L = 0; L < off.size(); ++L) {
-    const double* x = w + off[L];
-    int m = len[L];
+  PairwisePlan pl;
+  pairwise_plan(n, pl);
+  std::vector<double> node(pl.nnodes);
+  for (size_t L = 0; L < pl.leaf_off.size(); ++L) {
+    const double* x = w + pl.leaf_off[L];
+    int m = pl.leaf_len[L];
     double res;
     if (m < 8) {
       res = 0.0;
@@ -97,17 +96,35 @@ double hc_pairwise_sum(const double* w, int n) {
       res = (a01 + a23) + (a45 + a67);
       for (int i = body; i < m; ++i) res += x[i];
     }
-    leaf[L] = res;
+    node[L] = res;
   }
-  double stack[32], total = 0.0;
-  int sp = 0;
-  bool first = true;
-  for (int16_t op : prog) {
-    if (op >= 0) stack[sp++] = leaf[op];
-    else if (op == -1) { double b = stack[--sp]; double a = stack[--sp]; stack[sp++] = a + b; }
-    else { double v = stack[--sp]; total = first ? v : total + v; first = false; }
-  }
+  int nlevels = (int)pl.level_off.size() - 1;
+  for (int l = 0; l < nlevels; ++l)
+    for (int k = pl.level_off[l]; k < pl.level_off[l + 1]; ++k)
+      node[pl.ops[3 * k]] = node[pl.ops[3 * k + 1]] + node[pl.ops[3 * k + 2]];
+  double total = node[pl.roots[0]];
+  for (size_t r = 1; r < pl.roots.size(); ++r) total += node[pl.roots[r]];
   return total;
+}
+
+// max |poly-table basis - de Boor basis| over all intervals of n-site splines, nsamp points each
+double hc_poly_basis_error(int nmax, int nsamp) {
+  std::vector<double> tab(16 * GLH_NPOLY);
+  basis_poly_table(tab.data());
+  double worst = 0.0;
+  for (int n = 4; n <= nmax; ++n)
+    for (int q = 0; q <= n - 4; ++q) {
+      double a = spline_interval_start(q), b = knot_local(q + 4, n);
+      for (int k = 0; k <= nsamp; ++k) {
+        double xl = a + (b - a) * k / nsamp;
+        if (spline_interval(xl, n) != q) continue;  // right end belongs to the next interval
+        double h1[4], h2[4];
+        spline_basis_local(xl, q, n, h1);
+        spline_basis_poly(tab.data(), xl, q, n, h2);
+        for (int m = 0; m < 4; ++m) worst = fmax(worst, fabs(h1[m] - h2[m]));
+      }
+    }
+  return worst;
 }
 
 void hc_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {

@@ -82,7 +82,7 @@ def test_stage_resample_bit_exact(lib, golden):
         idx = lib.stage_resample(w, float(g[f"r{i}_u"]))
         np.testing.assert_array_equal(idx, g[f"r{i}_idx"])
     rng = np.random.default_rng(11)
-    for n in [64, 255, 256, 257, 3000, 8192, 8193, 16000]:
+    for n in [64, 255, 256, 257, 3000, 8192, 8193, 12000]:
         for trial in range(3):
             w = np.exp(-rng.random(n) * rng.choice([1.0, 20.0, 200.0])) + 1e-300
             u = rng.random()

@@ -23,6 +23,7 @@ def hc():
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", OUT, SRC], check=True)
     lib = C.CDLL(OUT)
     lib.hc_pairwise_sum.restype = C.c_double
+    lib.hc_poly_basis_error.restype = C.c_double
     return lib
 
 
@@ -120,6 +121,11 @@ def test_spline_fit_and_eval_match_reference(hc, golden):
         hc.hc_spline_sample(p(z), z.shape[0], z.shape[1], p(np.ascontiguousarray(box)), p(np.ascontiguousarray(uv)),
                             len(uv), p(out))
         np.testing.assert_allclose(out, val, rtol=0, atol=5e-13)
+
+
+def test_polynomial_basis_table_equals_de_boor(hc):
+    # the 22 per-interval cubic matrices reproduce the de Boor basis for every n and interval
+    assert hc.hc_poly_basis_error(64, 37) < 4e-16
 
 
 def test_pairwise_sum_plan_is_numpy_sum(hc):
