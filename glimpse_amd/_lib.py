@@ -83,6 +83,7 @@ SIGNATURES = {
     "glh_get_likelihood_debug": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "glh_set_debug": (_I, [_P, _I]),
     "glh_get_resample_indices": (_I, [_P, _P]),
+    "glh_get_log_likelihoods": (_I, [_P, _I, _P]),
     "glh_profile_enable": (_I, [_P, _I]),
     "glh_profile_reset": (_I, [_P]),
     "glh_stage_count": (_I, []),
@@ -344,6 +345,11 @@ class Context:
         sse = np.empty((hs - th + 1, ws - tw + 1)) if want_sse else None
         check(self.lib.glh_get_likelihood_debug(self.handle, obs, point, None, None, _ptr(search), _ptr(sse)))
         return {"uv": uv, "box": box, "search": search, "sse": sse}
+
+    def log_likelihoods(self, obs):
+        out = np.empty((self.P, self.N))
+        check(self.lib.glh_get_log_likelihoods(self.handle, obs, _ptr(out)))
+        return out
 
     def resample_indices(self):
         out = np.empty((self.P, self.N), dtype=np.int32)

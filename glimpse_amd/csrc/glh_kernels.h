@@ -859,6 +859,7 @@ struct WeightArgs {
   const double* tmpl_duv;
   const double* coef;
   const double* poly;  // [GLH_NPOLY][16] basis polynomials (glh_host.h)
+  double* ll_out;      // optional [O][P][N] per-observer log likelihoods (debug), NaN = skipped
   uint32_t* pt_status;
   int32_t* pt_err_frame;
   double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
@@ -892,8 +893,9 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
     if (i >= a.N) break;
     double ll = 0.0;
     for (int o = 0; o < a.O; ++o) {
-      if (!a.on[o]) continue;
       const size_t slot = (size_t)o * a.P + pt;
+      if (a.ll_out) a.ll_out[slot * a.N + i] = NAN;
+      if (!a.on[o]) continue;
       if (a.obs_status[slot] != GLH_OBS_OK) continue;
       const int* box = a.box + slot * 4;
       const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
@@ -904,6 +906,7 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
         flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
       double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       double val = spline_eval_poly(tab, a.coef + slot * (size_t)a.sse_cap, wo, ho, wo, cv0, cu0, q.x, q.y);
+      if (a.ll_out) a.ll_out[slot * a.N + i] = val * a.inv2s2[o];
       ll += val * a.inv2s2[o];
     }
     if (zs != 0.0) {

@@ -95,7 +95,7 @@ struct glh_ctx {
   int32_t *tmpl_box = nullptr, *tmpl_hist_n = nullptr, *tmpl_valid = nullptr;
   double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
   float *tmpl_tile32 = nullptr, *search = nullptr;
-  double *sse = nullptr, *sse_copy = nullptr;
+  double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
   int64_t* lu_off = nullptr;
@@ -207,7 +207,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search);
-  dfree(c->sse); dfree(c->sse_copy); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->leaf_off);
+  dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -545,6 +545,13 @@ extern "C" int glh_get_observer_status(glh_ctx* c, int32_t* st) {
   DOWNLOAD(st, c->obs_status, (size_t)c->cfg.n_observers * c->P, int32_t);
   return GLH_OK;
 }
+extern "C" int glh_get_log_likelihoods(glh_ctx* c, int o, double* ll) {
+  CHK(need_seq(c));
+  CHK(check_obs(c, o));
+  if (!ll || !c->keep_sse || !c->ll_dbg) return fail(GLH_E_STATE, "log-likelihood capture is off (glh_set_debug)");
+  DOWNLOAD(ll, c->ll_dbg + (size_t)o * c->P * c->N, (size_t)c->P * c->N, double);
+  return GLH_OK;
+}
 extern "C" int glh_get_search_boxes(glh_ctx* c, int32_t* boxes) {
   CHK(need_seq(c));
   if (!boxes) return fail(GLH_E_INVALID, "boxes is null");
@@ -567,6 +574,8 @@ extern "C" int glh_set_debug(glh_ctx* c, int keep) {
     if (!c->sse_copy)
       CHK(dalloc(&c->sse_copy, (size_t)c->cfg.n_observers * c->cfg.max_points * (size_t)c->sse_cap));
     if (!c->idx) CHK(dalloc(&c->idx, (size_t)c->cfg.max_points * c->cfg.max_particles));
+    if (!c->ll_dbg)
+      CHK(dalloc(&c->ll_dbg, (size_t)c->cfg.n_observers * c->cfg.max_points * c->cfg.max_particles));
   }
   return GLH_OK;
 }
@@ -819,6 +828,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.tmpl_duv = c->tmpl_duv;
   wa.coef = c->sse;
   wa.poly = c->poly;
+  wa.ll_out = c->keep_sse ? c->ll_dbg : nullptr;
   wa.pt_status = c->pt_status;
   wa.pt_err_frame = c->pt_err_frame;
   for (int o = 0; o < O; ++o) {
@@ -896,7 +906,8 @@ extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t 
   }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
-  c->moments_frame = c->frame;
+  // the fused moments cover every point only when no active mask was in force
+  c->moments_frame = c->have_active ? -1 : c->frame;
   return GLH_OK;
 }
 
@@ -904,7 +915,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
   CHK(need_seq(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
-  if (c->moments_frame == frame) return GLH_OK;  // already written by the fused resample kernel
+  if (c->moments_frame == frame && !c->have_active) return GLH_OK;  // written by the fused resample kernel
   return launch_moments(c, c->moments + (size_t)frame * c->P * 12, 12, 1);
 }
 

@@ -1,0 +1,449 @@
+"""`Tracker`: drop-in for `glimpse.Tracker` (/root/reference/src/glimpse/track/tracker.py).
+
+Same constructor, `track()` signature, result container and error behaviour as the
+reference, but the per-frame particle-filter step (tracker.py:326-357) runs on an MI355X
+through libglimpse_hip.so for ALL tracks at once: the reference loops tracks outermost
+(tracker.py:381-387), this loops frames outermost -- legal because tracks are independent.
+
+There is no CPU fallback: without the HIP library every method that computes raises.
+
+Random numbers.  The reference draws from the legacy global `np.random` stream, one whole
+track after another.  `rng="numpy"` (default) reproduces exactly that
+stream on the host and feeds it to the device, so `np.random.seed(s); tracker.track(...)`
+gives the reference's particles, indices and posteriors.  `rng="philox"` draws on the device
+(counter-based Philox4x32-10) and is what large runs use.
+"""
+import datetime
+import warnings as _warnings
+
+import numpy as np
+
+from . import _lib
+from .motion import CartesianMotion
+from .tracks import Tracks
+
+_ERRORS = (
+    (_lib.PT_NAN, ValueError, "Some particles have missing (NaN) values"),
+    (_lib.PT_TEMPLATE_OOB, IndexError, "Box extends beyond grid bounds"),
+    (_lib.PT_CONST_TILE, ValueError, "Template tile has zero variance"),
+    (_lib.PT_SAMPLE_OUTSIDE, ValueError, "Some sampling points are outside box"),
+    (_lib.PT_RESAMPLE_CLAMP, IndexError, "Resampling index out of bounds (weights do not sum to 1)"),
+)
+_OOB_WARNING = "Particles too close to or beyond image bounds, skipping image"
+_MAX_HOST_DRAWS_BYTES = 4 << 30
+
+
+def _timestamps(dts):
+    return np.array([d.timestamp() for d in dts], dtype=float)
+
+
+def pairwise_distance_datetimes(x, y):
+    """helpers.py:1831-1854: |x_i - y_j| in seconds."""
+    return np.abs(_timestamps(x)[:, None] - _timestamps(y)[None, :])
+
+
+class Tracker:
+    def __init__(self, observers, viewshed=None, resample_method="systematic", highpass={"size": (5, 5)},  # noqa: B006
+                 interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=320):  # noqa: B006
+        """tracker.py:52-70 (+ `device`, `max_search_dim`: GPU ordinal and search-tile workspace)."""
+        self.observers = list(observers)
+        if viewshed is not None:
+            raise NotImplementedError("viewshed lookups are listed under 'next' (SURVEY.md 8(f) rank 1)")
+        if resample_method != "systematic":
+            raise NotImplementedError("only systematic resampling runs on the GPU path (others: 'next')")
+        if tuple(highpass.get("size", (5, 5))) != (5, 5) or set(highpass) - {"size"}:
+            raise NotImplementedError("the high-pass filter is the reference default: median, size (5, 5)")
+        if interpolation.get("kx", 3) != 3 or interpolation.get("ky", 3) != 3:
+            raise NotImplementedError("sub-pixel interpolation is the reference default: bicubic (kx = ky = 3)")
+        self.viewshed = viewshed
+        self.resample_method = resample_method
+        self.highpass = highpass
+        self.interpolation = interpolation
+        self.device = device
+        self.max_search_dim = max_search_dim
+        self.particles = None
+        self.weights = None
+        self.templates = None
+        self._ctx = None
+        self._ctx_key = None
+
+    # ---- host logic shared with the reference -------------------------------------------
+    @property
+    def datetimes(self):
+        """tracker.py:84-87."""
+        return np.unique(np.concatenate([obs.datetimes for obs in self.observers]))
+
+    def reset(self):
+        """tracker.py:419-423."""
+        self.particles = None
+        self.weights = None
+        self.templates = None
+
+    def parse_datetimes(self, datetimes, maxdt=datetime.timedelta(0)):
+        """tracker.py:425-464."""
+        datetimes = np.asarray(datetimes)
+        monotonic = (datetimes[1:] >= datetimes[:-1]).all() or (datetimes[1:] <= datetimes[:-1]).all()
+        if not monotonic:
+            raise ValueError("Datetimes must be monotonic")
+        selected = np.concatenate(((True,), datetimes[1:] != datetimes[:-1]))
+        if not all(selected):
+            _warnings.warn("Dropping duplicate datetimes")
+            datetimes = datetimes[selected]
+        distances = pairwise_distance_datetimes(datetimes, self.datetimes)
+        selected = distances.min(axis=1) <= abs(maxdt.total_seconds())
+        if not all(selected):
+            _warnings.warn("Dropping datetimes not matching any Observers")
+            datetimes = datetimes[selected]
+        if len(datetimes) < 2:
+            raise ValueError("Fewer than two valid datetimes")
+        return datetimes
+
+    def match_datetimes(self, datetimes, maxdt=datetime.timedelta(0)):
+        """tracker.py:466-492."""
+        matches = np.full((len(datetimes), len(self.observers)), None)
+        for i, observer in enumerate(self.observers):
+            distances = pairwise_distance_datetimes(datetimes, observer.datetimes)
+            nearest_index = np.argmin(distances, axis=1)
+            matches[:, i] = nearest_index
+            nearest_distance = distances[np.arange(distances.shape[0]), nearest_index]
+            not_selected = nearest_distance > abs(maxdt.total_seconds())
+            matches[not_selected, i] = None
+        return matches
+
+    # ---- device context ---------------------------------------------------------------------
+    def _context(self, n_points, n_particles, n_frames, tile_size):
+        O = len(self.observers)
+        key = (n_points, n_particles, n_frames, max(tile_size))
+        if self._ctx is not None and self._ctx_key == key:
+            return self._ctx
+        if self._ctx is not None:
+            self._ctx.close()
+        ctx = _lib.Context(n_points, n_particles, O, device_id=self.device, max_tile=max(31, max(tile_size)),
+                           max_search_dim=self.max_search_dim, max_frames=n_frames)
+        for o, obs in enumerate(self.observers):
+            first = obs.images[0].read()
+            if first.dtype != np.uint8:
+                raise NotImplementedError("frames must be uint8 (gray or RGB) on the GPU path")
+            h, w = first.shape[:2]
+            ch = 1 if first.ndim == 2 else first.shape[2]
+            ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
+            ctx.observer_set_cameras(o, np.stack([img.cam.vector24 for img in obs.images]))
+        self._ctx, self._ctx_key = ctx, key
+        self._uploaded = set()
+        return ctx
+
+    def _upload_images(self, ctx, matching):
+        for o, obs in enumerate(self.observers):
+            for img in sorted({m for m in matching[:, o] if m is not None}):
+                if (o, img) not in self._uploaded:
+                    ctx.observer_upload_frame(o, int(img), obs.images[img].read())
+                    self._uploaded.add((o, img))
+
+    # ---- the tracking loop (tracker.py:225-417) ------------------------------------------------
+    def track(self, motion_models, datetimes=None, maxdt=datetime.timedelta(0), tile_size=(15, 15),
+              observer_mask=None, return_covariances=False, return_particles=False, reduce_particles=None,
+              parallel=False, rng="numpy", seed=0):
+        if reduce_particles:
+            return_particles = True
+        params = dict(motion_models=motion_models, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
+                      observer_mask=observer_mask, return_covariances=return_covariances,
+                      return_particles=return_particles, reduce_particles=reduce_particles, parallel=parallel)
+        if return_covariances:
+            raise NotImplementedError("return_covariances is listed under 'next' (SURVEY.md 8(f) rank 3)")
+        time_unit = motion_models[0].time_unit
+        for model in motion_models[1:]:
+            if model.time_unit != time_unit:
+                raise ValueError("Motion models must have equal time units")
+        for model in motion_models:
+            if not isinstance(model, CartesianMotion):
+                raise NotImplementedError(f"{type(model).__name__}: only CartesianMotion runs on the GPU path")
+        self.reset()
+        ntracks = len(motion_models)
+        raise_errors = ntracks < 2
+        n = motion_models[0].n
+        if any(m.n != n for m in motion_models):
+            raise NotImplementedError("all motion models must use the same number of particles (ragged n: later)")
+        if datetimes is None:
+            datetimes = self.datetimes
+        else:
+            datetimes = self.parse_datetimes(datetimes=datetimes, maxdt=maxdt)
+        nobs = len(self.observers)
+        if observer_mask is None:
+            observer_mask = np.ones((ntracks, nobs), dtype=bool)
+        observer_mask = np.asarray(observer_mask, dtype=bool)
+        matching = self.match_datetimes(datetimes=datetimes, maxdt=maxdt)
+        has = np.not_equal(matching, None)
+        template_indices = has.argmax(axis=0)
+        ntimes = len(datetimes)
+        dts = np.diff(datetimes)
+        taus = np.array([dt.total_seconds() / time_unit.total_seconds() for dt in dts])
+        # per-track [first, last] window (tracker.py:321-325)
+        observed = (has[None, :, :] & observer_mask[:, None, :]).any(axis=2)  # (P, T)
+        first = observed.argmax(axis=1)
+        last = ntimes - 1 - observed[:, ::-1].argmax(axis=1)
+        empty = ~observed.any(axis=1)
+        first[empty], last[empty] = 0, -1
+
+        ctx = self._context(ntracks, n, ntimes, tile_size)
+        self._upload_images(ctx, matching)
+        uniform = bool(observer_mask.all()) and bool((first == first[0]).all()) and bool((last == last[0]).all())
+
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        warn_log = [[] for _ in range(ntracks)]
+        images_of = lambda i: [m if m is not None else -1 for m in matching[i]]  # noqa: E731
+
+        def set_active(mask):
+            ctx.set_active(None if (uniform and mask.all()) else mask.astype(np.uint8))
+
+        lo, hi = int(first[~empty].min()) if (~empty).any() else 0, int(last.max())
+
+        def run(draws):
+            """The frame loop (tracker.py:326-357) for all tracks at once."""
+            ctx.begin_sequence(ntracks, n, tile_size)
+            ctx.set_motion_cartesian(np.stack([m.params() for m in motion_models]))
+            ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
+            for w in warn_log:
+                w.clear()
+            out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None
+            out_w = np.full((ntracks, ntimes, n), np.nan) if return_particles else None
+            for i in range(lo, hi + 1):
+                ctx.set_frame(i)
+                starting = (first == i) & ~empty
+                running = (first < i) & (i <= last)
+                window = starting | running
+                if starting.any():
+                    set_active(starting)
+                    if draws is None:
+                        ctx.init_particles(seed=seed)
+                    else:
+                        ctx.init_particles(normals=draws["init"])
+                if running.any():
+                    set_active(running)
+                    if draws is None:
+                        ctx.evolve(taus[i - 1], seed=seed, step=i)
+                    else:
+                        ctx.evolve(taus[i - 1], normals=draws["evolve"][i])
+                set_active(window)
+                for o in np.nonzero(template_indices == i)[0]:
+                    if has[i, o]:
+                        ctx.init_templates(int(o), int(matching[i][o]))
+                if running.any():
+                    set_active(running)
+                    ctx.update_weights(images_of(i))
+                    status = ctx.observer_status()
+                    for o in range(nobs):
+                        for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
+                            warn_log[p].append(UserWarning(_OOB_WARNING))
+                        for p in np.nonzero(running & (status[o] == _lib.OBS_TILE_TOO_LARGE))[0]:
+                            warn_log[p].append(RuntimeWarning(
+                                f"search tile exceeds max_search_dim={self.max_search_dim}; observer {o} skipped"))
+                    if draws is None:
+                        ctx.resample(seed=seed, step=i)
+                    else:
+                        ctx.resample(u=draws["u"][i])
+                set_active(window)
+                ctx.record_moments(i)
+                if return_particles:
+                    P_, W_ = ctx.get_particles(), ctx.get_weights()
+                    out_p[window, i] = P_[window]
+                    out_w[window, i] = W_[window]
+            return out_p, out_w, ctx.point_status(), ctx.point_error_frame()
+
+        if rng == "philox":
+            out_particles, out_weights, status, err_frame = run(None)
+        else:
+            # The reference stops drawing for a track at the frame where it fails, which shifts
+            # the stream of the tracks after it: replay until the assumed consumption is consistent.
+            state0 = np.random.get_state()
+            stops = np.stack((last, last), axis=1)
+            for _ in range(ntracks + 1):
+                np.random.set_state(state0)
+                draws = self._draw_numpy(ntracks, n, first, last, stops)
+                out_particles, out_weights, status, err_frame = run(draws)
+                new_stops = np.stack((last, last), axis=1)
+                for p in np.nonzero(status)[0]:
+                    e = int(err_frame[p])
+                    new_stops[p, 0] = e
+                    new_stops[p, 1] = e if (status[p] & _lib.PT_RESAMPLE_CLAMP and not status[p] & 0x17) else e - 1
+                if (new_stops == stops).all():
+                    break
+                stops = new_stops
+
+        moments = ctx.get_moments(0, ntimes)  # (T, P, 12)
+        means = np.ascontiguousarray(np.transpose(moments[:, :, 0:6], (1, 0, 2)))
+        sigmas = np.ascontiguousarray(np.transpose(moments[:, :, 6:12], (1, 0, 2)))
+        errors = [None] * ntracks
+        for p in range(ntracks):
+            if status[p]:
+                for bit, cls, msg in _ERRORS:
+                    if status[p] & bit:
+                        errors[p] = cls(msg)
+                        break
+                e = int(err_frame[p])
+                means[p, e:] = np.nan
+                sigmas[p, e:] = np.nan
+                if return_particles:
+                    out_particles[p, e:] = np.nan
+                    out_weights[p, e:] = np.nan
+        if raise_errors and errors[0] is not None:
+            raise errors[0]
+        # single-track state, like the reference leaves it after the last track
+        self.particles = ctx.get_particles()[-1]
+        self.weights = ctx.get_weights()[-1]
+        kwargs = dict(time_unit=time_unit, datetimes=datetimes, means=means, sigmas=sigmas,
+                      particles=None if reduce_particles else out_particles,
+                      weights=None if reduce_particles else out_weights, tracker=self, images=matching,
+                      params=params, errors=errors,
+                      warnings=[tuple(w) if w else None for w in warn_log])
+        tracks = Tracks(**kwargs)
+        if reduce_particles:
+            tracks.reduced = [reduce_particles(out_particles[p], out_weights[p]) for p in range(ntracks)]
+        return tracks
+
+    @staticmethod
+    def _draw_numpy(ntracks, n, first, last, stops):
+        """Consume the legacy global stream exactly like the reference (one track after another):
+        randn(n,2), randn(n), randn(n,3), then per step randn(n,3) and random().  `stops[p]` =
+        (last frame with an evolve draw, last frame with a resample draw) of track p."""
+        T = int(max(last.max() + 1, 1))
+        nbytes = ntracks * T * n * 3 * 8
+        if nbytes > _MAX_HOST_DRAWS_BYTES:
+            raise MemoryError(f"rng='numpy' would stage {nbytes / 2**30:.1f} GiB of host draws; use rng='philox'")
+        init = np.zeros((ntracks, n, 6))
+        evolve = np.zeros((T, ntracks, n, 3))
+        u = np.zeros((T, ntracks))
+        for p in range(ntracks):
+            if last[p] < first[p]:
+                continue
+            init[p, :, 0:2] = np.random.randn(n, 2)
+            init[p, :, 2] = np.random.randn(n)
+            init[p, :, 3:6] = np.random.randn(n, 3)
+            for i in range(first[p] + 1, last[p] + 1):
+                if i <= stops[p, 0]:
+                    evolve[i, p] = np.random.randn(n, 3)
+                if i <= stops[p, 1]:
+                    u[i, p] = np.random.random()
+        return {"init": init, "evolve": evolve, "u": u}
+
+    # ---- single-track step methods of the reference's public API ---------------------------------
+    # They operate on `self.particles` (n, 6) / `self.weights` (n,) through a one-point device context.
+    def _single(self, tile_size=None):
+        n = len(self.particles)
+        tile = tile_size or getattr(self, "_single_tile", (15, 15))
+        key = (n, tuple(tile))
+        if getattr(self, "_sctx_key", None) != key:
+            if getattr(self, "_sctx", None) is not None:
+                self._sctx.close()
+            O = len(self.observers)
+            ctx = _lib.Context(1, n, O, device_id=self.device, max_tile=max(31, max(tile)),
+                               max_search_dim=self.max_search_dim, max_frames=2)
+            for o, obs in enumerate(self.observers):
+                a0 = obs.images[0].read()
+                ctx.observer_init(o, len(obs.images), a0.shape[1], a0.shape[0], 1 if a0.ndim == 2 else a0.shape[2],
+                                  obs.sigma)
+                ctx.observer_set_cameras(o, np.stack([img.cam.vector24 for img in obs.images]))
+            ctx.begin_sequence(1, n, tile)
+            ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
+            self._sctx, self._sctx_key, self._single_tile, self._s_uploaded = ctx, key, tuple(tile), set()
+        return self._sctx
+
+    def _single_upload(self, ctx, obs, img):
+        if (obs, img) not in self._s_uploaded:
+            ctx.observer_upload_frame(obs, int(img), self.observers[obs].images[img].read())
+            self._s_uploaded.add((obs, img))
+
+    def _push(self, ctx):
+        ctx.set_particles(np.asarray(self.particles, dtype=float)[None])
+        ctx.set_weights(np.asarray(self.weights, dtype=float)[None])
+
+    @property
+    def particle_mean(self):
+        """tracker.py:72-76 (device reduction)."""
+        ctx = self._single()
+        self._push(ctx)
+        ctx.record_moments(0)
+        return ctx.get_moments(0, 1)[0, 0, 0:6]
+
+    def compute_particle_sigma(self, mean=None):
+        """tracker.py:89-104."""
+        ctx = self._single()
+        self._push(ctx)
+        ctx.record_moments(0)
+        return ctx.get_moments(0, 1)[0, 0, 6:12]
+
+    def initialize_weights(self):
+        """tracker.py:121-124."""
+        self.weights = np.ones(len(self.particles))
+
+    def test_particles(self):
+        """tracker.py:106-119 (NaN test; no viewshed)."""
+        if np.isnan(self.particles).any():
+            raise ValueError("Some particles have missing (NaN) values")
+
+    def initialize_template(self, obs, img, tile_size):
+        """tracker.py:536-561."""
+        ctx = self._single(tuple(int(v) for v in tile_size))
+        self._single_upload(ctx, obs, img)
+        self._push(ctx)
+        ctx.init_templates(obs, img)
+        if ctx.point_status()[0] & _lib.PT_TEMPLATE_OOB:
+            ctx.begin_sequence(1, len(self.particles), self._single_tile)
+            ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
+            raise IndexError("Box extends beyond grid bounds")
+        if self.templates is None:
+            self.templates = [None] * len(self.observers)
+        t = ctx.get_template(obs, 0)
+        self.templates[obs] = {"obs": obs, "img": img, **t}
+
+    def update_weights(self, imgs, motion_model=None):
+        """tracker.py:126-149.  `motion_model` must be a CartesianMotion (its DEM term is added) or None."""
+        ctx = self._single()
+        params = np.zeros((1, _lib.MOTION_LEN))
+        if motion_model is not None:
+            params[0] = motion_model.params()
+        ctx.set_motion_cartesian(params)
+        for o, img in enumerate(imgs):
+            if img is not None:
+                self._single_upload(ctx, o, img)
+        self._push(ctx)
+        ctx.update_weights([-1 if i is None else i for i in imgs])
+        st = ctx.observer_status()[:, 0]
+        if any(s == _lib.OBS_OUT_OF_BOUNDS for s in st):
+            _warnings.warn(_OOB_WARNING)
+        if ctx.point_status()[0] & _lib.PT_SAMPLE_OUTSIDE:
+            raise ValueError("Some sampling points are outside box")
+        if motion_model is not None or any(s == _lib.OBS_OK for s in st):
+            self.weights = ctx.get_weights()[0]
+
+    def compute_observer_log_likelihoods(self, obs, img):
+        """tracker.py:563-625: (n,) log likelihoods of `self.particles` for one observer, or None."""
+        if img is None:
+            return None
+        ctx = self._single()
+        ctx.set_debug(True)
+        ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
+        self._single_upload(ctx, obs, img)
+        self._push(ctx)
+        imgs = [-1] * len(self.observers)
+        imgs[obs] = img
+        ctx.update_weights(imgs)
+        st = ctx.observer_status()[obs, 0]
+        if st == _lib.OBS_OUT_OF_BOUNDS:
+            _warnings.warn(_OOB_WARNING)
+            return None
+        if st != _lib.OBS_OK:
+            return None
+        if ctx.point_status()[0] & _lib.PT_SAMPLE_OUTSIDE:
+            raise ValueError("Some sampling points are outside box")
+        return ctx.log_likelihoods(obs)[0]
+
+    def resample_particles(self, method=None):
+        """tracker.py:151-223 (systematic), drawing u from the legacy global stream like the reference."""
+        if (method or self.resample_method) != "systematic":
+            raise NotImplementedError("only systematic resampling runs on the GPU path")
+        ctx = self._single()
+        self._push(ctx)
+        ctx.resample(u=np.array([np.random.random()]))
+        self.particles = ctx.get_particles()[0]
+        self.weights = ctx.get_weights()[0]

@@ -179,6 +179,10 @@ int glh_get_likelihood_debug(glh_ctx* ctx, int obs, int point, double* uv, int32
 /* Keep a copy of the SSE surface before the in-place spline fit and the resample indices
  * (costs extra passes; off by default, on for parity tests).                                */
 int glh_set_debug(glh_ctx* ctx, int keep);
+/* Per-observer log likelihoods of the last glh_update_weights, i.e. the return value of
+ * compute_observer_log_likelihoods (track/tracker.py:563-625): ll [P][N], NaN where the
+ * reference returns None (needs glh_set_debug).                                              */
+int glh_get_log_likelihoods(glh_ctx* ctx, int obs, double* ll);
 /* np.searchsorted result of the last glh_resample (needs glh_set_debug): idx [P][N].        */
 int glh_get_resample_indices(glh_ctx* ctx, int32_t* idx);
 /* Per-stage device time (ms, HIP events on the context's stream) accumulated since the

@@ -1,0 +1,126 @@
+"""Host-side logic of the drop-in API that needs no GPU: datetime matching, containers, guards."""
+import datetime
+
+import numpy as np
+import pytest
+
+import glimpse_amd
+from tests.helpers_api import DAY, T0, models_from, observers_from
+
+
+@pytest.mark.parametrize("name", ["g8_c1.npz", "g8_c2mini.npz", "g8_c5mini.npz"])
+def test_match_datetimes_equals_reference(golden, name):
+    g = golden(name)
+    tracker = glimpse_amd.Tracker(observers_from(g))
+    datetimes = tracker.datetimes
+    assert [(d - T0).total_seconds() / 86400.0 for d in datetimes] == list(g["datetimes_days"])
+    m = tracker.match_datetimes(datetimes, maxdt=datetime.timedelta(days=float(g["maxdt_days"])))
+    got = np.array([[-1 if v is None else int(v) for v in row] for row in m])
+    np.testing.assert_array_equal(got, g["matching"])
+
+
+def test_parse_datetimes_rules(golden):
+    g = golden("g8_c1.npz")
+    tracker = glimpse_amd.Tracker(observers_from(g))
+    dts = list(tracker.datetimes)
+    with pytest.raises(ValueError, match="monotonic"):
+        tracker.parse_datetimes([dts[0], dts[2], dts[1]])
+    with pytest.warns(UserWarning, match="duplicate"):
+        out = tracker.parse_datetimes([dts[0], dts[0], dts[1]])
+    assert len(out) == 2
+    with pytest.warns(UserWarning, match="not matching"):
+        out = tracker.parse_datetimes([dts[0], dts[1], dts[1] + datetime.timedelta(hours=5)])
+    assert len(out) == 2
+    with pytest.raises(ValueError, match="Fewer than two"):
+        with pytest.warns(UserWarning):
+            tracker.parse_datetimes([dts[0], dts[0] + datetime.timedelta(hours=5)])
+    # backward (monotone decreasing) sequences are accepted (tracker.py:446-450)
+    assert list(tracker.parse_datetimes(dts[::-1])) == dts[::-1]
+
+
+def test_observer_validation(golden):
+    g = golden("g8_c1.npz")
+    obs = observers_from(g)[0]
+    with pytest.raises(ValueError, match="two or greater"):
+        glimpse_amd.Observer(obs.images[:1])
+    with pytest.raises(ValueError, match="increasing"):
+        glimpse_amd.Observer(obs.images[::-1])
+    assert obs.index(obs.images[2]) == 2
+    assert obs.index(obs.datetimes[3]) == 3
+    with pytest.raises(ValueError, match="out of range"):
+        obs.index(obs.datetimes[3] + datetime.timedelta(hours=1))
+    # tile_box == Grid.snap_box (raster.py:390-421): integer edges, IndexError outside the image
+    np.testing.assert_array_equal(obs.tile_box((100.4, 50.6), (15, 15), 0), [93, 43, 108, 58])
+    with pytest.raises(IndexError):
+        obs.tile_box((3.0, 50.0), (15, 15), 0)
+    np.testing.assert_array_equal(obs.extract_tile((10, 20, 14, 23), 1), g["obs0_frames"][1][20:23, 10:14])
+
+
+def test_camera_constructor_contract():
+    cam = glimpse_amd.Camera(imgsz=(800, 536), sensorsz=(23.6, 15.8), fmm=20)
+    np.testing.assert_allclose(cam.f, 20 * np.array([800, 536]) / np.array([23.6, 15.8]))
+    np.testing.assert_allclose(cam.fmm, [20, 20])
+    with pytest.raises(ValueError):
+        glimpse_amd.Camera(imgsz=(10, 10), fmm=20)
+    with pytest.raises(ValueError):
+        glimpse_amd.Camera(imgsz=(10, 10), f=5, fmm=20, sensorsz=(1, 1))
+    with pytest.raises(ValueError):
+        glimpse_amd.Camera(imgsz=(10.5, 10), f=5)
+    with pytest.raises(ValueError):
+        glimpse_amd.Camera(imgsz=10)
+    cam = glimpse_amd.Camera(imgsz=10, f=10, correction=True)
+    assert cam.correction == {"radius": 6.3781e6, "refraction": 0.13}
+    v = cam.vector24
+    assert v[20] == 1 and v[21] == 6.3781e6 and v[22] == 0.13
+    # camera.py:712-715 doctest
+    cam = glimpse_amd.Camera(imgsz=(10, 12), f=10)
+    assert list(cam.inframe(np.array([(-1, 1), (0, 0), (9, 11), (10, 15)]))) == [False, True, True, False]
+    # camera.py:651-656 doctest (host inverse projection)
+    cam = glimpse_amd.Camera(imgsz=10, f=10)
+    np.testing.assert_allclose(cam.uv_to_xyz(np.array([(5, 5)])), [[0, 1, 0]], atol=1e-15)
+
+
+def test_tracker_guards(golden):
+    g = golden("g8_c1.npz")
+    observers = observers_from(g)
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker(observers, resample_method="residual")
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker(observers, highpass={"size": (3, 3)})
+    tracker = glimpse_amd.Tracker(observers)
+    models = models_from(g)
+    other = glimpse_amd.CartesianMotion(xy=(0, 0), time_unit=datetime.timedelta(hours=1), dem=0, dem_sigma=0)
+    with pytest.raises(ValueError, match="equal time units"):
+        tracker.track(models + [other])
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.CartesianMotion(xy=(0, 0), time_unit=DAY, dem=0, dem_sigma=None)
+
+
+def test_motion_host_methods_match_reference(golden):
+    g = golden("g7_motion.npz")
+    for i in range(2):
+        p = g[f"m{i}_params"]
+        n = len(g[f"m{i}_p0"])
+        model = glimpse_amd.CartesianMotion(xy=p[0:2], time_unit=DAY, dem=p[16], dem_sigma=p[17], n=n,
+                                            xy_sigma=p[2:4], vxyz=p[4:7], vxyz_sigma=p[7:10], axyz=p[10:13],
+                                            axyz_sigma=p[13:16])
+        np.testing.assert_array_equal(model.params(), p)
+        np.random.seed(700 + i)
+        p0 = model.initialize_particles()
+        np.testing.assert_array_equal(p0, g[f"m{i}_p0"])
+        model.evolve_particles(p0, datetime.timedelta(days=1.5))
+        np.testing.assert_array_equal(p0, g[f"m{i}_p1"])
+        model.evolve_particles(p0, datetime.timedelta(days=-0.75))
+        np.testing.assert_array_equal(p0, g[f"m{i}_p2"])
+        np.testing.assert_array_equal(model.compute_log_likelihoods(p0), g[f"m{i}_ll"])
+
+
+def test_tracks_container():
+    means = np.full((2, 3, 6), np.nan)
+    means[0, 1:] = 1.0
+    tr = glimpse_amd.Tracks(datetimes=[T0, T0 + DAY, T0 + 2 * DAY], time_unit=DAY, means=means,
+                            sigmas=np.ones((2, 3, 6)), errors=[None, ValueError("x")])
+    assert tr.xyz.shape == (2, 3, 3) and tr.vxyz_sigma.shape == (2, 3, 3)
+    valid, first, last = tr.endpoints
+    assert list(valid) == [True, False] and list(first) == [1] and list(last) == [2]
+    assert list(tr.success) == [True, False]
