@@ -77,6 +77,7 @@ SIGNATURES = {
     "glh_resample": (_I, [_P, _I, _P, _U64, _U64]),
     "glh_record_moments": (_I, [_P, _I]),
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
+    "glh_set_fused": (_I, [_P, _I]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
     "glh_get_template": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -297,6 +298,9 @@ class Context:
             n = _arr(normals, np.float64, (self.P, self.N, 3))
             uu = _arr(u, np.float64, (self.P,))
             check(self.lib.glh_step(self.handle, int(frame), float(tau), _ptr(im), RNG_HOST, _ptr(n), _ptr(uu), 0))
+
+    def set_fused(self, on=True):
+        check(self.lib.glh_set_fused(self.handle, int(bool(on))))
 
     def sync(self):
         check(self.lib.glh_sync(self.handle))

@@ -18,6 +18,7 @@ LIB = os.path.join(LIBDIR, "libglimpse_hip.so")
 DEPS = [
     SRC,
     os.path.join(HERE, "csrc", "glh_kernels.h"),
+    os.path.join(HERE, "csrc", "glh_point.h"),
     os.path.join(HERE, "csrc", "glh_math.h"),
     os.path.join(HERE, "csrc", "glh_median.h"),
     os.path.join(HERE, "csrc", "glh_host.h"),

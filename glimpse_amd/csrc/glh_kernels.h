@@ -69,19 +69,54 @@ __device__ __forceinline__ void flag_point(uint32_t* pt_status, int32_t* pt_err_
 // ------------------------------------------------------------------------------------------
 // normals: host-fed (parity with np.random) or Philox + Box-Muller
 // ------------------------------------------------------------------------------------------
-// Two standard normals from one Philox4x32-10 block.  Bench-mode process noise does not need
+// Standard normals from one Philox4x32-10 block.  Bench-mode process noise does not need
 // float64 transcendentals: the Box-Muller radius/angle run on the float32 hardware units
 // (v_log_f32, v_sqrt_f32, v_sin/cos_f32 in revolutions), |z| <= 6.6, then widen to float64.
+__device__ __forceinline__ void box_muller_f32(uint32_t ra, uint32_t rb, double& z0, double& z1) {
+  const float u1 = ((float)ra + 0.5f) * 2.3283064365386963e-10f;   // (0, 1]
+  const float u2 = (float)(rb >> 8) * 5.9604644775390625e-08f;      // [0, 1) revolutions
+  const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+  z0 = (double)(rad * __builtin_amdgcn_cosf(u2));
+  z1 = (double)(rad * __builtin_amdgcn_sinf(u2));
+}
 __device__ __forceinline__ void philox_normals2(uint64_t seed, uint32_t c0, uint32_t c1,
                                                 uint32_t c2, uint32_t c3, double& z0, double& z1) {
   uint32_t r[4];
   philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-  const float u1 = ((float)r[0] + 0.5f) * 2.3283064365386963e-10f;   // (0, 1]
-  const float u2 = (float)(r[1] >> 8) * 5.9604644775390625e-08f;      // [0, 1) revolutions
-  const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
-  z0 = (double)(rad * __builtin_amdgcn_cosf(u2));
-  z1 = (double)(rad * __builtin_amdgcn_sinf(u2));
-  (void)r[2];
+  box_muller_f32(r[0], r[1], z0, z1);
+}
+// three normals from ONE block (all four output words are used)
+__device__ __forceinline__ void philox_normals3(uint64_t seed, uint32_t c0, uint32_t c1,
+                                                uint32_t c2, uint32_t c3, double* z) {
+  uint32_t r[4];
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  double dump;
+  box_muller_f32(r[0], r[1], z[0], z[1]);
+  box_muller_f32(r[2], r[3], z[2], dump);
+}
+
+// The three evolve normals of particle i of point pt at frame `step`: host-fed (parity with
+// np.random, motion.py:176) or counter-based, hence recomputable wherever the particle is
+// needed again (the fused step re-evolves the resampled sources instead of storing them).
+__device__ __forceinline__ void evolve_noise(int rng_mode, const double* normals, uint64_t seed, uint64_t step,
+                                             int pt, int i, int N, double* n) {
+  if (rng_mode == GLH_RNG_HOST) {
+    const double* src = normals + ((size_t)pt * N + i) * 3;
+    n[0] = src[0]; n[1] = src[1]; n[2] = src[2];
+  } else {
+    philox_normals3(seed, (uint32_t)i, (uint32_t)pt, (uint32_t)step, 0x45564f4cu, n);
+  }
+}
+
+// CartesianMotion.evolve_particles (motion.py:165-179) for one particle p[6], tau2 = tau * tau
+__device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
+                                                double tau2) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double acc = m[10 + k] + m[13 + k] * n[k];
+    p[k] += tau * p[3 + k] + 0.5 * acc * tau2;
+    p[3 + k] += tau * acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -130,7 +165,8 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
 //     + per-block uv bounding box partials (tracker.py:583).
 // ------------------------------------------------------------------------------------------
 struct EvolveArgs {
-  double* particles;  // [P][N][6] current buffer (updated in place)
+  double* particles;  // [P][N][6] current buffer (updated in place when `store`)
+  double* lldem_out;  // [P][N] DEM log likelihood of the evolved particle (fused step), or null
   const double* motion;
   const uint8_t* active;
   const uint8_t* obs_mask;  // [P][O] or null
@@ -141,7 +177,7 @@ struct EvolveArgs {
   int32_t* pt_err_frame;
   uint64_t seed, step;
   double tau;
-  int32_t do_evolve, rng_mode, N, P, O, NB, frame;
+  int32_t do_evolve, store, rng_mode, N, P, O, NB, frame;
   ObsFrame obs[MAX_OBS];
 };
 
@@ -161,25 +197,24 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
     if (a.do_evolve) {
       const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
       double n[3];
-      if (a.rng_mode == GLH_RNG_HOST) {
-        const double* src_n = a.normals + ((size_t)pt * a.N + i) * 3;
-        n[0] = src_n[0]; n[1] = src_n[1]; n[2] = src_n[2];
-      } else {
-        double dump;
-        philox_normals2(a.seed, i, pt, (uint32_t)a.step, 0x45564f4cu, n[0], n[1]);
-        philox_normals2(a.seed, i, pt, (uint32_t)a.step, 0x45564f4du, n[2], dump);
+      evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, i, a.N, n);
+      evolve_particle(p, m, n, a.tau, a.tau * a.tau);
+      if (a.store) {
+        double2* dst = reinterpret_cast<double2*>(pp);
+        dst[0] = make_double2(p[0], p[1]);
+        dst[1] = make_double2(p[2], p[3]);
+        dst[2] = make_double2(p[4], p[5]);
       }
-      const double tau = a.tau, tau2 = a.tau * a.tau;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        double acc = m[10 + k] + m[13 + k] * n[k];
-        p[k] += tau * p[3 + k] + 0.5 * acc * tau2;
-        p[3 + k] += tau * acc;
+      if (a.lldem_out) {
+        // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
+        const double zs = m[17];
+        double ll = 0.0;
+        if (zs != 0.0) {
+          const double d = m[16] - p[2];
+          ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
+        }
+        a.lldem_out[(size_t)pt * a.N + i] = ll;
       }
-      double2* dst = reinterpret_cast<double2*>(pp);
-      dst[0] = make_double2(p[0], p[1]);
-      dst[1] = make_double2(p[2], p[3]);
-      dst[2] = make_double2(p[4], p[5]);
     }
     bool bad = false;
 #pragma unroll

@@ -14,6 +14,7 @@
 #include "../../include/glimpse_hip.h"
 #include "glh_host.h"
 #include "glh_kernels.h"
+#include "glh_point.h"
 
 using namespace glh;
 
@@ -59,11 +60,13 @@ enum Stage {
   ST_SPLINE_FIT,
   ST_WEIGHTS,
   ST_RESAMPLE,
+  ST_POINT_STEP,
   ST_COUNT
 };
 static const char* kStageNames[ST_COUNT] = {"init_particles", "evolve_project", "moments",
                                             "template_init",  "tileprep",       "ssd",
-                                            "spline_fit",     "weights",        "resample"};
+                                            "spline_fit",     "weights",        "resample",
+                                            "point_step"};
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -82,7 +85,8 @@ struct glh_ctx {
   int P = 0, N = 0, tw = 0, th = 0, NB = 0;
   int cur = 0;  // current particle/weight buffer
   int frame = 0;
-  bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false;
+  bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false, has_dem = false;
+  bool fused = true;  // glh_step may use the fused per-point kernel (glh_point.h)
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
@@ -307,7 +311,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e1 = hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+    hipError_t e4 = hipFuncSetAttribute((const void*)k_point_step, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       rc = fail(GLH_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   }
   if (rc != GLH_OK) {
@@ -487,6 +492,9 @@ extern "C" int glh_set_motion_cartesian(glh_ctx* c, const double* params) {
   CHK(need_seq(c));
   if (!params) return fail(GLH_E_INVALID, "params is null");
   UPLOAD(c->motion, params, (size_t)c->P * GLH_MOTION_LEN, double);
+  c->has_dem = false;
+  for (int p = 0; p < c->P; ++p)
+    if (params[(size_t)p * GLH_MOTION_LEN + 17] != 0.0) c->has_dem = true;
   return GLH_OK;
 }
 extern "C" int glh_set_observer_mask(glh_ctx* c, const uint8_t* mask) {
@@ -646,10 +654,13 @@ static int check_images(glh_ctx* c, const int32_t* images) {
 
 // evolve (optional) + project into the given images + bbox partials
 static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng_mode, uint64_t seed,
-                                 uint64_t step, const int32_t* images) {
+                                 uint64_t step, const int32_t* images, bool store = true,
+                                 double* lldem_out = nullptr) {
   if (do_evolve) c->moments_frame = -1;
   EvolveArgs a{};
   a.particles = c->particles[c->cur];
+  a.store = store;
+  a.lldem_out = lldem_out;
   a.motion = c->motion;
   a.active = c->have_active ? c->active : nullptr;
   a.obs_mask = c->have_mask ? c->obs_mask : nullptr;
@@ -746,10 +757,9 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   return GLH_OK;
 }
 
-static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected) {
+// search tile -> SSD surface -> spline coefficients of every observer with an image
+static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
   const int O = c->cfg.n_observers;
-  // uv + bbox of the (already evolved) particles in the matched images
-  if (!projected) CHK(launch_evolve_project(c, false, 0.0, GLH_RNG_PHILOX, 0, 0, images));
   for (int o = 0; o < O; ++o) {
     if (images[o] < 0) continue;
     TilePrepArgs tp{};
@@ -816,6 +826,14 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
     }
     HIPCHK(hipGetLastError());
   }
+  return GLH_OK;
+}
+
+static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected) {
+  const int O = c->cfg.n_observers;
+  // uv + bbox of the (already evolved) particles in the matched images
+  if (!projected) CHK(launch_evolve_project(c, false, 0.0, GLH_RNG_PHILOX, 0, 0, images));
+  CHK(launch_tile_stages(c, images));
   c->moments_frame = -1;
   WeightArgs wa{};
   wa.particles = c->particles[c->cur];
@@ -919,6 +937,72 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
   return launch_moments(c, c->moments + (size_t)frame * c->P * 12, 12, 1);
 }
 
+// The fused frame step (glh_point.h): project without storing the evolved state, tile stages,
+// then ONE per-point kernel for weights + resample + re-evolving gather + moments.
+static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, int rng_mode, const double* u,
+                      uint64_t seed) {
+  const int O = c->cfg.n_observers;
+  if (rng_mode == GLH_RNG_HOST) {
+    if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u [P]");
+    HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images, /*store=*/false,
+                            c->has_dem ? c->weights[c->cur] : nullptr));
+  CHK(launch_tile_stages(c, images));
+  PointArgs a{};
+  a.particles_in = c->particles[c->cur];
+  a.particles_out = c->particles[c->cur ^ 1];
+  a.weights_tmp = c->weights[c->cur];
+  a.weights_out = c->weights[c->cur ^ 1];
+  a.motion = c->motion;
+  a.normals = c->normals;
+  a.u = c->u;
+  a.uv = c->uv;
+  a.box = c->box;
+  a.obs_status = c->obs_status;
+  a.tmpl_duv = c->tmpl_duv;
+  a.coef = c->sse;
+  a.poly = c->poly;
+  a.idx_out = c->keep_idx ? c->idx : nullptr;
+  a.moments = c->moments + (size_t)frame * c->P * 12;
+  a.pt_status = c->pt_status;
+  a.pt_err_frame = c->pt_err_frame;
+  a.leaf_off = c->leaf_off;
+  a.leaf_len = c->leaf_len;
+  a.ops = c->sum_ops;
+  a.level_off = c->level_off;
+  a.roots = c->roots;
+  a.seed = seed;
+  a.step = (uint64_t)frame;
+  a.tau = tau;
+  for (int o = 0; o < O; ++o) {
+    a.on[o] = images[o] >= 0;
+    a.inv2s2[o] = 1.0 / (2.0 * (c->obs[o].sigma * c->obs[o].sigma));
+  }
+  a.N = c->N;
+  a.P = c->P;
+  a.O = O;
+  a.tw = c->tw;
+  a.th = c->th;
+  a.sse_cap = c->sse_cap;
+  a.frame = frame;
+  a.rng_mode = rng_mode;
+  a.has_dem = c->has_dem;
+  a.nleaves = c->nleaves;
+  a.nnodes = c->nnodes;
+  a.nlevels = c->nlevels;
+  a.nroots = c->nroots;
+  {
+    StageTimer t(c, ST_POINT_STEP);
+    hipLaunchKernelGGL(k_point_step, dim3(c->P), dim3(PT_BLK), pt_lds_bytes(c->N, O, c->nnodes), c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  c->cur ^= 1;
+  c->moments_frame = frame;
+  return GLH_OK;
+}
+
 extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images, int rng_mode,
                         const double* normals, const double* u, uint64_t seed) {
   CHK(need_seq(c));
@@ -931,11 +1015,18 @@ extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images
   } else if (rng_mode != GLH_RNG_PHILOX) {
     return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
   }
+  if (c->fused && !c->have_active && !c->keep_sse) return fused_step(c, frame, tau, images, rng_mode, u, seed);
   // one pass over the particle state: evolve, NaN test, project, bbox partials
   CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images));
   CHK(update_weights_impl(c, images, true));
   CHK(glh_resample(c, rng_mode, u, seed, (uint64_t)frame));
   return glh_record_moments(c, frame);
+}
+
+extern "C" int glh_set_fused(glh_ctx* c, int on) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  c->fused = on != 0;
+  return GLH_OK;
 }
 
 // ------------------------------------------------------------------------------------------

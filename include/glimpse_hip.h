@@ -161,6 +161,12 @@ int glh_record_moments(glh_ctx* ctx, int frame);
 int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng_mode,
              const double* normals, const double* u, uint64_t seed);
 
+/* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +
+ * re-evolving gather + moments in one launch, evolved state never round-trips through HBM)
+ * whenever no active mask / debug capture is in force; 0 = always the staged kernels
+ * (glh_evolve -> glh_update_weights -> glh_resample).  Both give the same particles.          */
+int glh_set_fused(glh_ctx* ctx, int on);
+
 /* ---- results --------------------------------------------------------------------------- */
 /* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
 int glh_get_moments(glh_ctx* ctx, int frame0, int n_frames, double* out);

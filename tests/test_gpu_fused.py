@@ -1,0 +1,101 @@
+"""The fused per-point frame step (glh_step, glimpse_amd/csrc/glh_point.h) against (i) the staged
+kernels it replaces -- same particles and weights BIT FOR BIT, since both apply the same
+arithmetic to the same draws -- and (ii) the reference's golden posteriors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from glimpse_amd import _lib
+
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def _run_golden(g, fused):
+    """Frame loop of tracker.py:326-357 with glh_step wherever no template starts mid-sequence."""
+    from tests.helpers_gpu import batched_draws, context_for
+
+    ctx = context_for(g, debug=False)
+    ctx.set_fused(fused)
+    matching = g["matching"]
+    taus = np.diff(g["datetimes_days"])
+    T, O = matching.shape
+    template_indices = (matching >= 0).argmax(axis=0)
+    init, ev, us = batched_draws(g)
+    ctx.set_frame(0)
+    ctx.init_particles(normals=init)
+    for o in np.nonzero(template_indices == 0)[0]:
+        ctx.init_templates(int(o), int(matching[0][o]))
+    ctx.record_moments(0)
+    for i in range(1, T):
+        late = np.nonzero(template_indices == i)[0]
+        if len(late):
+            ctx.set_frame(i)
+            ctx.evolve(taus[i - 1], normals=ev[i - 1])
+            for o in late:
+                ctx.init_templates(int(o), int(matching[i][o]))
+            ctx.update_weights(matching[i])
+            ctx.resample(u=us[i - 1])
+            ctx.record_moments(i)
+        else:
+            ctx.step(i, taus[i - 1], matching[i], normals=ev[i - 1], u=us[i - 1])
+    out = dict(moments=ctx.get_moments(0, T), particles=ctx.get_particles(), weights=ctx.get_weights(),
+               status=ctx.point_status(), obs_status=ctx.observer_status())
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["g8_c1.npz", "g8_c2mini.npz", "g8_c5mini.npz"])
+def test_fused_step_equals_staged_and_reference(lib, golden, name):
+    g = golden(name)
+    fused = _run_golden(g, True)
+    staged = _run_golden(g, False)
+    ok = ~g["errors"].astype(bool)
+    np.testing.assert_array_equal(fused["status"], staged["status"])
+    np.testing.assert_array_equal(fused["obs_status"], staged["obs_status"])
+    np.testing.assert_array_equal(fused["particles"][ok], staged["particles"][ok])
+    np.testing.assert_array_equal(fused["weights"][ok], staged["weights"][ok])
+    np.testing.assert_allclose(fused["moments"][:, ok], staged["moments"][:, ok], rtol=1e-12, atol=1e-13)
+    means = np.transpose(fused["moments"][:, :, 0:6], (1, 0, 2))
+    sigmas = np.transpose(fused["moments"][:, :, 6:12], (1, 0, 2))
+    np.testing.assert_allclose(means[ok], g["means"][ok], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(sigmas[ok], g["out_sigmas"][ok], rtol=RTOL, atol=1e-8)
+
+
+@pytest.mark.parametrize("cfg", [("C2", 16, 2000), ("C3", 6, 5000), ("C5", 4, 3001), ("C3", 3, 12000)])
+def test_fused_step_equals_staged_with_device_rng(lib, cfg):
+    """Philox mode (what large runs use): re-evolving the gathered sources from the counter-based
+    noise gives exactly the state the staged kernels store and gather."""
+    from glimpse_amd import workloads
+
+    name, P, N = cfg
+    T = 5
+    wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [wl.frames(o) for o in range(wl.O)]
+    res = []
+    for fused in (True, False):
+        with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
+            workloads.setup_context(ctx, wl, frames)
+            ctx.set_fused(fused)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=11)
+            for o in range(wl.O):
+                ctx.init_templates(o, 0)
+            ctx.record_moments(0)
+            for i in range(1, T):
+                ctx.step(i, 1.0, [i] * wl.O, seed=11)
+            assert (ctx.observer_status() == lib.OBS_OK).all()
+            assert (ctx.point_status() == 0).all()
+            res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T)))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
+    # the filter follows the synthetic motion (0.15 units/frame along x)
+    vx = res[0][2][-1, :, 3]
+    assert abs(np.median(vx) - 0.15) < 0.05
