@@ -78,6 +78,7 @@ SIGNATURES = {
     "glh_record_moments": (_I, [_P, _I]),
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
     "glh_set_fused": (_I, [_P, _I]),
+    "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
     "glh_get_template": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -301,6 +302,12 @@ class Context:
 
     def set_fused(self, on=True):
         check(self.lib.glh_set_fused(self.handle, int(bool(on))))
+
+    def phase_stamps(self):
+        """Diagnostic: s_memtime stamps (P, 10) of the fused kernel's phase boundaries (first call arms)."""
+        out = np.zeros((self.P, 10), dtype=np.uint64)
+        check(self.lib.glh_debug_phase_stamps(self.handle, _ptr(out)))
+        return out
 
     def sync(self):
         check(self.lib.glh_sync(self.handle))

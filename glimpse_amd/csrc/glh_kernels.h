@@ -710,6 +710,69 @@ __host__ __device__ __forceinline__ size_t ssd_lds_bytes(int tw, int th) {
   return (size_t)(th * ssd_twp(tw) + (SSD_TOH + th - 1) * ssd_ld(tw)) * sizeof(float);
 }
 
+// One strip of SSD_W outputs: template rows i = g, g + G, ... of the (s - t)^2 sum; float32
+// FMA along a template row, float64 across rows.  S row stride ld (floats, multiple of 4,
+// readable up to column cc + twp + 3), T [th][twp] zero padded.
+__device__ __forceinline__ void ssd_strip_rows(const float* S, int ld, const float* T, int tw, int th, int twp,
+                                               int rr, int cc, int g, int G, double* acc64) {
+  for (int i = g; i < th; i += G) {
+    const float* rowp = S + (rr + i) * ld + cc;
+    const float* trow = T + i * twp;
+    float acc[SSD_W];
+#pragma unroll
+    for (int k = 0; k < SSD_W; ++k) acc[k] = 0.0f;
+    float w[12];
+    {
+      float4 a0 = *reinterpret_cast<const float4*>(rowp);
+      w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w;
+    }
+    for (int jj = 0; jj < tw; jj += 8) {
+      float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 4);
+      float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 8);
+      w[4] = b0.x; w[5] = b0.y; w[6] = b0.z; w[7] = b0.w;
+      w[8] = b1.x; w[9] = b1.y; w[10] = b1.z; w[11] = b1.w;
+      float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
+      float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
+      const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      if (jj + 8 <= tw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int k = 0; k < SSD_W; ++k) {
+            float d = w[j + k] - tv[j];
+            acc[k] = fmaf(d, d, acc[k]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (jj + j < tw) {
+#pragma unroll
+            for (int k = 0; k < SSD_W; ++k) {
+              float d = w[j + k] - tv[j];
+              acc[k] = fmaf(d, d, acc[k]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = w[k + 8];
+    }
+#pragma unroll
+    for (int k = 0; k < SSD_W; ++k) acc64[k] += (double)acc[k];
+  }
+}
+
+// Template-row split of a whole wo x ho surface: the largest power of two G <= 8 such that
+// (strips of the surface) * G <= 512.  Shared by the staged and the fused kernels so that
+// their float64 row partials combine in the same order.
+__host__ __device__ __forceinline__ int ssd_row_split(int wo, int ho) {
+  const int nstrips = ((wo + SSD_W - 1) / SSD_W) * ho;
+  int G = 1;
+  while (G < 8 && nstrips * (G * 2) <= 512) G *= 2;
+  return G;
+}
+
 __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int pt = blockIdx.y, tid = threadIdx.x;
@@ -734,6 +797,7 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   const float* sg = a.search + slot * (size_t)a.search_cap;
   double* outg = a.sse + slot * (size_t)a.sse_cap;
   const double inv_area = 1.0 / (double)(tw * th);
+  const int G = ssd_row_split(wo, ho);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * SSD_TOH, x0 = tx * SSD_TOW;
@@ -747,76 +811,29 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
     __syncthreads();
     const int spr = (ow + SSD_W - 1) / SSD_W;
     const int nstrips = spr * oh;  // <= 8 * 16 = 128
-    int G = 1;                     // template-row split: largest power of two with nstrips * G <= BLK, <= 8
-    while (G < 8 && nstrips * (G * 2) <= BLK) G *= 2;
-    const int strip = tid / G, g = tid - strip * G;
-    const bool live = strip < nstrips;
-    const int rr = live ? strip / spr : 0;
-    const int cc = live ? (strip - rr * spr) * SSD_W : 0;
-    double acc64[SSD_W];
+    for (int s0 = 0; s0 < nstrips; s0 += BLK / G) {
+      const int strip = s0 + tid / G, g = tid % G;
+      const bool live = strip < nstrips;
+      const int rr = live ? strip / spr : 0;
+      const int cc = live ? (strip - rr * spr) * SSD_W : 0;
+      double acc64[SSD_W];
 #pragma unroll
-    for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
-    if (live) {
-      for (int i = g; i < th; i += G) {
-        const float* rowp = S + (rr + i) * ld + cc;
-        const float* trow = T + i * twp;
-        float acc[SSD_W];
+      for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
+      if (live) ssd_strip_rows(S, ld, T, tw, th, twp, rr, cc, g, G, acc64);
+      // combine the G row-split partials (adjacent lanes of one wave; G divides 64)
+      for (int off = 1; off < G; off <<= 1) {
 #pragma unroll
-        for (int k = 0; k < SSD_W; ++k) acc[k] = 0.0f;
-        float w[12];
-        {
-          float4 a0 = *reinterpret_cast<const float4*>(rowp);
-          w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w;
-        }
-        for (int jj = 0; jj < tw; jj += 8) {
-          float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 4);
-          float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 8);
-          w[4] = b0.x; w[5] = b0.y; w[6] = b0.z; w[7] = b0.w;
-          w[8] = b1.x; w[9] = b1.y; w[10] = b1.z; w[11] = b1.w;
-          float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
-          float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
-          const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-          if (jj + 8 <= tw) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-#pragma unroll
-              for (int k = 0; k < SSD_W; ++k) {
-                float d = w[j + k] - tv[j];
-                acc[k] = fmaf(d, d, acc[k]);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (jj + j < tw) {
-#pragma unroll
-                for (int k = 0; k < SSD_W; ++k) {
-                  float d = w[j + k] - tv[j];
-                  acc[k] = fmaf(d, d, acc[k]);
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] = w[k + 8];
-        }
-#pragma unroll
-        for (int k = 0; k < SSD_W; ++k) acc64[k] += (double)acc[k];
+        for (int k = 0; k < SSD_W; ++k) acc64[k] += __shfl_xor(acc64[k], off, WAVE);
       }
-    }
-    // combine the G row-split partials (adjacent lanes of one wave; G divides 64)
-    for (int off = 1; off < G; off <<= 1) {
+      if (live && g == 0) {
+        const int r = y0 + rr;
 #pragma unroll
-      for (int k = 0; k < SSD_W; ++k) acc64[k] += __shfl_xor(acc64[k], off, WAVE);
-    }
-    if (live && g == 0) {
-      const int r = y0 + rr;
-#pragma unroll
-      for (int k = 0; k < SSD_W; ++k) {
-        if (cc + k < ow) {
-          float raw = (float)acc64[k];
-          float val = (float)((double)raw * inv_area);  // sse *= 1/(tw*th) (tracker.py:614)
-          outg[(size_t)r * wo + x0 + cc + k] = (double)val;
+        for (int k = 0; k < SSD_W; ++k) {
+          if (cc + k < ow) {
+            float raw = (float)acc64[k];
+            float val = (float)((double)raw * inv_area);  // sse *= 1/(tw*th) (tracker.py:614)
+            outg[(size_t)r * wo + x0 + cc + k] = (double)val;
+          }
         }
       }
     }

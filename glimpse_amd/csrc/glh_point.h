@@ -1,17 +1,24 @@
-// glh_point.h -- the fused per-point frame step for gfx950: one 512-thread workgroup owns one
-// tracked point for the whole update (tracker.py:343-354) so that weights, cumulative sums and
-// resample indices never leave the CU:
+// glh_point.h -- the fused frame step for gfx950: ONE workgroup owns ONE tracked point for the
+// whole update (tracker.py:331-354), so per frame the particle state is read once from HBM and
+// written once, and everything in between lives in registers and LDS:
 //
-//   C  weights      spline coefficients staged in LDS, w = exp(-ll) + 1e-300   (tracker.py:126-149)
-//   D  resample     NumPy-exact w.sum(), float64 LDS scan, inverse searchsorted (tracker.py:168-176)
-//   E  gather       particles[idx] -- read the PRE-evolve record of the source particle and
-//                   re-apply its evolve step (same noise: host normals or counter-based Philox),
-//                   so the evolved state is never written to and re-read from HBM
-//                                                                              (tracker.py:222-223)
-//   F  moments      weighted mean / sigma of the resampled set                 (tracker.py:72-104)
+//   A  evolve + NaN test + project every particle; uv of observer 0 stays in registers (PPT per
+//      thread), wave-shuffle / LDS min-max -> integer search box          (motion.py:165-179,
+//      tracker.py:118, camera.py:591-628, tracker.py:580-603)
+//   B  per observer: crop -> histogram -> CDF-match LUT -> 5x5 median high-pass -> float32 search
+//      tile -> SSD surface -> not-a-knot spline coefficients, all in LDS  (tracker.py:605-614,
+//      observer.py:210); tiles too large for LDS use the HBM workspaces with the same code
+//   C  sample the spline at every particle, w = exp(-ll) + 1e-300         (tracker.py:622-625, :126-149)
+//   D  NumPy-exact w.sum(), float64 LDS scan, inverse searchsorted         (tracker.py:168-176)
+//   E  particles[idx]: re-read the PRE-evolve record of each source (L2 / Infinity-Cache hot:
+//      this workgroup streamed it in phase A) and re-apply its evolve step with the same noise
+//      (host normals or counter-based Philox) -- the evolved state is never stored un-resampled
+//                                                                           (tracker.py:222-223)
+//   F  weighted mean / sigma of the resampled set                          (tracker.py:72-104)
 //
-// The staged kernels of glh_kernels.h stay as the general path (active masks, debug hooks,
-// the reference's public step methods); this kernel is what glh_step runs.
+// HBM traffic per particle-frame: 48 B read + 48 B write of state, 8 + 8 B of weights.
+// The staged kernels of glh_kernels.h remain the general path (active masks, debug capture,
+// the reference's public step methods) and are bit-identical on the same inputs.
 #pragma once
 #include "glh_kernels.h"
 
@@ -19,7 +26,9 @@ namespace glh {
 
 constexpr int PT_BLK = 512;
 constexpr int PT_WAVES = PT_BLK / WAVE;
-constexpr int PT_COEF_CAP = 1600;  // spline coefficients per observer staged in LDS (<= 40 x 40)
+constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
+constexpr int PT_NSTAMP = 10;
+constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
 __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -32,21 +41,54 @@ __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   return t;
 }
 
+// uv of observer 0 lives in a per-thread register array; the particle loops stay ROLLED (small
+// code, bounded live ranges) and address it with compare-select chains instead of dynamic
+// indexing (which would send the array to scratch).
+template <int PPT>
+__device__ __forceinline__ double2 pt_pick(const double2 (&v)[PPT], int r) {
+  double2 q = v[0];
+#pragma unroll
+  for (int k = 1; k < PPT; ++k) {
+    q.x = r == k ? v[k].x : q.x;
+    q.y = r == k ? v[k].y : q.y;
+  }
+  return q;
+}
+template <int PPT>
+__device__ __forceinline__ void pt_put(double2 (&v)[PPT], int r, double2 q) {
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    v[k].x = r == k ? q.x : v[k].x;
+    v[k].y = r == k ? q.y : v[k].y;
+  }
+}
+
 struct PointArgs {
   const double* particles_in;  // [P][N][6] state after the previous frame (pre-evolve)
   double* particles_out;       // [P][N][6] evolved + resampled
-  double* weights_tmp;         // [P][N] in: DEM log likelihood (if has_dem); out: this frame's weights
+  double* weights_tmp;         // [P][N] this frame's weights (scratch: gathered by phase E)
   double* weights_out;         // [P][N] weights[idx]
   const double* motion;
+  const uint8_t* obs_mask;     // [P][O] or null
   const double* normals;       // [P][N][3] host-fed evolve normals, or null (Philox)
   const double* u;             // [P] host-fed resample offsets, or null (Philox)
-  const double* uv;            // [O][P][N][2]
-  const int32_t* box;          // [O][P][4]
-  const int32_t* obs_status;   // [O][P]
-  const double* tmpl_duv;      // [O][P][2]
-  const double* coef;          // [O][P][sse_cap] spline coefficients
+  double* uv;                  // [O][P][N][2] scratch for observers >= 1 (observer 0 stays in registers)
+  int32_t* box;                // [O][P][4]
+  int32_t* obs_status;         // [O][P]
+  const int32_t* tmpl_valid;
+  const double* tmpl_duv;
+  const float* tmpl_tile32;
+  const double* tmpl_hist_v;
+  const double* tmpl_hist_q;
+  const int32_t* tmpl_hist_n;
+  float* ws_search;            // [O][P][search_cap]  HBM workspaces for tiles that do not fit in LDS
+  uint16_t* ws_keys;           // [O][P][keys_cap]
+  double* ws_sse;              // [O][P][sse_cap]
+  const double* lu;            // spline LU factors by size (glh_host.h)
+  const int64_t* lu_off;
   const double* poly;          // [GLH_NPOLY][16]
   int32_t* idx_out;            // [P][N] or null
+  unsigned long long* stamps;  // [P][PT_NSTAMP] s_memtime at the phase boundaries (diagnostic), or null
   double* moments;             // [P][12]
   uint32_t* pt_status;
   int32_t* pt_err_frame;
@@ -57,78 +99,435 @@ struct PointArgs {
   const int32_t* roots;
   uint64_t seed, step;
   double tau;
-  double inv2s2[MAX_OBS];
-  int32_t on[MAX_OBS];
-  int32_t N, P, O, tw, th, sse_cap, frame, rng_mode, has_dem;
+  double inv2s2[PT_MAX_OBS];
+  ObsFrame obs[PT_MAX_OBS];
+  CamDev cam[PT_MAX_OBS];  // by value: read through the scalar cache from the kernel arguments
+  int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
+  int32_t r2_bytes;  // bytes of LDS behind c[N]
   int32_t nleaves, nnodes, nlevels, nroots;
 };
 
-// LDS: c[N] | region2 = max(PT_COEF_CAP coefficients, nnodes tree nodes + N uint16 indices)
-__host__ __device__ __forceinline__ size_t pt_lds_bytes(int N, int O, int nnodes) {
-  size_t r2a = (size_t)PT_COEF_CAP * sizeof(double);
-  size_t r2b = (size_t)nnodes * sizeof(double) + (((size_t)N * sizeof(uint16_t) + 15) & ~(size_t)15);
-  return (size_t)N * sizeof(double) + (r2a > r2b ? r2a : r2b);
+__host__ __device__ __forceinline__ int pt_align16(int x) { return (x + 15) & ~15; }
+// LDS row stride (floats) of the search tile: >= ws + 11 readable columns and == 8 (mod 32), so the
+// row-split lanes of a strip (rows g = 0..7) start in distinct 16-byte bank slots
+__host__ __device__ __forceinline__ int pt_search_ld(int ws) { return ((ws + 3 + 31) / 32) * 32 + 8; }
+// bytes of the arrays that always live in LDS: template tile + histogram / cumulative counts / LUT
+__host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
+  return pt_align16(th * ssd_twp(tw) * 4) + pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
 }
 
-__global__ __launch_bounds__(PT_BLK, 4) void k_point_step(PointArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double tab[16 * GLH_NPOLY];
-  __shared__ double wave_tot[PT_WAVES];
-  __shared__ double red[PT_WAVES];
-  const int pt = blockIdx.x, tid = threadIdx.x;
-  const int N = a.N;
-  double* c = reinterpret_cast<double*>(smem);  // [N] weights, then cumulative weights
-  double* r2 = c + N;
-  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
-  double* W = a.weights_tmp + (size_t)pt * N;
+// Where one observer's tile arrays live.
+struct TileWs {
+  float* T;         // [th][twp] template, zero padded                         (always LDS)
+  uint32_t* hist;   // [nb]                                                     (always LDS)
+  uint32_t* cum;    // [nb]
+  double* lut;      // [nb]
+  float* S;         // [hs][ld] search tile
+  uint16_t* keys;   // [hs * ws] raw pixel keys
+  double* Z;        // [ho * wo] SSD surface -> spline coefficients
+  const double* cdf_q;
+  const double* cdf_v;
+  const double* fh;  // LU factors for ho / wo
+  const double* fw;
+  int ld;
+};
 
-  // ---------------- C: weights ---------------------------------------------------------------
-  for (int k = tid; k < 16 * GLH_NPOLY; k += PT_BLK) tab[k] = a.poly[k];
-  // observers outermost: each one's surface is staged in LDS, sampled by every particle and
-  // accumulated into c[] in the reference's order (tracker.py:139-146: obs 0, obs 1, ..., motion)
-  for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
-  bool outside = false;
-  for (int o = 0; o < a.O; ++o) {
-    const size_t slot = (size_t)o * a.P + pt;
-    if (!a.on[o] || a.obs_status[slot] != GLH_OBS_OK) continue;  // uniform across the block
-    const int* box = a.box + slot * 4;
-    const int wo = box[2] - box[0] - a.tw + 1, ho = box[3] - box[1] - a.th + 1;
-    double sb[4];
-    sse_box_of(box, a.tmpl_duv + slot * 2, a.tw, a.th, sb);
-    const double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
-    const double scale = a.inv2s2[o];
-    const double* cg = a.coef + slot * (size_t)a.sse_cap;
-    const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
-    const bool in_lds = wo * ho <= PT_COEF_CAP;
-    __syncthreads();  // r2 free (previous observer's samples done), c[] initialised
-    if (in_lds) {
-      for (int k = tid; k < wo * ho; k += PT_BLK) r2[k] = cg[k];
-      __syncthreads();
-      for (int i = tid; i < N; i += PT_BLK) {
-        const double2 q = uvp[i];
-        if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-        c[i] += spline_eval_poly(tab, r2, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
-      }
-    } else {
-      for (int i = tid; i < N; i += PT_BLK) {
-        const double2 q = uvp[i];
-        if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-        c[i] += spline_eval_poly(tab, cg, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+// extract_tile(histogram=template CDF) (tracker.py:605-607) into ws.S; see search_tile_from_box.
+__device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box, int nb, int hist_n, const TileWs& ws,
+                                             uint32_t* scan_tmp) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  for (int b = tid; b < nb; b += PT_BLK) ws.hist[b] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += PT_BLK) {
+    const int r = idx / w, c = idx - r * w;
+    const int key = pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c);
+    ws.keys[idx] = (uint16_t)key;
+    atomicAdd(&ws.hist[key], 1u);
+  }
+  __syncthreads();
+  {
+    // inclusive scan of the nb <= 2 * PT_BLK bins: two bins per thread + block scan
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    const uint32_t h0 = b0 < nb ? ws.hist[b0] : 0u, h1 = b1 < nb ? ws.hist[b1] : 0u;
+    const uint32_t local = h0 + h1;
+    uint32_t incl = local;
+    const int lane = tid & (WAVE - 1);
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off, WAVE);
+      if (lane >= off) incl += t;
+    }
+    if (lane == WAVE - 1) scan_tmp[tid / WAVE] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int wv = 0; wv < tid / WAVE; ++wv) base += scan_tmp[wv];
+    const uint32_t excl = base + incl - local;
+    if (b0 < nb) ws.cum[b0] = excl + h0;
+    if (b1 < nb) ws.cum[b1] = excl + local;
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += PT_BLK) {
+    if (ws.hist[b]) {
+      const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
+      ws.lut[b] = np_interp(q, ws.cdf_q, ws.cdf_v, hist_n);
+    }
+  }
+  __syncthreads();
+  const int ld = ws.ld;
+  // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
+  for (int idx = tid; idx < h * (ld - w); idx += PT_BLK) {
+    const int r = idx / (ld - w), c = w + idx - r * (ld - w);
+    ws.S[r * ld + c] = 0.0f;
+  }
+  // 5x5 median of the raw keys around every pixel (tiles are >= 8 pixels on a side, so a window
+  // leaves the tile by at most 2 and ONE edge reflection is exact: d c b a | a b c d | d c b a)
+  for (int idx = tid; idx < n; idx += PT_BLK) {
+    const int r = idx / w, c = idx - r * w;
+    int rows[5], cols[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      int rr = r + d - 2, cc = c + d - 2;
+      rr = rr < 0 ? -rr - 1 : (rr >= h ? 2 * h - 1 - rr : rr);
+      cc = cc < 0 ? -cc - 1 : (cc >= w ? 2 * w - 1 - cc : cc);
+      rows[d] = rr * w;
+      cols[d] = cc;
+    }
+    int v[25];
+#pragma unroll
+    for (int dr = 0; dr < 5; ++dr)
+#pragma unroll
+      for (int dc = 0; dc < 5; ++dc) v[dr * 5 + dc] = ws.keys[rows[dr] + cols[dc]];
+    const int key = v[12];
+    const int med = median25(v);
+    ws.S[r * ld + c] = (float)(ws.lut[key] - ws.lut[med]);
+  }
+  __syncthreads();
+}
+
+// cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614) from ws.S / ws.T into ws.Z (widened
+// to float64 for the spline fit); arithmetic and summation order of k_ssd.
+__device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo, int ho) {
+  const int tid = threadIdx.x;
+  const int twp = ssd_twp(tw);
+  const int spr = (wo + SSD_W - 1) / SSD_W;
+  const int nstrips = spr * ho;
+  const int G = ssd_row_split(wo, ho);
+  const double inv_area = 1.0 / (double)(tw * th);
+  for (int s0 = 0; s0 < nstrips; s0 += PT_BLK / G) {
+    const int strip = s0 + tid / G, g = tid % G;
+    const bool live = strip < nstrips;
+    const int rr = live ? strip / spr : 0;
+    const int cc = live ? (strip - rr * spr) * SSD_W : 0;
+    double acc64[SSD_W];
+#pragma unroll
+    for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
+    if (live) ssd_strip_rows(ws.S, ws.ld, ws.T, tw, th, twp, rr, cc, g, G, acc64);
+    for (int off = 1; off < G; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < SSD_W; ++k) acc64[k] += __shfl_xor(acc64[k], off, WAVE);
+    }
+    if (live && g == 0) {
+#pragma unroll
+      for (int k = 0; k < SSD_W; ++k) {
+        if (cc + k < wo) {
+          const float raw = (float)acc64[k];
+          const float val = (float)((double)raw * inv_area);
+          ws.Z[(size_t)rr * wo + cc + k] = (double)val;
+        }
       }
     }
   }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) {
+  const int tid = threadIdx.x;
+  for (int c = tid; c < wo; c += PT_BLK) solve_line(ws.Z + c, wo, ho, ws.fh);
+  __syncthreads();
+  for (int r = tid; r < ho; r += PT_BLK) solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
+  __syncthreads();
+}
+
+#define PT_STAMP(k)                                                                      \
+  do {                                                                                   \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+template <int PPT, int MINW, int NOBS>
+__global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double tab[16 * GLH_NPOLY];
+  __shared__ double wave_tot[PT_WAVES];
+  __shared__ double bred[NOBS][PT_WAVES][5];
+  __shared__ uint32_t scan_tmp[PT_WAVES];
+  __shared__ int s_box[NOBS][4];
+  __shared__ int s_status[NOBS];
+  const int pt = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), wave = tid / WAVE;
+  const int N = a.N;
+  double* c = reinterpret_cast<double*>(smem);  // [N] log likelihoods -> weights -> cumulative weights
+  unsigned char* r2 = smem + pt_align16(N * (int)sizeof(double));
+  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+  const double* Pin = a.particles_in + (size_t)pt * N * 6;
+  double* W = a.weights_tmp + (size_t)pt * N;
+  const double tau = a.tau, tau2 = a.tau * a.tau;
+
+  PT_STAMP(0);
+  for (int k = tid; k < 16 * GLH_NPOLY; k += PT_BLK) tab[k] = a.poly[k];
+
+  auto evolved = [&](int k, double* x) {
+    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)k * 6);
+    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
+    double n[3];
+    evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, k, N, n);
+    evolve_particle(x, m, n, tau, tau2);
+  };
+  auto obs_live = [&](int o) -> bool {  // uniform across the block
+    return a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
+  };
+
+  // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
+  double2 uv0[PPT];
+  {
+    double mn[NOBS][2], mx[NOBS][2], nanf[NOBS];
+#pragma unroll
+    for (int o = 0; o < NOBS; ++o) {
+      mn[o][0] = mn[o][1] = INFINITY;
+      mx[o][0] = mx[o][1] = -INFINITY;
+      nanf[o] = 0.0;
+    }
+    bool bad = false;
+    const double zs = m[17];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) uv0[r] = make_double2(0.0, 0.0);
+    // software pipeline: the next particle's record is in flight while this one is evolved / projected
+    double2 nx0, nx1, nx2;
+    {
+      const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)(tid < N ? tid : 0) * 6);
+      nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
+    }
+#pragma unroll 1
+    for (int r = 0; r < PPT; ++r) {
+      const int i = r * PT_BLK + tid;
+      double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
+      {
+        const int inext = i + PT_BLK;
+        const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)(inext < N ? inext : 0) * 6);
+        nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
+      }
+      if (i < N) {
+        double n[3];
+        evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, i, N, n);
+        evolve_particle(x, m, n, tau, tau2);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
+        if (a.has_dem) {
+          // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
+          double ll = 0.0;
+          if (zs != 0.0) {
+            const double d = m[16] - x[2];
+            ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
+          }
+          W[i] = ll;
+        }
+#pragma unroll
+        for (int o = 0; o < NOBS; ++o) {
+          if (!obs_live(o)) continue;
+          double u, v;
+          project(a.cam[o], x[0], x[1], x[2], u, v);
+          if (o == 0)
+            pt_put<PPT>(uv0, r, make_double2(u, v));
+          else
+            reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * N + i] = make_double2(u, v);
+          if (isnan(u) || isnan(v)) {
+            nanf[o] = 1.0;
+          } else {
+            mn[o][0] = fmin(mn[o][0], u); mx[o][0] = fmax(mx[o][0], u);
+            mn[o][1] = fmin(mn[o][1], v); mx[o][1] = fmax(mx[o][1], v);
+          }
+        }
+      }
+    }
+    if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
+#pragma unroll
+    for (int o = 0; o < NOBS; ++o) {
+      if (!obs_live(o)) continue;
+      const double r0 = wave_min(mn[o][0]), r1 = wave_min(mn[o][1]);
+      const double r2m = wave_max(mx[o][0]), r3 = wave_max(mx[o][1]), r4 = wave_max(nanf[o]);
+      if (lane == 0) {
+        double* b = bred[o][wave];
+        b[0] = r0; b[1] = r1; b[2] = r2m; b[3] = r3; b[4] = r4;
+      }
+    }
+    __syncthreads();
+    if (tid < NOBS) {
+      const int o = tid;
+      const size_t slot = (size_t)o * a.P + pt;
+      int st;
+      if (!obs_live(o)) {
+        st = GLH_OBS_SKIPPED;
+      } else if (!a.tmpl_valid[slot]) {
+        st = GLH_OBS_NO_TEMPLATE;
+      } else {
+        double mnu = bred[o][0][0], mnv = bred[o][0][1], mxu = bred[o][0][2], mxv = bred[o][0][3],
+               nf = bred[o][0][4];
+        for (int w = 1; w < PT_WAVES; ++w) {
+          mnu = fmin(mnu, bred[o][w][0]); mnv = fmin(mnv, bred[o][w][1]);
+          mxu = fmax(mxu, bred[o][w][2]); mxv = fmax(mxv, bred[o][w][3]);
+          nf = fmax(nf, bred[o][w][4]);
+        }
+        st = GLH_OBS_OK;
+        const ObsFrame& ob = a.obs[o];
+        if (search_box(mnu, mnv, mxu, mxv, nf != 0.0, a.tw, a.th, a.cam[o].imgsz[0], a.cam[o].imgsz[1], s_box[o]))
+          st = GLH_OBS_OUT_OF_BOUNDS;
+        else if (s_box[o][2] > ob.width || s_box[o][3] > ob.height)
+          st = GLH_OBS_OUT_OF_BOUNDS;
+        else {
+          const int w = s_box[o][2] - s_box[o][0], h = s_box[o][3] - s_box[o][1];
+          if (w > a.max_dim || h > a.max_dim || (long long)w * h > a.keys_cap ||
+              (long long)h * ((w + 14) & ~3) > a.search_cap)
+            st = GLH_OBS_TILE_TOO_LARGE;
+        }
+        if (st == GLH_OBS_OK)
+          for (int k = 0; k < 4; ++k) a.box[slot * 4 + k] = s_box[o][k];
+      }
+      s_status[o] = st;
+      a.obs_status[slot] = st;
+    }
+    for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
+    __syncthreads();
+  }
+
+  PT_STAMP(1);
+  // ---------------- B + C per observer, in the reference's order (tracker.py:139-146) ----------
+  bool outside = false;
+  for (int o = 0; o < NOBS; ++o) {
+    if (s_status[o] != GLH_OBS_OK) continue;  // uniform
+    const size_t slot = (size_t)o * a.P + pt;
+    const ObsFrame& ob = a.obs[o];
+    const int* box = s_box[o];
+    const int tw = a.tw, th = a.th;
+    const int ws_ = box[2] - box[0], hs = box[3] - box[1];
+    const int wo = ws_ - tw + 1, ho = hs - th + 1;
+    const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
+    const int hist_n = a.tmpl_hist_n[slot];
+    const int twp = ssd_twp(tw);
+    // ---- LDS carve: [T | S | X] with X = max(hist + cum + lut + keys + cdf, Z + LU)
+    TileWs ws;
+    int off = 0;
+    ws.T = reinterpret_cast<float*>(r2 + off);
+    off += pt_align16(th * twp * 4);
+    const int ld_lds = pt_search_ld(ws_);
+    const int s_bytes = pt_align16(hs * ld_lds * 4);
+    const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
+    const int l1 = hcl + pt_align16(hs * ws_ * 2) + 2 * pt_align16(hist_n * 8);
+    const int l2 = pt_align16(ho * wo * 8) + pt_align16(5 * (ho + wo) * 8);
+    const bool fits = off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
+    const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
+    const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
+    const double* fh_g = a.lu + a.lu_off[ho];
+    const double* fw_g = a.lu + a.lu_off[wo];
+    {
+      const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
+      for (int idx = tid; idx < th * twp; idx += PT_BLK) {
+        const int i = idx / twp, j = idx - i * twp;
+        ws.T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
+      }
+    }
+    // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
+    //      once per branch below so that the coefficient loads keep their address space
+    auto sample_all = [&](const double* Z) {
+      // geometry is derived here, not before the tile stages: nothing extra stays live across them
+      double sb[4];
+      sse_box_of(box, a.tmpl_duv + slot * 2, tw, th, sb);
+      const double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
+      const double scale = a.inv2s2[o];
+      const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
+      if (o == 0) {
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r) {
+          const int i = r * PT_BLK + tid;
+          if (i < N) {
+            const double2 q = pt_pick<PPT>(uv0, r);
+            if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
+            c[i] += spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          }
+        }
+      } else {
+        for (int i = tid; i < N; i += PT_BLK) {
+          const double2 q = uvp[i];
+          if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
+          c[i] += spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+        }
+      }
+    };
+    if (fits) {
+      ws.ld = ld_lds;
+      ws.S = reinterpret_cast<float*>(r2 + off);
+      unsigned char* X = r2 + off + s_bytes;
+      ws.hist = reinterpret_cast<uint32_t*>(X);
+      ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
+      ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
+      ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
+      double* cq = reinterpret_cast<double*>(X + hcl + pt_align16(hs * ws_ * 2));
+      double* cv = cq + pt_align16(hist_n * 8) / 8;
+      for (int k = tid; k < hist_n; k += PT_BLK) {
+        cq[k] = hq_g[k];
+        cv[k] = hv_g[k];
+      }
+      ws.cdf_q = cq;
+      ws.cdf_v = cv;
+      pt_tile_prep(ob, box, nb, hist_n, ws, scan_tmp);  // starts with a barrier: T, cdf visible
+      PT_STAMP(2);
+      ws.Z = reinterpret_cast<double*>(X);
+      double* fl = ws.Z + pt_align16(ho * wo * 8) / 8;
+      // X is reused: the histogram / keys / cdf are dead once the search tile is written
+      for (int k = tid; k < 5 * ho; k += PT_BLK) fl[k] = fh_g[k];
+      for (int k = tid; k < 5 * wo; k += PT_BLK) fl[5 * ho + k] = fw_g[k];
+      ws.fh = fl;
+      ws.fw = fl + 5 * ho;
+      pt_ssd(ws, tw, th, wo, ho);
+      PT_STAMP(3);
+      pt_spline_fit(ws, wo, ho);
+      PT_STAMP(4);
+      sample_all(ws.Z);
+    } else {
+      // big tile: search / keys / surface in the HBM workspaces, histogram + LUT stay in LDS
+      unsigned char* X = r2 + off;
+      ws.hist = reinterpret_cast<uint32_t*>(X);
+      ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
+      ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
+      ws.ld = (ws_ + 14) & ~3;
+      ws.S = a.ws_search + slot * (size_t)a.search_cap;
+      ws.keys = a.ws_keys + slot * (size_t)a.keys_cap;
+      ws.Z = a.ws_sse + slot * (size_t)a.sse_cap;
+      ws.cdf_q = hq_g;
+      ws.cdf_v = hv_g;
+      ws.fh = fh_g;
+      ws.fw = fw_g;
+      pt_tile_prep(ob, box, nb, hist_n, ws, scan_tmp);
+      pt_ssd(ws, tw, th, wo, ho);
+      pt_spline_fit(ws, wo, ho);
+      sample_all(ws.Z);
+    }
+    __syncthreads();  // region 2 is free for the next observer
+  }
+  PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
   for (int i = tid; i < N; i += PT_BLK) {
     double ll = c[i];
-    if (a.has_dem) ll += W[i];  // CartesianMotion.compute_log_likelihoods, appended last (tracker.py:143)
+    if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
     const double w = exp(-ll) + 1e-300;
     W[i] = w;
     c[i] = w;
   }
   __syncthreads();
 
+  PT_STAMP(6);
   // ---------------- D: w.sum() as NumPy's pairwise tree, cumsum(w / total), searchsorted ------
-  double* node = r2;
+  double* node = reinterpret_cast<double*>(r2);
   {
     const int sub = tid & 7;
     for (int L = tid >> 3; L < a.nleaves; L += PT_BLK / 8) {
@@ -170,18 +569,17 @@ __global__ __launch_bounds__(PT_BLK, 4) void k_point_step(PointArgs a) {
     c[k] = run;
   }
   double incl = run;
-  const int lane = tid & (WAVE - 1);
 #pragma unroll
   for (int off = 1; off < WAVE; off <<= 1) {
     double t = __shfl_up(incl, off, WAVE);
     if (lane >= off) incl += t;
   }
-  if (lane == WAVE - 1) wave_tot[tid / WAVE] = incl;
+  if (lane == WAVE - 1) wave_tot[wave] = incl;
   double prev = __shfl_up(incl, 1, WAVE);
   if (lane == 0) prev = 0.0;
   __syncthreads();
   double base = 0.0;
-  for (int w = 0; w < tid / WAVE; ++w) base += wave_tot[w];
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
   const double excl = base + prev;
   if (tid > 0)
     for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
@@ -217,19 +615,10 @@ __global__ __launch_bounds__(PT_BLK, 4) void k_point_step(PointArgs a) {
   }
   __syncthreads();
 
+  PT_STAMP(7);
   // ---------------- E + F: gather with re-evolve, moments --------------------------------------
-  const double* Pin = a.particles_in + (size_t)pt * N * 6;
   double* Pout = a.particles_out + (size_t)pt * N * 6;
   double* Wout = a.weights_out + (size_t)pt * N;
-  const double tau = a.tau, tau2 = a.tau * a.tau;
-  auto evolved = [&](int k, double* x) {
-    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)k * 6);
-    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
-    x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
-    double n[3];
-    evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, k, N, n);
-    evolve_particle(x, m, n, tau, tau2);
-  };
   double K[6];
   evolved(0, K);  // pivot of the shifted moments: the point's first evolved particle
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
@@ -268,18 +657,37 @@ __global__ __launch_bounds__(PT_BLK, 4) void k_point_step(PointArgs a) {
       }
     }
   }
-  s0 = pt_block_sum(s0, red);
-  double* out = a.moments + (size_t)pt * 12;
+  PT_STAMP(8);
+  {
+    // one pass for the 13 sums: wave shuffles -> LDS [wave][13] -> thread k < 6 finishes component k
+    double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (sidx is dead after the gather)
+    __syncthreads();
+    const double t0 = wave_sum(s0);
+    if (lane == 0) mred[wave * 13] = t0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double m1 = pt_block_sum(s1[k], red) / s0;
-    double m2 = pt_block_sum(s2[k], red) / s0;
-    if (tid == 0) {
-      double var = m2 - m1 * m1;
-      out[k] = K[k] + m1;
-      out[6 + k] = sqrt(var > 0.0 ? var : 0.0);
+    for (int k = 0; k < 6; ++k) {
+      const double t1 = wave_sum(s1[k]), t2 = wave_sum(s2[k]);
+      if (lane == 0) {
+        mred[wave * 13 + 1 + k] = t1;
+        mred[wave * 13 + 7 + k] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 6) {
+      double S0 = mred[0], S1 = mred[1 + tid], S2 = mred[7 + tid];
+      for (int w = 1; w < PT_WAVES; ++w) {
+        S0 += mred[w * 13];
+        S1 += mred[w * 13 + 1 + tid];
+        S2 += mred[w * 13 + 7 + tid];
+      }
+      const double m1 = S1 / S0, m2 = S2 / S0;
+      const double var = m2 - m1 * m1;
+      double* out = a.moments + (size_t)pt * 12;
+      out[tid] = K[tid] + m1;
+      out[6 + tid] = sqrt(var > 0.0 ? var : 0.0);
     }
   }
+  PT_STAMP(9);
 }
 
 }  // namespace glh

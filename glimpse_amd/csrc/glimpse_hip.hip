@@ -47,6 +47,10 @@ static int fail(int code, const char* fmt, ...) {
     if (rc_ != GLH_OK) return rc_; \
   } while (0)
 
+// LDS plan of the fused kernel (glh_point.h): c[N] + region 2
+constexpr int PT_LDS_MAX = 156 * 1024;   // dynamic LDS of one workgroup (static ~4 KB on top)
+constexpr int PT_LDS_HALF = 76 * 1024;   // dynamic LDS that still lets two workgroups share a CU
+
 // ------------------------------------------------------------------------------------------
 // stages (for the event timers)
 // ------------------------------------------------------------------------------------------
@@ -75,6 +79,7 @@ struct Observer {
   int n_images = 0, width = 0, height = 0, channels = 0;
   double sigma = 0.3;
   CamDev* cams = nullptr;               // device [n_images]
+  std::vector<CamDev> cams_host;        // same, for kernels that take the camera by value
   std::vector<const uint8_t*> frames;   // device pointers (owned or borrowed)
   std::vector<uint8_t*> owned;          // owned allocations (same indexing; null if borrowed)
 };
@@ -99,6 +104,9 @@ struct glh_ctx {
   int32_t *tmpl_box = nullptr, *tmpl_hist_n = nullptr, *tmpl_valid = nullptr;
   double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
   float *tmpl_tile32 = nullptr, *search = nullptr;
+  unsigned long long* stamps = nullptr;  // phase stamps of the fused kernel (diagnostic)
+  uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
+  int keys_cap = 0;
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
@@ -210,7 +218,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->mean6); dfree(c->moments); dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -242,7 +250,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   c->cfg = k;
   const size_t P = k.max_points, N = k.max_particles, O = k.n_observers;
   c->tile_cap = k.max_tile * k.max_tile;
-  c->search_cap = k.max_search_dim * k.max_search_dim;
+  c->search_cap = k.max_search_dim * (k.max_search_dim + 16);  // rows padded for the fused kernel
+  c->keys_cap = k.max_search_dim * k.max_search_dim;
   c->sse_cap = c->search_cap;
   const size_t NBmax = (N + BLK - 1) / BLK;
   int rc = GLH_OK;
@@ -279,6 +288,7 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   A(dalloc(&c->tmpl_hist_v, O * P * c->tile_cap));
   A(dalloc(&c->tmpl_hist_q, O * P * c->tile_cap));
   A(dalloc(&c->search, O * P * (size_t)c->search_cap));
+  A(dalloc(&c->ws_keys, O * P * (size_t)c->keys_cap));
   A(dalloc(&c->sse, O * P * (size_t)c->sse_cap));
   // spline LU table for every surface side 4..max_search_dim
   if (rc == GLH_OK) {
@@ -311,7 +321,13 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e1 = hipFuncSetAttribute((const void*)k_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipError_t e4 = hipFuncSetAttribute((const void*)k_point_step, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e4 = hipSuccess;
+    for (const void* f : {(const void*)k_point_step<4, 4, 1>, (const void*)k_point_step<10, 4, 1>,
+                          (const void*)k_point_step<20, 2, 1>, (const void*)k_point_step<4, 4, 2>,
+                          (const void*)k_point_step<10, 4, 2>, (const void*)k_point_step<20, 2, 2>}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
+      if (e != hipSuccess) e4 = e;
+    }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       rc = fail(GLH_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   }
@@ -381,6 +397,8 @@ extern "C" int glh_observer_set_cameras(glh_ctx* c, int o, int first, int n, con
                   tmp[i].imgsz[0], tmp[i].imgsz[1], ob.width, ob.height);
   }
   HIPCHK(hipSetDevice(c->cfg.device_id));
+  if ((int)ob.cams_host.size() != ob.n_images) ob.cams_host.resize(ob.n_images);
+  for (int i = 0; i < n; ++i) ob.cams_host[first + i] = tmp[i];
   HIPCHK(hipMemcpyAsync(ob.cams + first, tmp.data(), n * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return GLH_OK;
@@ -937,34 +955,68 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
   return launch_moments(c, c->moments + (size_t)frame * c->P * 12, 12, 1);
 }
 
-// The fused frame step (glh_point.h): project without storing the evolved state, tile stages,
-// then ONE per-point kernel for weights + resample + re-evolving gather + moments.
+// LDS plan of the fused kernel (glh_point.h): c[N] + region 2.  Two workgroups per CU when the
+// state and a typical tile fit in half the LDS, otherwise one.
+
+static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
+  const int O = c->cfg.n_observers;
+  if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
+  if (c->N > 20 * PT_BLK) return false;
+  int nb = 256;
+  for (int o = 0; o < O; ++o) {
+    if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
+    if (c->obs[o].channels == 3) nb = 766;
+  }
+  const int cN = pt_align16(c->N * 8);
+  const int plan = pt_align16(c->nnodes * 8) + pt_align16(c->N * 2);
+  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb));
+  // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
+  const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + 48 * 48 * 2 + 4096;
+  int r2;
+  if (cN + std::max(r2_min, typical) <= PT_LDS_HALF)
+    r2 = PT_LDS_HALF - cN;
+  else
+    r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
+  if (r2 < r2_min) return false;
+  *r2_bytes = r2;
+  return true;
+}
+
+// The fused frame step (glh_point.h): ONE launch, one workgroup per point.
 static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, int rng_mode, const double* u,
-                      uint64_t seed) {
+                      uint64_t seed, int r2_bytes) {
   const int O = c->cfg.n_observers;
   if (rng_mode == GLH_RNG_HOST) {
     if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u [P]");
     HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images, /*store=*/false,
-                            c->has_dem ? c->weights[c->cur] : nullptr));
-  CHK(launch_tile_stages(c, images));
   PointArgs a{};
   a.particles_in = c->particles[c->cur];
   a.particles_out = c->particles[c->cur ^ 1];
   a.weights_tmp = c->weights[c->cur];
   a.weights_out = c->weights[c->cur ^ 1];
   a.motion = c->motion;
+  a.obs_mask = c->have_mask ? c->obs_mask : nullptr;
   a.normals = c->normals;
   a.u = c->u;
   a.uv = c->uv;
   a.box = c->box;
   a.obs_status = c->obs_status;
+  a.tmpl_valid = c->tmpl_valid;
   a.tmpl_duv = c->tmpl_duv;
-  a.coef = c->sse;
+  a.tmpl_tile32 = c->tmpl_tile32;
+  a.tmpl_hist_v = c->tmpl_hist_v;
+  a.tmpl_hist_q = c->tmpl_hist_q;
+  a.tmpl_hist_n = c->tmpl_hist_n;
+  a.ws_search = c->search;
+  a.ws_keys = c->ws_keys;
+  a.ws_sse = c->sse;
+  a.lu = c->lu;
+  a.lu_off = c->lu_off;
   a.poly = c->poly;
   a.idx_out = c->keep_idx ? c->idx : nullptr;
+  a.stamps = c->stamps;
   a.moments = c->moments + (size_t)frame * c->P * 12;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
@@ -977,7 +1029,10 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.step = (uint64_t)frame;
   a.tau = tau;
   for (int o = 0; o < O; ++o) {
-    a.on[o] = images[o] >= 0;
+    fill_obs(c, o, images[o], &a.obs[o]);
+    if ((int)c->obs[o].cams_host.size() != c->obs[o].n_images)
+      return fail(GLH_E_STATE, "observer %d: cameras have not been set", o);
+    a.cam[o] = c->obs[o].cams_host[images[o] >= 0 ? images[o] : 0];
     a.inv2s2[o] = 1.0 / (2.0 * (c->obs[o].sigma * c->obs[o].sigma));
   }
   a.N = c->N;
@@ -985,17 +1040,36 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.O = O;
   a.tw = c->tw;
   a.th = c->th;
+  a.tile_cap = c->tile_cap;
+  a.search_cap = c->search_cap;
+  a.keys_cap = c->keys_cap;
   a.sse_cap = c->sse_cap;
+  a.max_dim = c->cfg.max_search_dim;
   a.frame = frame;
   a.rng_mode = rng_mode;
   a.has_dem = c->has_dem;
+  a.r2_bytes = r2_bytes;
   a.nleaves = c->nleaves;
   a.nnodes = c->nnodes;
   a.nlevels = c->nlevels;
   a.nroots = c->nroots;
   {
     StageTimer t(c, ST_POINT_STEP);
-    hipLaunchKernelGGL(k_point_step, dim3(c->P), dim3(PT_BLK), pt_lds_bytes(c->N, O, c->nnodes), c->stream, a);
+    const size_t lds = (size_t)pt_align16(c->N * 8) + r2_bytes;
+    const dim3 grid(c->P), block(PT_BLK);
+    const int ppt = c->N <= 4 * PT_BLK ? 4 : (c->N <= 10 * PT_BLK ? 10 : 20);
+#define GLH_LAUNCH_POINT(PPT_, MINW_, NOBS_) \
+  hipLaunchKernelGGL((k_point_step<PPT_, MINW_, NOBS_>), grid, block, lds, c->stream, a)
+    if (O == 1) {
+      if (ppt == 4) GLH_LAUNCH_POINT(4, 4, 1);
+      else if (ppt == 10) GLH_LAUNCH_POINT(10, 4, 1);
+      else GLH_LAUNCH_POINT(20, 2, 1);
+    } else {
+      if (ppt == 4) GLH_LAUNCH_POINT(4, 4, 2);
+      else if (ppt == 10) GLH_LAUNCH_POINT(10, 4, 2);
+      else GLH_LAUNCH_POINT(20, 2, 2);
+    }
+#undef GLH_LAUNCH_POINT
   }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
@@ -1015,12 +1089,30 @@ extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images
   } else if (rng_mode != GLH_RNG_PHILOX) {
     return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
   }
-  if (c->fused && !c->have_active && !c->keep_sse) return fused_step(c, frame, tau, images, rng_mode, u, seed);
+  int r2_bytes = 0;
+  if (c->fused && !c->have_active && !c->keep_sse && fused_plan(c, &r2_bytes))
+    return fused_step(c, frame, tau, images, rng_mode, u, seed, r2_bytes);
   // one pass over the particle state: evolve, NaN test, project, bbox partials
   CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images));
   CHK(update_weights_impl(c, images, true));
   CHK(glh_resample(c, rng_mode, u, seed, (uint64_t)frame));
   return glh_record_moments(c, frame);
+}
+
+extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
+  CHK(need_seq(c));
+  if (!stamps) return fail(GLH_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const size_t n = (size_t)c->P * PT_NSTAMP;
+  if (!c->stamps) {
+    // first call arms the stamps; the next fused steps record them
+    CHK(dalloc(&c->stamps, (size_t)c->cfg.max_points * PT_NSTAMP));
+    HIPCHK(hipMemset(c->stamps, 0, (size_t)c->cfg.max_points * PT_NSTAMP * sizeof(unsigned long long)));
+    memset(stamps, 0, n * sizeof(uint64_t));
+    return GLH_OK;
+  }
+  DOWNLOAD(stamps, c->stamps, n, unsigned long long);
+  return GLH_OK;
 }
 
 extern "C" int glh_set_fused(glh_ctx* c, int on) {

@@ -167,6 +167,10 @@ int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng
  * (glh_evolve -> glh_update_weights -> glh_resample).  Both give the same particles.          */
 int glh_set_fused(glh_ctx* ctx, int on);
 
+/* Diagnostic: s_memtime stamps [P][10] at the phase boundaries of the fused kernel during the
+ * last fused glh_step (the first call only arms them and returns zeros).                      */
+int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
+
 /* ---- results --------------------------------------------------------------------------- */
 /* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
 int glh_get_moments(glh_ctx* ctx, int frame0, int n_frames, double* out);

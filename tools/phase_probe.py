@@ -1,0 +1,47 @@
+"""Diagnostic: mean cycles per phase of the fused per-point kernel on a synthetic workload.
+
+    python tools/phase_probe.py [C3] [points] [particles]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glimpse_amd import _lib, workloads  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+P = int(sys.argv[2]) if len(sys.argv) > 2 else None
+N = int(sys.argv[3]) if len(sys.argv) > 3 else None
+T = 8
+wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N)
+frames = [wl.frames(o) for o in range(wl.O)]
+NAMES = ["", "A evolve+project", "B tile_prep", "B ssd", "B spline_fit", "C sample", "C exp", "D resample",
+         "E gather", "F moments"]
+with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
+    workloads.setup_context(ctx, wl, frames)
+    ctx.set_frame(0)
+    ctx.init_particles(seed=3)
+    for o in range(wl.O):
+        ctx.init_templates(o, 0)
+    ctx.record_moments(0)
+    ctx.phase_stamps()  # arm
+    ctx.profile_enable(True)
+    for i in range(1, T):
+        if i == T - 1:
+            ctx.profile_reset()
+        ctx.step(i, 1.0, [i] * wl.O, seed=3)
+    ctx.sync()
+    ms = {k: v for k, v in ctx.profile_get().items() if v[0] > 0}
+    st = ctx.phase_stamps().astype(np.int64)
+    d = np.diff(st, axis=1)  # (P, 9)
+    tot = d.sum(axis=1)
+    span = st[:, -1].max() - st[:, 0].min()
+    print(f"{wl.describe()['workload']}")
+    print(f"  last step kernels (ms): {ms}")
+    print(f"  kernel span {span} ticks; per-point total: min {tot.min()} median {np.median(tot):.0f} max {tot.max()}")
+    print(f"  concurrency (sum of point times / span): {tot.sum() / span:.1f} points in flight")
+    for k in range(9):
+        print(f"  {NAMES[k + 1]:18s} median {np.median(d[:, k]):10.0f} ticks  {100 * d[:, k].sum() / tot.sum():5.1f} %")
+    bx = ctx.search_boxes()[0]
+    print("  search tile w x h median:", np.median(bx[:, 2] - bx[:, 0]), np.median(bx[:, 3] - bx[:, 1]))
