@@ -59,6 +59,7 @@ SIGNATURES = {
     "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
     "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
     "glh_set_motion_cartesian": (_I, [_P, _P]),
+    "glh_set_point_offset": (_I, [_P, _I]),
     "glh_set_observer_mask": (_I, [_P, _P]),
     "glh_set_active": (_I, [_P, _P]),
     "glh_set_particles": (_I, [_P, _P]),
@@ -300,8 +301,12 @@ class Context:
             uu = _arr(u, np.float64, (self.P,))
             check(self.lib.glh_step(self.handle, int(frame), float(tau), _ptr(im), RNG_HOST, _ptr(n), _ptr(uu), 0))
 
-    def set_fused(self, on=True):
-        check(self.lib.glh_set_fused(self.handle, int(bool(on))))
+    def set_fused(self, mode=1):
+        """0 staged kernels, 1 fused per-point kernel (default), 2 fused with tiles forced to HBM (test)."""
+        check(self.lib.glh_set_fused(self.handle, int(mode)))
+
+    def set_point_offset(self, offset):
+        check(self.lib.glh_set_point_offset(self.handle, int(offset)))
 
     def phase_stamps(self):
         """Diagnostic: s_memtime stamps (P, 10) of the fused kernel's phase boundaries (first call arms)."""

@@ -99,12 +99,12 @@ __device__ __forceinline__ void philox_normals3(uint64_t seed, uint32_t c0, uint
 // np.random, motion.py:176) or counter-based, hence recomputable wherever the particle is
 // needed again (the fused step re-evolves the resampled sources instead of storing them).
 __device__ __forceinline__ void evolve_noise(int rng_mode, const double* normals, uint64_t seed, uint64_t step,
-                                             int pt, int i, int N, double* n) {
+                                             int pt, int pt_base, int i, int N, double* n) {
   if (rng_mode == GLH_RNG_HOST) {
     const double* src = normals + ((size_t)pt * N + i) * 3;
     n[0] = src[0]; n[1] = src[1]; n[2] = src[2];
   } else {
-    philox_normals3(seed, (uint32_t)i, (uint32_t)pt, (uint32_t)step, 0x45564f4cu, n);
+    philox_normals3(seed, (uint32_t)i, (uint32_t)(pt + pt_base), (uint32_t)step, 0x45564f4cu, n);
   }
 }
 
@@ -129,7 +129,7 @@ struct InitArgs {
   const uint8_t* active;
   const double* normals;  // [P][N][6] or null
   uint64_t seed;
-  int32_t rng_mode, N;
+  int32_t rng_mode, N, pt_base;  // pt_base: global index of point 0 (sharding-invariant Philox streams)
 };
 
 __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
@@ -144,9 +144,10 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) n[k] = src[k];
   } else {
-    philox_normals2(a.seed, i, pt, 0u, 0x494e4954u, n[0], n[1]);
-    philox_normals2(a.seed, i, pt, 1u, 0x494e4954u, n[2], n[3]);
-    philox_normals2(a.seed, i, pt, 2u, 0x494e4954u, n[4], n[5]);
+    const uint32_t gp = (uint32_t)(pt + a.pt_base);
+    philox_normals2(a.seed, i, gp, 0u, 0x494e4954u, n[0], n[1]);
+    philox_normals2(a.seed, i, gp, 1u, 0x494e4954u, n[2], n[3]);
+    philox_normals2(a.seed, i, gp, 2u, 0x494e4954u, n[4], n[5]);
   }
   double* p = a.particles + ((size_t)pt * a.N + i) * 6;
   p[0] = m[0] + m[2] * n[0];
@@ -177,7 +178,7 @@ struct EvolveArgs {
   int32_t* pt_err_frame;
   uint64_t seed, step;
   double tau;
-  int32_t do_evolve, store, rng_mode, N, P, O, NB, frame;
+  int32_t do_evolve, store, rng_mode, N, P, O, NB, frame, pt_base;
   ObsFrame obs[MAX_OBS];
 };
 
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
     if (a.do_evolve) {
       const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
       double n[3];
-      evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, i, a.N, n);
+      evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, a.N, n);
       evolve_particle(p, m, n, a.tau, a.tau * a.tau);
       if (a.store) {
         double2* dst = reinterpret_cast<double2*>(pp);
@@ -1016,7 +1017,7 @@ struct ResampleArgs {
   const int32_t* level_off;  // [nlevels + 1]
   const int32_t* roots;      // chunk roots, summed left to right
   uint64_t seed, step;
-  int32_t N, nleaves, nnodes, nlevels, nroots, rng_mode, frame;
+  int32_t N, nleaves, nnodes, nlevels, nroots, rng_mode, frame, pt_base;
 };
 
 __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     u = a.u[pt];
   } else {
     uint32_t r[4];
-    philox4x32_10((uint32_t)pt, 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+    philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
                   (uint32_t)(a.seed >> 32), r);
     u = u01_halfopen(r[0], r[1]);
   }

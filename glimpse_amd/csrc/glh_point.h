@@ -104,6 +104,7 @@ struct PointArgs {
   CamDev cam[PT_MAX_OBS];  // by value: read through the scalar cache from the kernel arguments
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
   int32_t r2_bytes;  // bytes of LDS behind c[N]
+  int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
   int32_t nleaves, nnodes, nlevels, nroots;
 };
 
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     const double2 v0 = src[0], v1 = src[1], v2 = src[2];
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
-    evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, k, N, n);
+    evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
     evolve_particle(x, m, n, tau, tau2);
   };
   auto obs_live = [&](int o) -> bool {  // uniform across the block
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       }
       if (i < N) {
         double n[3];
-        evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, i, N, n);
+        evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
         evolve_particle(x, m, n, tau, tau2);
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
@@ -508,8 +509,11 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       ws.fh = fh_g;
       ws.fw = fw_g;
       pt_tile_prep(ob, box, nb, hist_n, ws, scan_tmp);
+      PT_STAMP(2);
       pt_ssd(ws, tw, th, wo, ho);
+      PT_STAMP(3);
       pt_spline_fit(ws, wo, ho);
+      PT_STAMP(4);
       sample_all(ws.Z);
     }
     __syncthreads();  // region 2 is free for the next observer
@@ -589,7 +593,8 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     u = a.u[pt];
   } else {
     uint32_t r[4];
-    philox4x32_10((uint32_t)pt, 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+    philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+                  (uint32_t)(a.seed >> 32), r);
     u = u01_halfopen(r[0], r[1]);
   }
   const double inv_n = 1.0 / (double)N;

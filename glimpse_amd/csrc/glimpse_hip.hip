@@ -91,7 +91,8 @@ struct glh_ctx {
   int cur = 0;  // current particle/weight buffer
   int frame = 0;
   bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false, has_dem = false;
-  bool fused = true;  // glh_step may use the fused per-point kernel (glh_point.h)
+  int fused = 1;    // glh_step: 0 staged kernels, 1 fused per-point kernel, 2 fused with tiles forced to HBM (test)
+  int pt_base = 0;  // global index of this context's point 0
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
@@ -445,6 +446,7 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   c->cur = 0;
   c->frame = 0;
   c->have_mask = c->have_active = false;
+  c->pt_base = 0;
   const size_t O = c->cfg.n_observers;
   HIPCHK(hipMemsetAsync(c->pt_status, 0, P * sizeof(uint32_t), c->stream));
   HIPCHK(hipMemsetAsync(c->pt_err_frame, 0x7f, P * sizeof(int32_t), c->stream));
@@ -513,6 +515,12 @@ extern "C" int glh_set_motion_cartesian(glh_ctx* c, const double* params) {
   c->has_dem = false;
   for (int p = 0; p < c->P; ++p)
     if (params[(size_t)p * GLH_MOTION_LEN + 17] != 0.0) c->has_dem = true;
+  return GLH_OK;
+}
+extern "C" int glh_set_point_offset(glh_ctx* c, int offset) {
+  CHK(need_seq(c));
+  if (offset < 0) return fail(GLH_E_INVALID, "offset must be >= 0");
+  c->pt_base = offset;
   return GLH_OK;
 }
 extern "C" int glh_set_observer_mask(glh_ctx* c, const uint8_t* mask) {
@@ -641,6 +649,7 @@ extern "C" int glh_init_particles(glh_ctx* c, int rng_mode, const double* normal
   a.seed = seed;
   a.rng_mode = rng_mode;
   a.N = c->N;
+  a.pt_base = c->pt_base;
   {
     StageTimer t(c, ST_INIT);
     hipLaunchKernelGGL(k_init_particles, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, a);
@@ -697,6 +706,7 @@ static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng
   a.O = c->cfg.n_observers;
   a.NB = c->NB;
   a.frame = c->frame;
+  a.pt_base = c->pt_base;
   for (int o = 0; o < a.O; ++o) fill_obs(c, o, images ? images[o] : -1, &a.obs[o]);
   {
     StageTimer t(c, ST_EVOLVE_PROJECT);
@@ -928,6 +938,7 @@ extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t 
   a.nroots = c->nroots;
   a.rng_mode = rng_mode;
   a.frame = c->frame;
+  a.pt_base = c->pt_base;
   if (c->have_active) {
     // inactive points keep their state: copy their rows across before swapping buffers
     HIPCHK(hipMemcpyAsync(c->particles[c->cur ^ 1], c->particles[c->cur], (size_t)c->P * c->N * 6 * sizeof(double),
@@ -977,6 +988,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
     r2 = PT_LDS_HALF - cN;
   else
     r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
+  if (c->fused == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
   if (r2 < r2_min) return false;
   *r2_bytes = r2;
   return true;
@@ -1049,6 +1061,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.rng_mode = rng_mode;
   a.has_dem = c->has_dem;
   a.r2_bytes = r2_bytes;
+  a.pt_base = c->pt_base;
   a.nleaves = c->nleaves;
   a.nnodes = c->nnodes;
   a.nlevels = c->nlevels;
@@ -1117,7 +1130,8 @@ extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
 
 extern "C" int glh_set_fused(glh_ctx* c, int on) {
   if (!c) return fail(GLH_E_INVALID, "null context");
-  c->fused = on != 0;
+  if (on < 0 || on > 2) return fail(GLH_E_INVALID, "mode must be 0, 1 or 2");
+  c->fused = on;
   return GLH_OK;
 }
 

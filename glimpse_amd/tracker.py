@@ -142,7 +142,7 @@ class Tracker:
     # ---- the tracking loop (tracker.py:225-417) ------------------------------------------------
     def track(self, motion_models, datetimes=None, maxdt=datetime.timedelta(0), tile_size=(15, 15),
               observer_mask=None, return_covariances=False, return_particles=False, reduce_particles=None,
-              parallel=False, rng="numpy", seed=0):
+              parallel=False, rng="numpy", seed=0, point_offset=0):
         if reduce_particles:
             return_particles = True
         params = dict(motion_models=motion_models, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
@@ -203,47 +203,61 @@ class Tracker:
             ctx.begin_sequence(ntracks, n, tile_size)
             ctx.set_motion_cartesian(np.stack([m.params() for m in motion_models]))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
+            ctx.set_point_offset(point_offset)
             for w in warn_log:
                 w.clear()
             out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None
             out_w = np.full((ntracks, ntimes, n), np.nan) if return_particles else None
+            def note_skips(i, running):
+                status = ctx.observer_status()
+                for o in range(nobs):
+                    for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
+                        warn_log[p].append(UserWarning(_OOB_WARNING))
+                    for p in np.nonzero(running & (status[o] == _lib.OBS_TILE_TOO_LARGE))[0]:
+                        warn_log[p].append(RuntimeWarning(
+                            f"search tile exceeds max_search_dim={self.max_search_dim}; observer {o} skipped"))
+
             for i in range(lo, hi + 1):
                 ctx.set_frame(i)
                 starting = (first == i) & ~empty
                 running = (first < i) & (i <= last)
                 window = starting | running
-                if starting.any():
-                    set_active(starting)
+                if uniform and running.all() and not (template_indices == i).any():
+                    # the common frame: every track is running and no template starts here ->
+                    # ONE fused launch for evolve + likelihood + resample + moments (glh_step)
+                    set_active(window)
                     if draws is None:
-                        ctx.init_particles(seed=seed)
+                        ctx.step(i, taus[i - 1], images_of(i), seed=seed)
                     else:
-                        ctx.init_particles(normals=draws["init"])
-                if running.any():
-                    set_active(running)
-                    if draws is None:
-                        ctx.evolve(taus[i - 1], seed=seed, step=i)
-                    else:
-                        ctx.evolve(taus[i - 1], normals=draws["evolve"][i])
-                set_active(window)
-                for o in np.nonzero(template_indices == i)[0]:
-                    if has[i, o]:
-                        ctx.init_templates(int(o), int(matching[i][o]))
-                if running.any():
-                    set_active(running)
-                    ctx.update_weights(images_of(i))
-                    status = ctx.observer_status()
-                    for o in range(nobs):
-                        for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
-                            warn_log[p].append(UserWarning(_OOB_WARNING))
-                        for p in np.nonzero(running & (status[o] == _lib.OBS_TILE_TOO_LARGE))[0]:
-                            warn_log[p].append(RuntimeWarning(
-                                f"search tile exceeds max_search_dim={self.max_search_dim}; observer {o} skipped"))
-                    if draws is None:
-                        ctx.resample(seed=seed, step=i)
-                    else:
-                        ctx.resample(u=draws["u"][i])
-                set_active(window)
-                ctx.record_moments(i)
+                        ctx.step(i, taus[i - 1], images_of(i), normals=draws["evolve"][i], u=draws["u"][i])
+                    note_skips(i, running)
+                else:
+                    if starting.any():
+                        set_active(starting)
+                        if draws is None:
+                            ctx.init_particles(seed=seed)
+                        else:
+                            ctx.init_particles(normals=draws["init"])
+                    if running.any():
+                        set_active(running)
+                        if draws is None:
+                            ctx.evolve(taus[i - 1], seed=seed, step=i)
+                        else:
+                            ctx.evolve(taus[i - 1], normals=draws["evolve"][i])
+                    set_active(window)
+                    for o in np.nonzero(template_indices == i)[0]:
+                        if has[i, o]:
+                            ctx.init_templates(int(o), int(matching[i][o]))
+                    if running.any():
+                        set_active(running)
+                        ctx.update_weights(images_of(i))
+                        note_skips(i, running)
+                        if draws is None:
+                            ctx.resample(seed=seed, step=i)
+                        else:
+                            ctx.resample(u=draws["u"][i])
+                    set_active(window)
+                    ctx.record_moments(i)
                 if return_particles:
                     P_, W_ = ctx.get_particles(), ctx.get_weights()
                     out_p[window, i] = P_[window]

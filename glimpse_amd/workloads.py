@@ -98,10 +98,10 @@ class Workload:
         }
 
 
-def setup_context(ctx, wl, frames=None):
+def setup_context(ctx, wl, frames=None, channels=1):
     """Upload cameras + frames of a workload into a glimpse_amd._lib.Context and start a sequence."""
     for o in range(wl.O):
-        ctx.observer_init(o, wl.T, wl.imgsz[0], wl.imgsz[1], 1, wl.sigmas[o])
+        ctx.observer_init(o, wl.T, wl.imgsz[0], wl.imgsz[1], channels, wl.sigmas[o])
         ctx.observer_set_cameras(o, np.tile(wl.cams[o], (wl.T, 1)))
         for t in range(wl.T):
             f = frames[o][t] if frames is not None else wl.frame(o, t)

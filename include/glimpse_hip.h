@@ -112,6 +112,10 @@ int glh_observer_set_frame_device(glh_ctx* ctx, int obs, int image, const void* 
 int glh_begin_sequence(glh_ctx* ctx, int n_points, int n_particles, int tile_w, int tile_h);
 /* CartesianMotion parameters per point: [P][GLH_MOTION_LEN] (track/motion.py:121-147).     */
 int glh_set_motion_cartesian(glh_ctx* ctx, const double* params);
+/* Global index of this context's point 0 when the tracked points are sharded over several
+ * contexts / GPUs (default 0).  The device RNG (GLH_RNG_PHILOX) is keyed on the GLOBAL point
+ * index, so a sharded run draws exactly what the unsharded run draws.                        */
+int glh_set_point_offset(glh_ctx* ctx, int offset);
 /* observer_mask [P][O] (track/tracker.py:250-252, :289-290); NULL = all ones.              */
 int glh_set_observer_mask(glh_ctx* ctx, const uint8_t* mask);
 /* active [P]: 1 = the point takes part in the following stage calls (frames inside its
@@ -164,7 +168,9 @@ int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng
 /* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +
  * re-evolving gather + moments in one launch, evolved state never round-trips through HBM)
  * whenever no active mask / debug capture is in force; 0 = always the staged kernels
- * (glh_evolve -> glh_update_weights -> glh_resample).  Both give the same particles.          */
+ * (glh_evolve -> glh_update_weights -> glh_resample); 2 = fused, but with every search tile
+ * forced into the HBM workspaces (test hook for the large-tile path).  All give the same
+ * particles bit for bit.                                                                      */
 int glh_set_fused(glh_ctx* ctx, int on);
 
 /* Diagnostic: s_memtime stamps [P][10] at the phase boundaries of the fused kernel during the

@@ -54,9 +54,13 @@ def _run_golden(g, fused):
 @pytest.mark.parametrize("name", ["g8_c1.npz", "g8_c2mini.npz", "g8_c5mini.npz"])
 def test_fused_step_equals_staged_and_reference(lib, golden, name):
     g = golden(name)
-    fused = _run_golden(g, True)
-    staged = _run_golden(g, False)
+    fused = _run_golden(g, 1)
+    staged = _run_golden(g, 0)
+    hbm = _run_golden(g, 2)  # same kernel with every tile in the HBM workspaces (large-tile path)
     ok = ~g["errors"].astype(bool)
+    np.testing.assert_array_equal(hbm["particles"][ok], staged["particles"][ok])
+    np.testing.assert_array_equal(hbm["weights"][ok], staged["weights"][ok])
+    np.testing.assert_array_equal(hbm["moments"][:, ok], fused["moments"][:, ok])
     np.testing.assert_array_equal(fused["status"], staged["status"])
     np.testing.assert_array_equal(fused["obs_status"], staged["obs_status"])
     np.testing.assert_array_equal(fused["particles"][ok], staged["particles"][ok])
@@ -68,21 +72,22 @@ def test_fused_step_equals_staged_and_reference(lib, golden, name):
     np.testing.assert_allclose(sigmas[ok], g["out_sigmas"][ok], rtol=RTOL, atol=1e-8)
 
 
-@pytest.mark.parametrize("cfg", [("C2", 16, 2000), ("C3", 6, 5000), ("C5", 4, 3001), ("C3", 3, 12000)])
+@pytest.mark.parametrize("cfg", [("C2", 16, 2000, 1), ("C3", 6, 5000, 1), ("C5", 4, 3001, 1), ("C3", 3, 10240, 1),
+                                 ("C3", 2, 12000, 1), ("C2", 5, 777, 3), ("C5", 3, 1500, 3)])
 def test_fused_step_equals_staged_with_device_rng(lib, cfg):
     """Philox mode (what large runs use): re-evolving the gathered sources from the counter-based
     noise gives exactly the state the staged kernels store and gather."""
     from glimpse_amd import workloads
 
-    name, P, N = cfg
+    name, P, N, channels = cfg
     T = 5
     wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
-    frames = [wl.frames(o) for o in range(wl.O)]
+    frames = [[wl.scene.render(wl.cams[o], float(t), channels=channels) for t in range(T)] for o in range(wl.O)]
     res = []
-    for fused in (True, False):
+    for mode in (1, 0, 2):
         with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
-            workloads.setup_context(ctx, wl, frames)
-            ctx.set_fused(fused)
+            workloads.setup_context(ctx, wl, frames, channels=channels)
+            ctx.set_fused(mode)
             ctx.set_frame(0)
             ctx.init_particles(seed=11)
             for o in range(wl.O):
@@ -93,9 +98,42 @@ def test_fused_step_equals_staged_with_device_rng(lib, cfg):
             assert (ctx.observer_status() == lib.OBS_OK).all()
             assert (ctx.point_status() == 0).all()
             res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T)))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
-    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
+    for other in (1, 2):
+        np.testing.assert_array_equal(res[0][0], res[other][0])
+        np.testing.assert_array_equal(res[0][1], res[other][1])
+        np.testing.assert_allclose(res[0][2], res[other][2], rtol=1e-12, atol=1e-13)
     # the filter follows the synthetic motion (0.15 units/frame along x)
     vx = res[0][2][-1, :, 3]
     assert abs(np.median(vx) - 0.15) < 0.05
+
+
+def test_sharded_contexts_reproduce_the_unsharded_run(lib):
+    """Device RNG is keyed on the GLOBAL point index (glh_set_point_offset): two contexts tracking
+    points [0, 5) and [5, 8) give exactly the particles of one context tracking all 8."""
+    from glimpse_amd import sharding, workloads
+
+    T, P, N = 4, 8, 1500
+    wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [wl.frames(0)]
+
+    def run(lo, hi):
+        with lib.Context(hi - lo, N, 1, max_search_dim=160, max_frames=T) as ctx:
+            ctx.observer_init(0, T, 640, 640, 1, wl.sigmas[0])
+            ctx.observer_set_cameras(0, np.tile(wl.cams[0], (T, 1)))
+            for t in range(T):
+                ctx.observer_upload_frame(0, t, frames[0][t])
+            ctx.begin_sequence(hi - lo, N, wl.tile)
+            ctx.set_motion_cartesian(wl.params[lo:hi])
+            ctx.set_point_offset(lo)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=5)
+            ctx.init_templates(0, 0)
+            ctx.record_moments(0)
+            for i in range(1, T):
+                ctx.step(i, 1.0, [i], seed=5)
+            return ctx.get_particles(), ctx.get_moments(0, T)
+
+    full_p, full_m = run(0, P)
+    parts = [run(*sharding.shard_range(P, 2, r)) for r in range(2)]
+    np.testing.assert_array_equal(np.concatenate([p for p, _ in parts]), full_p)
+    np.testing.assert_array_equal(np.concatenate([m for _, m in parts], axis=1), full_m)

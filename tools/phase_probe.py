@@ -40,8 +40,14 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     print(f"{wl.describe()['workload']}")
     print(f"  last step kernels (ms): {ms}")
     print(f"  kernel span {span} ticks; per-point total: min {tot.min()} median {np.median(tot):.0f} max {tot.max()}")
-    print(f"  concurrency (sum of point times / span): {tot.sum() / span:.1f} points in flight")
+    print(f"  per-point total percentiles 50/90/99: {np.percentile(tot, [50, 90, 99])}")
+    t0 = st[:, 0] - st[:, 0].min()
+    t1 = st[:, -1] - st[:, 0].min()
+    print(f"  block start ticks percentiles 25/50/75/100: {np.percentile(t0, [25, 50, 75, 100])}; last end {t1.max()}")
     for k in range(9):
         print(f"  {NAMES[k + 1]:18s} median {np.median(d[:, k]):10.0f} ticks  {100 * d[:, k].sum() / tot.sum():5.1f} %")
     bx = ctx.search_boxes()[0]
-    print("  search tile w x h median:", np.median(bx[:, 2] - bx[:, 0]), np.median(bx[:, 3] - bx[:, 1]))
+    wsz, hsz = bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]
+    print("  search tile w x h median:", np.median(wsz), np.median(hsz), "max:", wsz.max(), hsz.max())
+    slow = np.argsort(tot)[-5:]
+    print("  slowest points: total", tot[slow], "tile", list(zip(wsz[slow], hsz[slow])))
