@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override points per GPU")
     ap.add_argument("--particles", type=int, default=None)
-    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented steps after the timed region")
+    ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--seed", type=int, default=1234)
@@ -47,6 +47,25 @@ class DevArray:
     def __init__(self, ptr, shape, typestr="<f8"):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2}
+
+
+KERNEL_OF_STAGE = {"point_step": "k_point_step", "evolve_project": "k_evolve_project", "resample": "k_resample",
+                   "weights": "k_weights", "ssd": "k_ssd", "tileprep": "k_tileprep", "spline_fit": "k_spline_fit"}
+
+
+def pmc_traffic(wl, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command),
+    or None when no counters were collected for this workload shape."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    key = f"{wl.name}:{wl.P}x{wl.N}"
+    entry = table.get(key, {}).get(kernel)
+    return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
 def algorithmic_bytes_per_step(P, N, O, tile, boxes, status):
@@ -121,15 +140,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from glimpse_amd import _lib, workloads
 
-    K, W, KP = args.steps, args.warmup, max(0, args.profile_steps)
-    T = 1 + W + K + KP
+    K, W = args.steps, args.warmup
+    T = 1 + W + K
     wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
                             seed=0)
     frames = [wl.frames(o) for o in range(wl.O)]
-    ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=local_rank, max_tile=max(wl.tile), max_search_dim=320,
+    ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=local_rank, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
                        max_frames=T)
     workloads.setup_context(ctx, wl, frames)
-    seed = args.seed + rank
+    # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
+    # sharded run draws what a single-GPU run of all points would draw
+    ctx.set_point_offset(rank * wl.P)
+    seed = args.seed
     images = lambda i: [i] * wl.O  # noqa: E731
 
     # frame 0: initialise particles + templates (tracker.py:327-342), untimed
@@ -161,6 +183,9 @@ def main():
             gather_list = [torch.empty_like(mom) for _ in range(world)]
         dist.gather(mom, gather_list, dst=0)  # warm the communicator up outside the timed region
 
+    # HIP events around every kernel launch on the context's stream, over the timed region itself
+    ctx.profile_enable(True)
+    ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(1 + W, 1 + W + K):
@@ -176,25 +201,18 @@ def main():
         t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    stage_ms = ctx.profile_get()
+    ctx.profile_enable(False)
 
     # health of the run: every point must still be tracked by every observer
     status = ctx.observer_status()
     pt_status = ctx.point_status()
     frac_ok = float((status == 0).mean())
     n_err = int((pt_status != 0).sum())
-
-    # instrumented steps (HIP events on the context's stream around every kernel)
-    stage_ms, flops, abytes = {}, 0.0, 0.0
-    if KP > 0:
-        ctx.profile_enable(True)
-        ctx.profile_reset()
-        for i in range(1 + W + K, 1 + W + K + KP):
-            ctx.step(i, 1.0, images(i), seed=seed)
-            st, bx = ctx.observer_status(), ctx.search_boxes()
-            flops += ssd_flops_per_step(wl.O, wl.tile, bx, st)
-            abytes += algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, bx, st)
-        stage_ms = ctx.profile_get()
-        ctx.profile_enable(False)
+    # algorithmic bytes / SSD flops of one step, from the search boxes of the last timed step
+    boxes = ctx.search_boxes()
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
+    flops = ssd_flops_per_step(wl.O, wl.tile, boxes, status)
 
     if rank == 0:
         value = world * wl.P * wl.N * K / elapsed
@@ -215,32 +233,21 @@ def main():
                            frames_per_s=K / elapsed),
             "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err},
         }
-        if KP > 0:
-            tot = sum(ms for ms, _ in stage_ms.values())
-            dom = max(stage_ms, key=lambda k: stage_ms[k][0])
-            dom_ms, dom_n = stage_ms[dom]
-            per_launch_ms = dom_ms / max(dom_n, 1)
-            launches_per_step = dom_n / KP
-            if dom == "ssd":
-                ach = flops / KP / launches_per_step / (per_launch_ms * 1e-3) / 1e12
-                roof = {"kernel": "k_ssd", "bound": "fp32-valu", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-                        "note": "SSD is (s-t)^2 accumulation on the FP32 vector pipe (no MFMA form); "
-                                "algorithmic flops = 3*tw*th*Wo*Ho per point-frame (SURVEY 8(d))"}
-            else:
-                ach = abytes / KP / launches_per_step / (per_launch_ms * 1e-3) / 1e9
-                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            roof["avg_launch_ms"] = per_launch_ms
-            out["roofline"] = roof
-            step_ms = tot / KP
-            out["roofline_step"] = {
-                "bound": "hbm", "achieved": abytes / KP / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": abytes / KP / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_particle_frame": abytes / KP / (wl.P * wl.N),
-                "note": "whole step: algorithmic bytes (SURVEY 8(d)) / sum of kernel times",
-            }
-            out["stage_ms_per_step"] = {k: ms / KP for k, (ms, _) in stage_ms.items() if ms > 0}
+        tot = sum(ms for ms, _ in stage_ms.values())
+        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+        dom_ms, dom_n = stage_ms[dom]
+        per_launch_ms = dom_ms / max(dom_n, 1)
+        launches_per_step = dom_n / K
+        # one launch of the dominant kernel processes P*N particle-frames (SURVEY 8(d) per-unit bytes)
+        ach = abytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9
+        roof = {"kernel": KERNEL_OF_STAGE.get(dom, dom), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, KERNEL_OF_STAGE.get(dom, dom)),
+                "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": abytes / launches_per_step,
+                "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
+                "ssd_fp32_tflops": flops / (tot / K * 1e-3) / 1e12}
+        out["roofline"] = roof
+        out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, frames, min(K, 4), args.cpu_seconds)
         print(json.dumps(out), flush=True)
