@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libglimpse_hip.so")
+LIB_PATH = os.environ.get("GLH_LIB") or os.path.join(HERE, "lib", "libglimpse_hip.so")  # GLH_LIB: experimental builds
 
 CAM_LEN = 24
 MOTION_LEN = 18

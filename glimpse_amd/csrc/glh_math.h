@@ -302,9 +302,14 @@ GLH_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a
 GLH_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                           uint32_t k1, uint32_t* out) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-  for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+#ifndef GLH_PHILOX_ROUNDS
+#define GLH_PHILOX_ROUNDS 10
+#endif
+  for (int r = 0; r < GLH_PHILOX_ROUNDS; ++r) {
+    // one 32 x 32 -> 64 product per multiplier (a single v_mad_u64_u32 on gfx950) gives hi and lo
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += W0;

@@ -264,18 +264,26 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   __shared__ uint32_t scan_tmp[PT_WAVES];
   __shared__ int s_box[NOBS][4];
   __shared__ int s_status[NOBS];
+  __shared__ double s_m[GLH_MOTION_LEN];  // this point's motion parameters: the loops below store to global
+                                          // memory, so reading them through a global pointer would reload
+                                          // (and wait for) them on every iteration
   const int pt = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int N = a.N;
   double* c = reinterpret_cast<double*>(smem);  // [N] log likelihoods -> weights -> cumulative weights
   unsigned char* r2 = smem + pt_align16(N * (int)sizeof(double));
-  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+  const double* m = s_m;
   const double* Pin = a.particles_in + (size_t)pt * N * 6;
   double* W = a.weights_tmp + (size_t)pt * N;
   const double tau = a.tau, tau2 = a.tau * a.tau;
 
   PT_STAMP(0);
   for (int k = tid; k < 16 * GLH_NPOLY; k += PT_BLK) tab[k] = a.poly[k];
+  if (tid < GLH_MOTION_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_LEN + tid];
+  bool live[NOBS];  // uniform across the block
+#pragma unroll
+  for (int o = 0; o < NOBS; ++o) live[o] = a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
+  __syncthreads();
 
   auto evolved = [&](int k, double* x) {
     const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)k * 6);
@@ -285,12 +293,14 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
     evolve_particle(x, m, n, tau, tau2);
   };
-  auto obs_live = [&](int o) -> bool {  // uniform across the block
-    return a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
-  };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
-  double2 uv0[PPT];
+  // PPT > 0: uv of observer 0 in PPT registers per thread.  PPT == 0: u parked in c[i] (LDS, free until
+  // phase C) and v in the first N doubles of the observer-0 slot of the uv scratch (L2 / Infinity Cache).
+  constexpr int NREG = PPT > 0 ? PPT : 1;
+  const int rounds = PPT > 0 ? PPT : (N + PT_BLK - 1) / PT_BLK;
+  double* V0 = a.uv + (size_t)pt * N * 2;
+  double2 uv0[NREG];
   {
     double mn[NOBS][2], mx[NOBS][2], nanf[NOBS];
 #pragma unroll
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     bool bad = false;
     const double zs = m[17];
 #pragma unroll
-    for (int r = 0; r < PPT; ++r) uv0[r] = make_double2(0.0, 0.0);
+    for (int r = 0; r < NREG; ++r) uv0[r] = make_double2(0.0, 0.0);
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
     {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
     }
 #pragma unroll 1
-    for (int r = 0; r < PPT; ++r) {
+    for (int r = 0; r < rounds; ++r) {
       const int i = r * PT_BLK + tid;
       double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
       {
@@ -335,12 +345,17 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
         }
 #pragma unroll
         for (int o = 0; o < NOBS; ++o) {
-          if (!obs_live(o)) continue;
+          if (!live[o]) continue;
           double u, v;
           project(a.cam[o], x[0], x[1], x[2], u, v);
-          if (o == 0)
-            pt_put<PPT>(uv0, r, make_double2(u, v));
-          else
+          if (o == 0) {
+            if constexpr (PPT > 0) {
+              pt_put<NREG>(uv0, r, make_double2(u, v));
+            } else {
+              c[i] = u;
+              V0[i] = v;
+            }
+          } else
             reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * N + i] = make_double2(u, v);
           if (isnan(u) || isnan(v)) {
             nanf[o] = 1.0;
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
 #pragma unroll
     for (int o = 0; o < NOBS; ++o) {
-      if (!obs_live(o)) continue;
+      if (!live[o]) continue;
       const double r0 = wave_min(mn[o][0]), r1 = wave_min(mn[o][1]);
       const double r2m = wave_max(mx[o][0]), r3 = wave_max(mx[o][1]), r4 = wave_max(nanf[o]);
       if (lane == 0) {
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       const int o = tid;
       const size_t slot = (size_t)o * a.P + pt;
       int st;
-      if (!obs_live(o)) {
+      if (!live[o]) {
         st = GLH_OBS_SKIPPED;
       } else if (!a.tmpl_valid[slot]) {
         st = GLH_OBS_NO_TEMPLATE;
@@ -397,13 +412,15 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       s_status[o] = st;
       a.obs_status[slot] = st;
     }
-    for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
+    if constexpr (PPT > 0)
+      for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
     __syncthreads();
   }
 
   PT_STAMP(1);
   // ---------------- B + C per observer, in the reference's order (tracker.py:139-146) ----------
   bool outside = false;
+  bool c_ready = PPT > 0;  // uniform: c[] holds log likelihoods (not the parked u coordinates)
   for (int o = 0; o < NOBS; ++o) {
     if (s_status[o] != GLH_OBS_OK) continue;  // uniform
     const size_t slot = (size_t)o * a.P + pt;
@@ -448,15 +465,30 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
       if (o == 0) {
 #pragma unroll 1
-        for (int r = 0; r < PPT; ++r) {
+        for (int r = 0; r < rounds; ++r) {
           const int i = r * PT_BLK + tid;
           if (i < N) {
-            const double2 q = pt_pick<PPT>(uv0, r);
+            double2 q;
+            if constexpr (PPT > 0)
+              q = pt_pick<NREG>(uv0, r);
+            else
+              q = make_double2(c[i], V0[i]);
             if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-            c[i] += spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+            const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+            if constexpr (PPT > 0)
+              c[i] += term;
+            else
+              c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           }
         }
+        c_ready = true;
       } else {
+        if constexpr (PPT == 0) {
+          if (!c_ready) {  // observer 0 was skipped: c[] still holds its u coordinates
+            for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
+            c_ready = true;
+          }
+        }
         for (int i = tid; i < N; i += PT_BLK) {
           const double2 q = uvp[i];
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
@@ -517,6 +549,10 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       sample_all(ws.Z);
     }
     __syncthreads();  // region 2 is free for the next observer
+  }
+  if constexpr (PPT == 0) {
+    if (!c_ready)
+      for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;  // every observer skipped (same-thread indices)
   }
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);

@@ -323,7 +323,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-    for (const void* f : {(const void*)k_point_step<4, 4, 1>, (const void*)k_point_step<10, 4, 1>,
+    for (const void* f : {(const void*)k_point_step<0, 4, 1>, (const void*)k_point_step<0, 4, 2>,
+                          (const void*)k_point_step<4, 4, 1>, (const void*)k_point_step<10, 4, 1>,
                           (const void*)k_point_step<20, 2, 1>, (const void*)k_point_step<4, 4, 2>,
                           (const void*)k_point_step<10, 4, 2>, (const void*)k_point_step<20, 2, 2>}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
@@ -988,6 +989,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
     r2 = PT_LDS_HALF - cN;
   else
     r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
+  if (getenv("GLH_PT_ONE_BLOCK")) r2 = std::min(PT_LDS_MAX - cN, 100 * 1024);  // experiment: 1 workgroup / CU
   if (c->fused == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
   if (r2 < r2_min) return false;
   *r2_bytes = r2;
@@ -1073,7 +1075,10 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const int ppt = c->N <= 4 * PT_BLK ? 4 : (c->N <= 10 * PT_BLK ? 10 : 20);
 #define GLH_LAUNCH_POINT(PPT_, MINW_, NOBS_) \
   hipLaunchKernelGGL((k_point_step<PPT_, MINW_, NOBS_>), grid, block, lds, c->stream, a)
-    if (O == 1) {
+    if (getenv("GLH_PT_UVLDS")) {
+      if (O == 1) GLH_LAUNCH_POINT(0, 4, 1);
+      else GLH_LAUNCH_POINT(0, 4, 2);
+    } else if (O == 1) {
       if (ppt == 4) GLH_LAUNCH_POINT(4, 4, 1);
       else if (ppt == 10) GLH_LAUNCH_POINT(10, 4, 1);
       else GLH_LAUNCH_POINT(20, 2, 1);
