@@ -24,12 +24,13 @@
 
 namespace glh {
 
-constexpr int PT_BLK = 512;
-constexpr int PT_WAVES = PT_BLK / WAVE;
+constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
+constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
 constexpr int PT_NSTAMP = 10;
 constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
+template <int TB>
 __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   v = wave_sum(v);
   __syncthreads();
@@ -37,7 +38,7 @@ __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   __syncthreads();
   double t = red[0];
 #pragma unroll
-  for (int w = 1; w < PT_WAVES; ++w) t += red[w];
+  for (int w = 1; w < TB / WAVE; ++w) t += red[w];
   return t;
 }
 
@@ -134,13 +135,14 @@ struct TileWs {
 };
 
 // extract_tile(histogram=template CDF) (tracker.py:605-607) into ws.S; see search_tile_from_box.
+template <int TB>
 __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box, int nb, int hist_n, const TileWs& ws,
                                              uint32_t* scan_tmp) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  for (int b = tid; b < nb; b += PT_BLK) ws.hist[b] = 0;
+  for (int b = tid; b < nb; b += TB) ws.hist[b] = 0;
   __syncthreads();
-  for (int idx = tid; idx < n; idx += PT_BLK) {
+  for (int idx = tid; idx < n; idx += TB) {
     const int r = idx / w, c = idx - r * w;
     const int key = pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c);
     ws.keys[idx] = (uint16_t)key;
@@ -148,7 +150,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   }
   __syncthreads();
   {
-    // inclusive scan of the nb <= 2 * PT_BLK bins: two bins per thread + block scan
+    // inclusive scan of the nb <= 2 * TB bins: two bins per thread + block scan
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
     const uint32_t h0 = b0 < nb ? ws.hist[b0] : 0u, h1 = b1 < nb ? ws.hist[b1] : 0u;
     const uint32_t local = h0 + h1;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     if (b1 < nb) ws.cum[b1] = excl + local;
   }
   __syncthreads();
-  for (int b = tid; b < nb; b += PT_BLK) {
+  for (int b = tid; b < nb; b += TB) {
     if (ws.hist[b]) {
       const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
       ws.lut[b] = np_interp(q, ws.cdf_q, ws.cdf_v, hist_n);
@@ -177,13 +179,13 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   __syncthreads();
   const int ld = ws.ld;
   // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
-  for (int idx = tid; idx < h * (ld - w); idx += PT_BLK) {
+  for (int idx = tid; idx < h * (ld - w); idx += TB) {
     const int r = idx / (ld - w), c = w + idx - r * (ld - w);
     ws.S[r * ld + c] = 0.0f;
   }
   // 5x5 median of the raw keys around every pixel (tiles are >= 8 pixels on a side, so a window
   // leaves the tile by at most 2 and ONE edge reflection is exact: d c b a | a b c d | d c b a)
-  for (int idx = tid; idx < n; idx += PT_BLK) {
+  for (int idx = tid; idx < n; idx += TB) {
     const int r = idx / w, c = idx - r * w;
     int rows[5], cols[5];
 #pragma unroll
@@ -208,6 +210,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
 
 // cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614) from ws.S / ws.T into ws.Z (widened
 // to float64 for the spline fit); arithmetic and summation order of k_ssd.
+template <int TB>
 __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo, int ho) {
   const int tid = threadIdx.x;
   const int twp = ssd_twp(tw);
@@ -215,7 +218,7 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   const int nstrips = spr * ho;
   const int G = ssd_row_split(wo, ho);
   const double inv_area = 1.0 / (double)(tw * th);
-  for (int s0 = 0; s0 < nstrips; s0 += PT_BLK / G) {
+  for (int s0 = 0; s0 < nstrips; s0 += TB / G) {
     const int strip = s0 + tid / G, g = tid % G;
     const bool live = strip < nstrips;
     const int rr = live ? strip / spr : 0;
@@ -242,11 +245,12 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   __syncthreads();
 }
 
+template <int TB>
 __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) {
   const int tid = threadIdx.x;
-  for (int c = tid; c < wo; c += PT_BLK) solve_line(ws.Z + c, wo, ho, ws.fh);
+  for (int c = tid; c < wo; c += TB) solve_line(ws.Z + c, wo, ho, ws.fh);
   __syncthreads();
-  for (int r = tid; r < ho; r += PT_BLK) solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
+  for (int r = tid; r < ho; r += TB) solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
   __syncthreads();
 }
 
@@ -255,8 +259,9 @@ __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) 
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <int PPT, int MINW, int NOBS>
-__global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
+template <int TB, int PPT, int MINW, int NOBS>
+__global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
+  constexpr int PT_WAVES = TB / WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double tab[16 * GLH_NPOLY];
   __shared__ double wave_tot[PT_WAVES];
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   const double tau = a.tau, tau2 = a.tau * a.tau;
 
   PT_STAMP(0);
-  for (int k = tid; k < 16 * GLH_NPOLY; k += PT_BLK) tab[k] = a.poly[k];
+  for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
   if (tid < GLH_MOTION_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_LEN + tid];
   bool live[NOBS];  // uniform across the block
 #pragma unroll
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   // PPT > 0: uv of observer 0 in PPT registers per thread.  PPT == 0: u parked in c[i] (LDS, free until
   // phase C) and v in the first N doubles of the observer-0 slot of the uv scratch (L2 / Infinity Cache).
   constexpr int NREG = PPT > 0 ? PPT : 1;
-  const int rounds = PPT > 0 ? PPT : (N + PT_BLK - 1) / PT_BLK;
+  const int rounds = PPT > 0 ? PPT : (N + TB - 1) / TB;
   double* V0 = a.uv + (size_t)pt * N * 2;
   double2 uv0[NREG];
   {
@@ -321,10 +326,10 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     }
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
-      const int i = r * PT_BLK + tid;
+      const int i = r * TB + tid;
       double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
       {
-        const int inext = i + PT_BLK;
+        const int inext = i + TB;
         const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)(inext < N ? inext : 0) * 6);
         nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
       }
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       a.obs_status[slot] = st;
     }
     if constexpr (PPT > 0)
-      for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
+      for (int i = tid; i < N; i += TB) c[i] = 0.0;
     __syncthreads();
   }
 
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     const double* fw_g = a.lu + a.lu_off[wo];
     {
       const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
-      for (int idx = tid; idx < th * twp; idx += PT_BLK) {
+      for (int idx = tid; idx < th * twp; idx += TB) {
         const int i = idx / twp, j = idx - i * twp;
         ws.T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
       }
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       if (o == 0) {
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-          const int i = r * PT_BLK + tid;
+          const int i = r * TB + tid;
           if (i < N) {
             double2 q;
             if constexpr (PPT > 0)
@@ -485,11 +490,11 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       } else {
         if constexpr (PPT == 0) {
           if (!c_ready) {  // observer 0 was skipped: c[] still holds its u coordinates
-            for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;
+            for (int i = tid; i < N; i += TB) c[i] = 0.0;
             c_ready = true;
           }
         }
-        for (int i = tid; i < N; i += PT_BLK) {
+        for (int i = tid; i < N; i += TB) {
           const double2 q = uvp[i];
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           c[i] += spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
@@ -506,24 +511,24 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
       double* cq = reinterpret_cast<double*>(X + hcl + pt_align16(hs * ws_ * 2));
       double* cv = cq + pt_align16(hist_n * 8) / 8;
-      for (int k = tid; k < hist_n; k += PT_BLK) {
+      for (int k = tid; k < hist_n; k += TB) {
         cq[k] = hq_g[k];
         cv[k] = hv_g[k];
       }
       ws.cdf_q = cq;
       ws.cdf_v = cv;
-      pt_tile_prep(ob, box, nb, hist_n, ws, scan_tmp);  // starts with a barrier: T, cdf visible
+      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp);  // starts with a barrier: T, cdf visible
       PT_STAMP(2);
       ws.Z = reinterpret_cast<double*>(X);
       double* fl = ws.Z + pt_align16(ho * wo * 8) / 8;
       // X is reused: the histogram / keys / cdf are dead once the search tile is written
-      for (int k = tid; k < 5 * ho; k += PT_BLK) fl[k] = fh_g[k];
-      for (int k = tid; k < 5 * wo; k += PT_BLK) fl[5 * ho + k] = fw_g[k];
+      for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
+      for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
       ws.fh = fl;
       ws.fw = fl + 5 * ho;
-      pt_ssd(ws, tw, th, wo, ho);
+      pt_ssd<TB>(ws, tw, th, wo, ho);
       PT_STAMP(3);
-      pt_spline_fit(ws, wo, ho);
+      pt_spline_fit<TB>(ws, wo, ho);
       PT_STAMP(4);
       sample_all(ws.Z);
     } else {
@@ -540,11 +545,11 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
       ws.cdf_v = hv_g;
       ws.fh = fh_g;
       ws.fw = fw_g;
-      pt_tile_prep(ob, box, nb, hist_n, ws, scan_tmp);
+      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp);
       PT_STAMP(2);
-      pt_ssd(ws, tw, th, wo, ho);
+      pt_ssd<TB>(ws, tw, th, wo, ho);
       PT_STAMP(3);
-      pt_spline_fit(ws, wo, ho);
+      pt_spline_fit<TB>(ws, wo, ho);
       PT_STAMP(4);
       sample_all(ws.Z);
     }
@@ -552,11 +557,11 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   }
   if constexpr (PPT == 0) {
     if (!c_ready)
-      for (int i = tid; i < N; i += PT_BLK) c[i] = 0.0;  // every observer skipped (same-thread indices)
+      for (int i = tid; i < N; i += TB) c[i] = 0.0;  // every observer skipped (same-thread indices)
   }
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
-  for (int i = tid; i < N; i += PT_BLK) {
+  for (int i = tid; i < N; i += TB) {
     double ll = c[i];
     if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
     const double w = exp(-ll) + 1e-300;
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   double* node = reinterpret_cast<double*>(r2);
   {
     const int sub = tid & 7;
-    for (int L = tid >> 3; L < a.nleaves; L += PT_BLK / 8) {
+    for (int L = tid >> 3; L < a.nleaves; L += TB / 8) {
       const int off = a.leaf_off[L], len = a.leaf_len[L];
       double res;
       if (len < 8) {
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   }
   __syncthreads();
   for (int l = 0; l < a.nlevels; ++l) {
-    for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += PT_BLK) {
+    for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += TB) {
       const int32_t* op = a.ops + 3 * k;
       node[op[0]] = node[op[1]] + node[op[2]];
     }
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   }
   double total = node[a.roots[0]];
   for (int r = 1; r < a.nroots; ++r) total += node[a.roots[r]];
-  const int seg = (N + PT_BLK - 1) / PT_BLK;
+  const int seg = (N + TB - 1) / TB;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   double run = 0.0;
   for (int k = k0; k < k1; ++k) {
@@ -664,12 +669,12 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
   evolved(0, K);  // pivot of the shifted moments: the point's first evolved particle
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
   constexpr int GU = 2;
-  for (int j0 = tid; j0 < N; j0 += GU * PT_BLK) {
+  for (int j0 = tid; j0 < N; j0 += GU * TB) {
     int lo[GU];
     double x[GU][6], w[GU];
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
-      const int j = j0 + g * PT_BLK;
+      const int j = j0 + g * TB;
       lo[g] = j < N ? sidx[j] : 0;
     }
 #pragma unroll
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(PT_BLK, MINW) void k_point_step(PointArgs a) {
     }
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
-      const int j = j0 + g * PT_BLK;
+      const int j = j0 + g * TB;
       if (j < N) {
         double2* dst = reinterpret_cast<double2*>(Pout + (size_t)j * 6);
         dst[0] = make_double2(x[g][0], x[g][1]);

@@ -48,7 +48,7 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // LDS plan of the fused kernel (glh_point.h): c[N] + region 2
-constexpr int PT_LDS_MAX = 156 * 1024;   // dynamic LDS of one workgroup (static ~4 KB on top)
+constexpr int PT_LDS_MAX = 152 * 1024;   // dynamic LDS of one workgroup (static <= 5 KB on top, 160 KB per CU)
 constexpr int PT_LDS_HALF = 76 * 1024;   // dynamic LDS that still lets two workgroups share a CU
 
 // ------------------------------------------------------------------------------------------
@@ -323,10 +323,11 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-    for (const void* f : {(const void*)k_point_step<0, 4, 1>, (const void*)k_point_step<0, 4, 2>,
-                          (const void*)k_point_step<4, 4, 1>, (const void*)k_point_step<10, 4, 1>,
-                          (const void*)k_point_step<20, 2, 1>, (const void*)k_point_step<4, 4, 2>,
-                          (const void*)k_point_step<10, 4, 2>, (const void*)k_point_step<20, 2, 2>}) {
+    for (const void* f : {(const void*)k_point_step<512, 0, 4, 1>, (const void*)k_point_step<512, 0, 4, 2>,
+                          (const void*)k_point_step<512, 4, 4, 1>, (const void*)k_point_step<512, 10, 4, 1>,
+                          (const void*)k_point_step<512, 4, 4, 2>, (const void*)k_point_step<512, 10, 4, 2>,
+                          (const void*)k_point_step<1024, 0, 4, 1>, (const void*)k_point_step<1024, 0, 4, 2>,
+                          (const void*)k_point_step<1024, 10, 4, 1>, (const void*)k_point_step<1024, 10, 4, 2>}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
@@ -973,7 +974,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
 static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
-  if (c->N > 20 * PT_BLK) return false;
+
   int nb = 256;
   for (int o = 0; o < O; ++o) {
     if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
@@ -1071,21 +1072,35 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   {
     StageTimer t(c, ST_POINT_STEP);
     const size_t lds = (size_t)pt_align16(c->N * 8) + r2_bytes;
-    const dim3 grid(c->P), block(PT_BLK);
-    const int ppt = c->N <= 4 * PT_BLK ? 4 : (c->N <= 10 * PT_BLK ? 10 : 20);
-#define GLH_LAUNCH_POINT(PPT_, MINW_, NOBS_) \
-  hipLaunchKernelGGL((k_point_step<PPT_, MINW_, NOBS_>), grid, block, lds, c->stream, a)
-    if (getenv("GLH_PT_UVLDS")) {
-      if (O == 1) GLH_LAUNCH_POINT(0, 4, 1);
-      else GLH_LAUNCH_POINT(0, 4, 2);
-    } else if (O == 1) {
-      if (ppt == 4) GLH_LAUNCH_POINT(4, 4, 1);
-      else if (ppt == 10) GLH_LAUNCH_POINT(10, 4, 1);
-      else GLH_LAUNCH_POINT(20, 2, 1);
+    const dim3 grid(c->P);
+    // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  uv of observer 0
+    // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that.
+    const bool big = c->N > 10 * PT_BLK;
+    const int tb = big ? PT_BLK_BIG : PT_BLK;
+    const dim3 block(tb);
+    int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
+    if (big && ppt == 4) ppt = 10;
+    if (getenv("GLH_PT_UVLDS")) ppt = 0;
+#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_) \
+  hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_>), grid, block, lds, c->stream, a)
+    if (!big) {
+      if (O == 1) {
+        if (ppt == 4) GLH_LAUNCH_POINT(512, 4, 1);
+        else if (ppt == 10) GLH_LAUNCH_POINT(512, 10, 1);
+        else GLH_LAUNCH_POINT(512, 0, 1);
+      } else {
+        if (ppt == 4) GLH_LAUNCH_POINT(512, 4, 2);
+        else if (ppt == 10) GLH_LAUNCH_POINT(512, 10, 2);
+        else GLH_LAUNCH_POINT(512, 0, 2);
+      }
     } else {
-      if (ppt == 4) GLH_LAUNCH_POINT(4, 4, 2);
-      else if (ppt == 10) GLH_LAUNCH_POINT(10, 4, 2);
-      else GLH_LAUNCH_POINT(20, 2, 2);
+      if (O == 1) {
+        if (ppt == 10) GLH_LAUNCH_POINT(1024, 10, 1);
+        else GLH_LAUNCH_POINT(1024, 0, 1);
+      } else {
+        if (ppt == 10) GLH_LAUNCH_POINT(1024, 10, 2);
+        else GLH_LAUNCH_POINT(1024, 0, 2);
+      }
     }
 #undef GLH_LAUNCH_POINT
   }

@@ -75,6 +75,17 @@ def uv_to_ground(cam, uv, z=0.0, iterations=20):
     return cam[0:2] + s[:, None] * d[:, 0:2]
 
 
+def project(cam, xyz):
+    """World xyz (n, 3) -> pixel uv (n, 2) for the packed camera vector (host NumPy; workload set-up only)."""
+    xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
+    R = rotation_matrix(cam[3:6])
+    c = (xyz - cam[0:3]) @ R.T
+    xy = c[:, 0:2] / c[:, 2:3]
+    xy[c[:, 2] <= 0] = np.nan
+    dr, dt = _distort(cam, xy)
+    return (xy * dr[:, None] + dt) * cam[8:10] + (cam[6:8] * 0.5 + cam[10:12])
+
+
 def make_texture(size, seed=0, blur=2.0):
     """Seeded white noise, Gaussian-blurred, rescaled to [0, 255] float32 (size x size)."""
     rng = np.random.default_rng(seed)

@@ -76,7 +76,26 @@ class Workload:
         if self.O == 2:
             border += 200.0  # keep the points inside the oblique view too
         # different shards track different points of the same scene
-        self.xy = synth.grid_points(cam0, self.P, border_px=border, seed=1000 + shard)
+        if self.O == 1:
+            self.xy = synth.grid_points(cam0, self.P, border_px=border, seed=1000 + shard)
+        else:
+            # keep only seeds that every camera sees with a full template + search margin
+            margin = 0.5 * max(self.tile) + (110.0 if min(self.imgsz) >= 1024 else 40.0)
+            want, factor = self.P, 2
+            while True:
+                cand = synth.grid_points(cam0, want * factor, border_px=border - 200.0 + margin, seed=1000 + shard)
+                ok = np.ones(len(cand), dtype=bool)
+                xyz = np.column_stack((cand, np.zeros(len(cand))))
+                for cam in self.cams:
+                    uv = synth.project(cam, xyz)
+                    ok &= (uv[:, 0] > margin) & (uv[:, 0] < cam[6] - margin)
+                    ok &= (uv[:, 1] > margin) & (uv[:, 1] < cam[7] - margin)
+                if ok.sum() >= want or factor > 64:
+                    break
+                factor *= 2
+            if ok.sum() < want:
+                raise ValueError(f"only {ok.sum()} of {want} points are visible in both cameras")
+            self.xy = cand[ok][:want]
         self.params = motion_params(self.xy, dem_sigma=self.dem_sigma)
 
     def frame(self, obs, t):
