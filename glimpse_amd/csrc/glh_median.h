@@ -39,4 +39,22 @@ GLH_HD T median25(T* v) {
   return v[12];
 }
 
+#if defined(__HIPCC__)
+// Two medians at once on packed 16-bit keys (v_pk_min_u16 / v_pk_max_u16): the same network
+// applied lane-wise to the low and high halves, i.e. to two neighbouring pixels.
+typedef unsigned short glh_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ glh_us2 median25_pk(glh_us2* v) {
+#define GLH_CE(a, b)                                          \
+  {                                                           \
+    glh_us2 lo_ = __builtin_elementwise_min(v[a], v[b]);      \
+    glh_us2 hi_ = __builtin_elementwise_max(v[a], v[b]);      \
+    v[a] = lo_;                                               \
+    v[b] = hi_;                                               \
+  }
+  GLH_MED25_NETWORK(GLH_CE)
+#undef GLH_CE
+  return v[12];
+}
+#endif
+
 }  // namespace glh

@@ -104,7 +104,7 @@ struct PointArgs {
   ObsFrame obs[PT_MAX_OBS];
   CamDev cam[PT_MAX_OBS];  // by value: read through the scalar cache from the kernel arguments
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
-  int32_t r2_bytes;  // bytes of LDS behind c[N]
+  int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
   int32_t nleaves, nnodes, nlevels, nroots;
 };
@@ -116,6 +116,11 @@ __host__ __device__ __forceinline__ int pt_search_ld(int ws) { return ((ws + 3 +
 // bytes of the arrays that always live in LDS: template tile + histogram / cumulative counts / LUT
 __host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
   return pt_align16(th * ssd_twp(tw) * 4) + pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
+}
+
+// ints of the NumPy pairwise-sum plan staged in LDS: leaf_off | leaf_len | ops | level_off | roots
+__host__ __device__ __forceinline__ int pt_plan_ints(int nleaves, int nnodes, int nlevels, int nroots) {
+  return 2 * nleaves + 3 * (nnodes - nleaves) + (nlevels + 1) + nroots;
 }
 
 // Where one observer's tile arrays live.
@@ -183,27 +188,39 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     const int r = idx / (ld - w), c = w + idx - r * (ld - w);
     ws.S[r * ld + c] = 0.0f;
   }
-  // 5x5 median of the raw keys around every pixel (tiles are >= 8 pixels on a side, so a window
-  // leaves the tile by at most 2 and ONE edge reflection is exact: d c b a | a b c d | d c b a)
-  for (int idx = tid; idx < n; idx += TB) {
-    const int r = idx / w, c = idx - r * w;
-    int rows[5], cols[5];
+  // 5x5 median of the raw keys around every pixel, TWO horizontally adjacent pixels per thread on
+  // packed 16-bit lanes (same selection network, v_pk_min/max_u16).  Tiles are >= 8 pixels on a side,
+  // so a window leaves the tile by at most 3 and ONE edge reflection is exact
+  // (scipy.ndimage 'reflect': d c b a | a b c d | d c b a).
+  const int npc = (w + 1) >> 1;
+  for (int idx = tid; idx < h * npc; idx += TB) {
+    const int r = idx / npc, c0 = 2 * (idx - r * npc);
+    int rows[5], cols[6];
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
-      int rr = r + d - 2, cc = c + d - 2;
+      int rr = r + d - 2;
       rr = rr < 0 ? -rr - 1 : (rr >= h ? 2 * h - 1 - rr : rr);
-      cc = cc < 0 ? -cc - 1 : (cc >= w ? 2 * w - 1 - cc : cc);
       rows[d] = rr * w;
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      int cc = c0 + d - 2;
+      cc = cc < 0 ? -cc - 1 : (cc >= w ? 2 * w - 1 - cc : cc);
       cols[d] = cc;
     }
-    int v[25];
+    glh_us2 v[25];
 #pragma unroll
-    for (int dr = 0; dr < 5; ++dr)
+    for (int dr = 0; dr < 5; ++dr) {
+      unsigned short k6[6];
 #pragma unroll
-      for (int dc = 0; dc < 5; ++dc) v[dr * 5 + dc] = ws.keys[rows[dr] + cols[dc]];
-    const int key = v[12];
-    const int med = median25(v);
-    ws.S[r * ld + c] = (float)(ws.lut[key] - ws.lut[med]);
+      for (int d = 0; d < 6; ++d) k6[d] = ws.keys[rows[dr] + cols[d]];
+#pragma unroll
+      for (int dc = 0; dc < 5; ++dc) v[dr * 5 + dc] = glh_us2{k6[dc], k6[dc + 1]};  // pixel c0 | pixel c0 + 1
+    }
+    const glh_us2 key = v[12];
+    const glh_us2 med = median25_pk(v);
+    ws.S[r * ld + c0] = (float)(ws.lut[key.x] - ws.lut[med.x]);
+    if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(ws.lut[key.y] - ws.lut[med.y]);
   }
   __syncthreads();
 }
@@ -245,14 +262,58 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   __syncthreads();
 }
 
+// solve_line (glh_kernels.h) with the same arithmetic, software-pipelined: the next element and its
+// LU factors are loaded BEFORE the current result is stored, so a dependent step costs its float64
+// chain instead of a full LDS round trip (the compiler cannot hoist loads above the aliasing store).
+__device__ __forceinline__ void pt_solve_line(double* x, int stride, int n, const double* f) {
+  const double *l1 = f, *l2 = f + n, *u0i = f + 2 * n, *u1 = f + 3 * n, *u2 = f + 4 * n;
+  double ym1 = x[0], ym2 = 0.0;
+  double nx = n > 1 ? x[stride] : 0.0, nl1 = n > 1 ? l1[1] : 0.0, nl2 = n > 1 ? l2[1] : 0.0;
+  for (int i = 1; i < n; ++i) {
+    const double cx = nx, cl1 = nl1, cl2 = nl2;
+    if (i + 1 < n) {
+      nx = x[(size_t)(i + 1) * stride];
+      nl1 = l1[i + 1];
+      nl2 = l2[i + 1];
+    }
+    double y = cx - cl1 * ym1;
+    if (i >= 2) y -= cl2 * ym2;
+    x[(size_t)i * stride] = y;
+    ym2 = ym1;
+    ym1 = y;
+  }
+  double xp1 = 0.0, xp2 = 0.0;
+  double na = x[(size_t)(n - 1) * stride], nu0 = u0i[n - 1], nu1 = u1[n - 1], nu2 = u2[n - 1];
+  for (int i = n - 1; i >= 0; --i) {
+    double acc = na;
+    const double c0 = nu0, c1 = nu1, c2 = nu2;
+    if (i > 0) {
+      na = x[(size_t)(i - 1) * stride];
+      nu0 = u0i[i - 1];
+      nu1 = u1[i - 1];
+      nu2 = u2[i - 1];
+    }
+    if (i + 1 < n) acc -= c1 * xp1;
+    if (i + 2 < n) acc -= c2 * xp2;
+    acc *= c0;
+    x[(size_t)i * stride] = acc;
+    xp2 = xp1;
+    xp1 = acc;
+  }
+}
+
 template <int TB>
 __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) {
   const int tid = threadIdx.x;
-  for (int c = tid; c < wo; c += TB) solve_line(ws.Z + c, wo, ho, ws.fh);
+  for (int c = tid; c < wo; c += TB) pt_solve_line(ws.Z + c, wo, ho, ws.fh);
   __syncthreads();
-  for (int r = tid; r < ho; r += TB) solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
+  for (int r = tid; r < ho; r += TB) pt_solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
   __syncthreads();
 }
+
+// barrier for phases that exchange data through LDS only: does not wait for this wave's outstanding
+// global loads / stores (which __syncthreads() would)
+__device__ __forceinline__ void pt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define PT_STAMP(k)                                                                      \
   do {                                                                                   \
@@ -285,6 +346,19 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(0);
   for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
   if (tid < GLH_MOTION_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_LEN + tid];
+  // the pairwise-sum plan (phase D) is read level by level between barriers: from LDS, not from HBM
+  int32_t* p_leaf_off = reinterpret_cast<int32_t*>(r2 + a.r2_bytes);
+  int32_t* p_leaf_len = p_leaf_off + a.nleaves;
+  int32_t* p_ops = p_leaf_len + a.nleaves;
+  int32_t* p_level_off = p_ops + 3 * (a.nnodes - a.nleaves);
+  int32_t* p_roots = p_level_off + a.nlevels + 1;
+  for (int k = tid; k < a.nleaves; k += TB) {
+    p_leaf_off[k] = a.leaf_off[k];
+    p_leaf_len[k] = a.leaf_len[k];
+  }
+  for (int k = tid; k < 3 * (a.nnodes - a.nleaves); k += TB) p_ops[k] = a.ops[k];
+  if (tid <= a.nlevels) p_level_off[tid] = a.level_off[tid];
+  if (tid < a.nroots) p_roots[tid] = a.roots[tid];
   bool live[NOBS];  // uniform across the block
 #pragma unroll
   for (int o = 0; o < NOBS; ++o) live[o] = a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
@@ -576,7 +650,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   {
     const int sub = tid & 7;
     for (int L = tid >> 3; L < a.nleaves; L += TB / 8) {
-      const int off = a.leaf_off[L], len = a.leaf_len[L];
+      const int off = p_leaf_off[L], len = p_leaf_len[L];
       double res;
       if (len < 8) {
         res = 0.0;
@@ -598,14 +672,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   }
   __syncthreads();
   for (int l = 0; l < a.nlevels; ++l) {
-    for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += TB) {
-      const int32_t* op = a.ops + 3 * k;
+    for (int k = p_level_off[l] + tid; k < p_level_off[l + 1]; k += TB) {
+      const int32_t* op = p_ops + 3 * k;
       node[op[0]] = node[op[1]] + node[op[2]];
     }
     __syncthreads();
   }
-  double total = node[a.roots[0]];
-  for (int r = 1; r < a.nroots; ++r) total += node[a.roots[r]];
+  double total = node[p_roots[0]];
+  for (int r = 1; r < a.nroots; ++r) total += node[p_roots[r]];
   const int seg = (N + TB - 1) / TB;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   double run = 0.0;
@@ -707,7 +781,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   {
     // one pass for the 13 sums: wave shuffles -> LDS [wave][13] -> thread k < 6 finishes component k
     double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (sidx is dead after the gather)
-    __syncthreads();
+    pt_lds_barrier();  // LDS only: the gather's stores drain in the background
     const double t0 = wave_sum(s0);
     if (lane == 0) mred[wave * 13] = t0;
 #pragma unroll
@@ -718,7 +792,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         mred[wave * 13 + 7 + k] = t2;
       }
     }
-    __syncthreads();
+    pt_lds_barrier();
     if (tid < 6) {
       double S0 = mred[0], S1 = mred[1 + tid], S2 = mred[7 + tid];
       for (int w = 1; w < PT_WAVES; ++w) {

@@ -980,7 +980,8 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
     if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
     if (c->obs[o].channels == 3) nb = 766;
   }
-  const int cN = pt_align16(c->N * 8);
+  // c[N] and, behind region 2, the pairwise-sum plan
+  const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
   const int plan = pt_align16(c->nnodes * 8) + pt_align16(c->N * 2);
   const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb));
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
@@ -1071,7 +1072,8 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.nroots = c->nroots;
   {
     StageTimer t(c, ST_POINT_STEP);
-    const size_t lds = (size_t)pt_align16(c->N * 8) + r2_bytes;
+    const size_t lds = (size_t)pt_align16(c->N * 8) + r2_bytes +
+                       pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
     const dim3 grid(c->P);
     // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  uv of observer 0
     // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that.
