@@ -34,6 +34,9 @@ def parse_args():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override points per GPU")
     ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--burn-in", type=int, default=6,
+                    help="untimed frames after initialisation, before the warm-up: the particle cloud starts "
+                         "from its wide prior and reaches the tracking regime after a few updates")
     ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -140,8 +143,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from glimpse_amd import _lib, workloads
 
-    K, W = args.steps, args.warmup
-    T = 1 + W + K
+    K, W, B = args.steps, args.warmup, max(0, args.burn_in)
+    T = 1 + B + W + K
     wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
                             seed=0)
     frames = [wl.frames(o) for o in range(wl.O)]
@@ -160,7 +163,7 @@ def main():
     for o in range(wl.O):
         ctx.init_templates(o, 0)
     ctx.record_moments(0)
-    for i in range(1, 1 + W):
+    for i in range(1, 1 + B + W):  # burn-in + warm-up, untimed
         ctx.step(i, 1.0, images(i), seed=seed)
     ctx.sync()
 
@@ -188,7 +191,7 @@ def main():
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for i in range(1 + W, 1 + W + K):
+    for i in range(1 + B + W, 1 + B + W + K):
         ctx.step(i, 1.0, images(i), seed=seed)
     if dist is not None:
         ctx.sync()
@@ -230,7 +233,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
-                           frames_per_s=K / elapsed),
+                           frames_per_s=K / elapsed, burn_in_steps=B),
             "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err},
         }
         tot = sum(ms for ms, _ in stage_ms.values())

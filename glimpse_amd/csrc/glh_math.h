@@ -36,13 +36,30 @@ struct CamDev {
   int32_t any_p;    // any(self.p)
 };
 
+// Which optional terms of the projection are active, as one word: the tests of the reference
+// (`if self.correction`, `any(self.k)`, `if self.k[i]`, ... camera.py:1148-1196, :1446) depend on
+// the camera only, so a kernel can take them from a scalar register and branch uniformly.
+enum : uint32_t {
+  CAM_F_CORR = 1u, CAM_F_ANYK = 2u, CAM_F_ANYKDEN = 4u, CAM_F_ANYP = 8u, CAM_F_K0 = 16u  // K0 << i: k[i] != 0
+};
+GLH_HD uint32_t cam_flags(const CamDev& c) {
+  uint32_t f = 0;
+  if (c.has_corr) f |= CAM_F_CORR;
+  if (c.any_k) f |= CAM_F_ANYK;
+  if (c.any_kden) f |= CAM_F_ANYKDEN;
+  if (c.any_p) f |= CAM_F_ANYP;
+  for (int i = 0; i < 6; ++i)
+    if (c.k[i] != 0.0) f |= CAM_F_K0 << i;
+  return f;
+}
+
 // Camera.xyz_to_uv (camera.py:591-628): _xyz_to_xy (:1435-1470), _distort (:1180-1196 with
-// :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).
-GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, double& v) {
+// :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).  `f` = cam_flags(c).
+GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
   double dx = x - c.xyz[0];
   double dy = y - c.xyz[1];
   double dz = z - c.xyz[2];
-  if (c.has_corr) {
+  if (f & CAM_F_CORR) {
     // helpers.elevation_corrections (helpers.py:1790)
     double sq = dx * dx + dy * dy;
     dz += (c.refraction - 1.0) * sq / (2.0 * c.radius);
@@ -57,24 +74,24 @@ GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, do
   double px = cx / cz;
   double py = cy / cz;
   double qx = px, qy = py;
-  if (c.any_k || c.any_p) {
+  if (f & (CAM_F_ANYK | CAM_F_ANYP)) {
     double r2 = px * px + py * py;
-    if (c.any_k) {
+    if (f & CAM_F_ANYK) {
       double dr = 1.0;
-      if (c.k[0] != 0.0) dr += c.k[0] * r2;
-      if (c.k[1] != 0.0) dr += c.k[1] * r2 * r2;
-      if (c.k[2] != 0.0) dr += c.k[2] * r2 * r2 * r2;
-      if (c.any_kden) {
+      if (f & (CAM_F_K0 << 0)) dr += c.k[0] * r2;
+      if (f & (CAM_F_K0 << 1)) dr += c.k[1] * r2 * r2;
+      if (f & (CAM_F_K0 << 2)) dr += c.k[2] * r2 * r2 * r2;
+      if (f & CAM_F_ANYKDEN) {
         double t = 1.0;
-        if (c.k[3] != 0.0) t += c.k[3] * r2;
-        if (c.k[4] != 0.0) t += c.k[4] * r2 * r2;
-        if (c.k[5] != 0.0) t += c.k[5] * r2 * r2 * r2;
+        if (f & (CAM_F_K0 << 3)) t += c.k[3] * r2;
+        if (f & (CAM_F_K0 << 4)) t += c.k[4] * r2 * r2;
+        if (f & (CAM_F_K0 << 5)) t += c.k[5] * r2 * r2 * r2;
         dr /= t;
       }
       qx = px * dr;
       qy = py * dr;
     }
-    if (c.any_p) {
+    if (f & CAM_F_ANYP) {
       double xty = px * py;
       double dtx = 2.0 * xty * c.p[0] + c.p[1] * (r2 + 2.0 * (px * px));
       double dty = c.p[0] * (r2 + 2.0 * (py * py)) + 2.0 * xty * c.p[1];
@@ -84,6 +101,9 @@ GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, do
   }
   u = qx * c.f[0] + c.off[0];
   v = qy * c.f[1] + c.off[1];
+}
+GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, double& v) {
+  project_f(c, cam_flags(c), x, y, z, u, v);
 }
 
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is

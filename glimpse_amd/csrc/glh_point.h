@@ -102,7 +102,8 @@ struct PointArgs {
   double tau;
   double inv2s2[PT_MAX_OBS];
   ObsFrame obs[PT_MAX_OBS];
-  CamDev cam[PT_MAX_OBS];  // by value: read through the scalar cache from the kernel arguments
+  CamDev cam[PT_MAX_OBS];  // by value; copied to LDS once per workgroup
+  uint32_t cam_flags[PT_MAX_OBS];  // cam_flags(cam[o]): scalar, so the optional projection terms branch uniformly
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ uint32_t scan_tmp[PT_WAVES];
   __shared__ int s_box[NOBS][4];
   __shared__ int s_status[NOBS];
+  __shared__ CamDev s_cam[NOBS];           // cameras: LDS broadcast reads instead of ~60 live SGPRs each
   __shared__ double s_m[GLH_MOTION_LEN];  // this point's motion parameters: the loops below store to global
                                           // memory, so reading them through a global pointer would reload
                                           // (and wait for) them on every iteration
@@ -346,6 +348,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(0);
   for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
   if (tid < GLH_MOTION_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_LEN + tid];
+  {
+    static_assert(sizeof(CamDev) % 8 == 0, "CamDev is copied as doubles");
+    constexpr int CW = sizeof(CamDev) / 8;
+    if (tid < NOBS * CW) {
+      const int o = tid / CW, k = tid - o * CW;
+      reinterpret_cast<double*>(&s_cam[o])[k] = reinterpret_cast<const double*>(&a.cam[o])[k];
+    }
+  }
   // the pairwise-sum plan (phase D) is read level by level between barriers: from LDS, not from HBM
   int32_t* p_leaf_off = reinterpret_cast<int32_t*>(r2 + a.r2_bytes);
   int32_t* p_leaf_len = p_leaf_off + a.nleaves;
@@ -400,6 +410,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
+      // compiler barrier: camera / motion constants are re-read from LDS (broadcast) every iteration
+      // instead of being hoisted into ~100 registers that would spill
+      asm volatile("" ::: "memory");
       const int i = r * TB + tid;
       double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
       {
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
           double u, v;
-          project(a.cam[o], x[0], x[1], x[2], u, v);
+          project_f(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
           if (o == 0) {
             if constexpr (PPT > 0) {
               pt_put<NREG>(uv0, r, make_double2(u, v));

@@ -49,7 +49,7 @@ static int fail(int code, const char* fmt, ...) {
 
 // LDS plan of the fused kernel (glh_point.h): c[N] + region 2
 constexpr int PT_LDS_MAX = 152 * 1024;   // dynamic LDS of one workgroup (static <= 5 KB on top, 160 KB per CU)
-constexpr int PT_LDS_HALF = 76 * 1024;   // dynamic LDS that still lets two workgroups share a CU
+constexpr int PT_LDS_HALF = 75 * 1024;   // dynamic LDS that still lets two workgroups share a CU
 
 // ------------------------------------------------------------------------------------------
 // stages (for the event timers)
@@ -1049,6 +1049,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     if ((int)c->obs[o].cams_host.size() != c->obs[o].n_images)
       return fail(GLH_E_STATE, "observer %d: cameras have not been set", o);
     a.cam[o] = c->obs[o].cams_host[images[o] >= 0 ? images[o] : 0];
+    a.cam_flags[o] = cam_flags(a.cam[o]);
     a.inv2s2[o] = 1.0 / (2.0 * (c->obs[o].sigma * c->obs[o].sigma));
   }
   a.N = c->N;
