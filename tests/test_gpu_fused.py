@@ -137,3 +137,47 @@ def test_sharded_contexts_reproduce_the_unsharded_run(lib):
     parts = [run(*sharding.shard_range(P, 2, r)) for r in range(2)]
     np.testing.assert_array_equal(np.concatenate([p for p, _ in parts]), full_p)
     np.testing.assert_array_equal(np.concatenate([m for _, m in parts], axis=1), full_m)
+
+
+def test_fused_step_edge_cases_match_staged(lib):
+    """Failure modes inside the fused kernel behave like the staged kernels: a NaN particle
+    (ValueError bit, tracker.py:118 -> uv NaN -> search box out of bounds, tracker.py:597-601), a cloud that
+    leaves the image (warning + skip: weights come from the motion model alone) and a template box
+    outside the image (IndexError bit, raster.py:417; no template -> observer skipped)."""
+    from glimpse_amd import workloads
+
+    T, P, N = 4, 6, 1200
+    wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [wl.frames(0)]
+    params = wl.params.copy()
+    params[1, 0:2] = (-30.6, 0.0)   # ~14 px from the left edge: template fits, the evolved cloud does not
+    params[2, 0:2] = (-31.6, 5.0)   # template box itself leaves the image
+    out = []
+    for mode in (1, 0, 2):
+        with lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
+            workloads.setup_context(ctx, wl, frames)
+            ctx.set_motion_cartesian(params)
+            ctx.set_fused(mode)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=3)
+            ctx.init_templates(0, 0)
+            ctx.record_moments(0)
+            p0 = ctx.get_particles()
+            p0[4, 17, 0] = np.nan  # one missing value in point 4
+            ctx.set_particles(p0)
+            for i in range(1, T):
+                ctx.step(i, 1.0, [i], seed=3)
+            out.append(dict(p=ctx.get_particles(), w=ctx.get_weights(), st=ctx.point_status(),
+                            ob=ctx.observer_status(), ef=ctx.point_error_frame(), m=ctx.get_moments(0, T)))
+    ref = out[1]
+    assert ref["st"][4] & lib.PT_NAN and ref["st"][2] & lib.PT_TEMPLATE_OOB
+    assert ref["ob"][0, 2] == lib.OBS_NO_TEMPLATE
+    assert ref["ob"][0, 1] == lib.OBS_OUT_OF_BOUNDS or ref["st"][1] == 0
+    for o in (out[0], out[2]):
+        np.testing.assert_array_equal(o["st"], ref["st"])
+        np.testing.assert_array_equal(o["ob"], ref["ob"])
+        np.testing.assert_array_equal(o["ef"], ref["ef"])
+        np.testing.assert_array_equal(o["p"], ref["p"])
+        np.testing.assert_array_equal(o["w"], ref["w"])
+        ok = [0, 1, 2, 3, 5]
+        np.testing.assert_allclose(o["m"][:, ok], ref["m"][:, ok], rtol=1e-12, atol=1e-13)
