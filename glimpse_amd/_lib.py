@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("GLH_LIB") or os.path.join(HERE, "lib", "libglimpse_hi
 CAM_LEN = 24
 MOTION_LEN = 18
 RNG_HOST, RNG_PHILOX = 0, 1
+RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2}
 OK = 0
 PT_NAN, PT_TEMPLATE_OOB, PT_SAMPLE_OUTSIDE, PT_RESAMPLE_CLAMP, PT_CONST_TILE = 1, 2, 4, 8, 16
 OBS_OK, OBS_SKIPPED, OBS_OUT_OF_BOUNDS, OBS_TILE_TOO_LARGE, OBS_NO_TEMPLATE = 0, 1, 2, 3, 4
@@ -76,6 +77,9 @@ SIGNATURES = {
     "glh_init_templates": (_I, [_P, _I, _I]),
     "glh_update_weights": (_I, [_P, _P]),
     "glh_resample": (_I, [_P, _I, _P, _U64, _U64]),
+    "glh_resample_method": (_I, [_P, _I, _I, _P, _U64, _U64]),
+    "glh_record_covariances": (_I, [_P, _I]),
+    "glh_get_covariances": (_I, [_P, _I, _I, _P]),
     "glh_record_moments": (_I, [_P, _I]),
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
     "glh_set_fused": (_I, [_P, _I]),
@@ -282,12 +286,21 @@ class Context:
         im = self._images(images)
         check(self.lib.glh_update_weights(self.handle, _ptr(im)))
 
-    def resample(self, u=None, seed=0, step=0):
+    def resample(self, u=None, seed=0, step=0, method="systematic"):
+        m = RESAMPLE[method]
         if u is None:
-            check(self.lib.glh_resample(self.handle, RNG_PHILOX, None, seed, step))
+            check(self.lib.glh_resample_method(self.handle, m, RNG_PHILOX, None, seed, step))
         else:
-            uu = _arr(u, np.float64, (self.P,))
-            check(self.lib.glh_resample(self.handle, RNG_HOST, _ptr(uu), 0, step))
+            uu = _arr(u, np.float64, (self.P,) if m == 0 else (self.P, self.N))
+            check(self.lib.glh_resample_method(self.handle, m, RNG_HOST, _ptr(uu), 0, step))
+
+    def record_covariances(self, frame):
+        check(self.lib.glh_record_covariances(self.handle, int(frame)))
+
+    def get_covariances(self, frame0, n_frames):
+        out = np.empty((n_frames, self.P, 6, 6))
+        check(self.lib.glh_get_covariances(self.handle, frame0, n_frames, _ptr(out)))
+        return out
 
     def record_moments(self, frame):
         check(self.lib.glh_record_moments(self.handle, int(frame)))

@@ -318,6 +318,69 @@ __global__ __launch_bounds__(BLK) void k_moments(MomentsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Tracker.particle_covariance (tracker.py:78-82): np.cov(particles.T, aweights=weights, ddof=0)
+//   avg = sum(w x)/sum(w);  cov[i][j] = sum(w (x_i - avg_i)(x_j - avg_j)) / sum(w).  One block per point.
+// ------------------------------------------------------------------------------------------
+struct CovArgs {
+  const double* particles;
+  const double* weights;
+  const uint8_t* active;
+  double* out;  // [P][36]
+  int32_t N;
+};
+
+__global__ __launch_bounds__(BLK) void k_covariance(CovArgs a) {
+  __shared__ double red[NWAVES];
+  const int pt = blockIdx.x;
+  if (a.active && !a.active[pt]) return;
+  const int tid = threadIdx.x;
+  const double* P0 = a.particles + (size_t)pt * a.N * 6;
+  const double* W0 = a.weights + (size_t)pt * a.N;
+  double sw = 0.0, s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < a.N; i += BLK) {
+    const double w = W0[i];
+    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
+    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    sw += w;
+    s[0] += v0.x * w; s[1] += v0.y * w; s[2] += v1.x * w;
+    s[3] += v1.y * w; s[4] += v2.x * w; s[5] += v2.y * w;
+  }
+  sw = block_sum(sw, red);
+  double mean[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mean[k] = block_sum(s[k], red) / sw;
+  double q[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) q[k] = 0.0;
+  for (int i = tid; i < a.N; i += BLK) {
+    const double w = W0[i];
+    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
+    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    const double d[6] = {v0.x - mean[0], v0.y - mean[1], v1.x - mean[2], v1.y - mean[3], v2.x - mean[4], v2.y - mean[5]};
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double wr = w * d[r];
+#pragma unroll
+      for (int cidx = r; cidx < 6; ++cidx) q[k++] += wr * d[cidx];
+    }
+  }
+  double* out = a.out + (size_t)pt * 36;
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int cidx = r; cidx < 6; ++cidx) {
+      const double v = block_sum(q[k++], red) * (1.0 / sw);
+      if (tid == 0) {
+        out[r * 6 + cidx] = v;
+        out[cidx * 6 + r] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // pixel keys: gray value, or channel sum for RGB (tile.mean(axis=2) is sum/3, tracker.py:524)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int pixel_key(const uint8_t* frame, int width, int channels, int row,
@@ -1007,7 +1070,7 @@ struct ResampleArgs {
   double* particles_out;
   double* weights_out;
   const uint8_t* active;
-  const double* u;   // [P] (host mode) or null
+  const double* u;   // [P] (systematic, host mode) or [P][N] (stratified / choice, host mode) or null
   int32_t* idx_out;  // [P][N] or null
   double* moments;   // [P][12] mean | sigma of the resampled set, or null
   uint32_t* pt_status;
@@ -1019,6 +1082,7 @@ struct ResampleArgs {
   const int32_t* roots;      // chunk roots, summed left to right
   uint64_t seed, step;
   int32_t N, nleaves, nnodes, nlevels, nroots, rng_mode, frame, pt_base;
+  int32_t method;  // GLH_RESAMPLE_*
 };
 
 __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
@@ -1095,23 +1159,23 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
   if (tid > 0)
     for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
   __syncthreads();
-  // --- positions (tracker.py:173): pos_j = (j + u) * (1 / n)
-  double u;
-  if (a.rng_mode == GLH_RNG_HOST) {
-    u = a.u[pt];
-  } else {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
-                  (uint32_t)(a.seed >> 32), r);
-    u = u01_halfopen(r[0], r[1]);
-  }
   const double inv_n = 1.0 / (double)N;
-  // --- np.searchsorted(c, pos) by its inverse: source k serves the positions with
-  //     c[k-1] < pos_j <= c[k], i.e. j in [f(k-1), f(k)) with f(k) = #{j : pos_j <= c[k]}.
-  //     f is guessed arithmetically and fixed up with the exact float comparison, so the
-  //     indices are exactly searchsorted's; each thread scatters the runs of its own k range.
   uint16_t* sidx = reinterpret_cast<uint16_t*>(node + a.nnodes);  // [N], N < 65536
-  {
+  if (a.method == GLH_RESAMPLE_SYSTEMATIC) {
+    // --- positions (tracker.py:173): pos_j = (j + u) * (1 / n)
+    double u;
+    if (a.rng_mode == GLH_RNG_HOST) {
+      u = a.u[pt];
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+                    (uint32_t)(a.seed >> 32), r);
+      u = u01_halfopen(r[0], r[1]);
+    }
+    // --- np.searchsorted(c, pos) by its inverse: source k serves the positions with
+    //     c[k-1] < pos_j <= c[k], i.e. j in [f(k-1), f(k)) with f(k) = #{j : pos_j <= c[k]}.
+    //     f is guessed arithmetically and fixed up with the exact float comparison, so the
+    //     indices are exactly searchsorted's; each thread scatters the runs of its own k range.
     auto count_le = [&](double ck) -> int {
       double g = floor(ck * (double)N - u) + 1.0;
       int f = g < 0.0 ? 0 : (g > (double)N ? N : (int)g);
@@ -1130,6 +1194,47 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       if (f_prev < N) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
       for (int j = f_prev; j < N; ++j) sidx[j] = (uint16_t)(N - 1);
     }
+  } else {
+    // --- one uniform per output (tracker.py:178-186 stratified, :205-209 np.random.choice): plain binary
+    //     search of every position in the LDS-resident cumulative weights
+    if (a.method == GLH_RESAMPLE_CHOICE) {
+      // RandomState.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, uniform, side='right')
+      const double last = c[N - 1];
+      __syncthreads();
+      for (int k = tid; k < N; k += BLK) c[k] = c[k] / last;
+      __syncthreads();
+    }
+    bool clamp = false;
+    for (int j = tid; j < N; j += BLK) {
+      double uj;
+      if (a.rng_mode == GLH_RNG_HOST) {
+        uj = a.u[(size_t)pt * N + j];
+      } else {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x53545241u, (uint32_t)a.seed,
+                      (uint32_t)(a.seed >> 32), r);
+        uj = u01_halfopen(r[0], r[1]);
+      }
+      int lo = 0, hi = N;
+      if (a.method == GLH_RESAMPLE_STRATIFIED) {
+        const double pos = ((double)j + uj) * inv_n;  // positions = (arange(n) + random(n)) * (1 / n)
+        while (lo < hi) {                              // side='left': #{k : c[k] < pos}
+          const int mid = (lo + hi) >> 1;
+          if (c[mid] < pos) lo = mid + 1; else hi = mid;
+        }
+      } else {
+        while (lo < hi) {                              // side='right': #{k : c[k] <= u}
+          const int mid = (lo + hi) >> 1;
+          if (c[mid] <= uj) lo = mid + 1; else hi = mid;
+        }
+      }
+      if (lo >= N) {
+        lo = N - 1;
+        clamp = true;
+      }
+      sidx[j] = (uint16_t)lo;
+    }
+    if (clamp) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
   }
   __syncthreads();
   // --- gather + moments

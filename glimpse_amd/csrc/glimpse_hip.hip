@@ -99,6 +99,8 @@ struct glh_ctx {
   double *particles[2] = {nullptr, nullptr}, *weights[2] = {nullptr, nullptr};
   double *motion = nullptr, *uv = nullptr, *bbox_part = nullptr, *normals = nullptr, *u = nullptr;
   double *mean6 = nullptr, *moments = nullptr;
+  double* covariances = nullptr;  // [max_frames][P][36], allocated on first use
+  double* uj = nullptr;           // [P][N] host-fed per-particle uniforms (stratified / choice)
   uint8_t *obs_mask = nullptr, *active = nullptr;
   uint32_t* pt_status = nullptr;
   int32_t *pt_err_frame = nullptr, *obs_status = nullptr, *box = nullptr, *idx = nullptr;
@@ -216,7 +218,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
     dfree(c->weights[i]);
   }
   dfree(c->motion); dfree(c->uv); dfree(c->bbox_part); dfree(c->normals); dfree(c->u);
-  dfree(c->mean6); dfree(c->moments); dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
+  dfree(c->mean6); dfree(c->moments); dfree(c->covariances); dfree(c->uj); dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
@@ -906,22 +908,36 @@ extern "C" int glh_update_weights(glh_ctx* c, const int32_t* images) {
 }
 
 extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t seed, uint64_t step) {
+  return glh_resample_method(c, GLH_RESAMPLE_SYSTEMATIC, rng_mode, u, seed, step);
+}
+
+extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const double* u, uint64_t seed,
+                                   uint64_t step) {
   CHK(need_seq(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (method != GLH_RESAMPLE_SYSTEMATIC && method != GLH_RESAMPLE_STRATIFIED && method != GLH_RESAMPLE_CHOICE)
+    return fail(GLH_E_UNSUPPORTED, "resampling method %d is not provided (systematic, stratified, choice)", method);
+  const bool per_particle = method != GLH_RESAMPLE_SYSTEMATIC;
   if (rng_mode == GLH_RNG_HOST) {
-    if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u [P]");
-    HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u (%s)", per_particle ? "[P][N]" : "[P]");
+    if (per_particle) {
+      if (!c->uj) CHK(dalloc(&c->uj, (size_t)c->cfg.max_points * c->cfg.max_particles));
+      HIPCHK(hipMemcpyAsync(c->uj, u, (size_t)c->P * c->N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+      HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
   } else if (rng_mode != GLH_RNG_PHILOX) {
     return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
   }
   ResampleArgs a{};
+  a.method = method;
   a.particles_in = c->particles[c->cur];
   a.weights_in = c->weights[c->cur];
   a.particles_out = c->particles[c->cur ^ 1];
   a.weights_out = c->weights[c->cur ^ 1];
   a.active = c->have_active ? c->active : nullptr;
-  a.u = c->u;
+  a.u = per_particle ? c->uj : c->u;
   a.idx_out = c->keep_idx ? c->idx : nullptr;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
@@ -1110,6 +1126,39 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   c->moments_frame = frame;
+  return GLH_OK;
+}
+
+extern "C" int glh_record_covariances(glh_ctx* c, int frame) {
+  CHK(need_seq(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
+  if (!c->covariances) {
+    const size_t n = (size_t)c->cfg.max_frames * c->cfg.max_points * 36;
+    CHK(dalloc(&c->covariances, n));
+    hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->covariances, n, (double)NAN);
+    HIPCHK(hipGetLastError());
+  }
+  CovArgs a{};
+  a.particles = c->particles[c->cur];
+  a.weights = c->weights[c->cur];
+  a.active = c->have_active ? c->active : nullptr;
+  a.out = c->covariances + (size_t)frame * c->P * 36;
+  a.N = c->N;
+  {
+    StageTimer t(c, ST_MOMENTS);
+    hipLaunchKernelGGL(k_covariance, dim3(c->P), dim3(BLK), 0, c->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return GLH_OK;
+}
+
+extern "C" int glh_get_covariances(glh_ctx* c, int frame0, int n_frames, double* out) {
+  CHK(need_seq(c));
+  if (!out || frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames)
+    return fail(GLH_E_INVALID, "bad frame range");
+  if (!c->covariances) return fail(GLH_E_STATE, "glh_record_covariances has not been called");
+  DOWNLOAD(out, c->covariances + (size_t)frame0 * c->P * 36, (size_t)n_frames * c->P * 36, double);
   return GLH_OK;
 }
 

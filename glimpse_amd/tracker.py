@@ -49,8 +49,9 @@ class Tracker:
         self.observers = list(observers)
         if viewshed is not None:
             raise NotImplementedError("viewshed lookups are listed under 'next' (SURVEY.md 8(f) rank 1)")
-        if resample_method != "systematic":
-            raise NotImplementedError("only systematic resampling runs on the GPU path (others: 'next')")
+        if resample_method not in _lib.RESAMPLE:
+            raise NotImplementedError(f"resample_method {resample_method!r}: the GPU path provides "
+                                      f"{sorted(_lib.RESAMPLE)} ('residual' is not built)")
         if tuple(highpass.get("size", (5, 5))) != (5, 5) or set(highpass) - {"size"}:
             raise NotImplementedError("the high-pass filter is the reference default: median, size (5, 5)")
         if interpolation.get("kx", 3) != 3 or interpolation.get("ky", 3) != 3:
@@ -148,8 +149,6 @@ class Tracker:
         params = dict(motion_models=motion_models, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
                       observer_mask=observer_mask, return_covariances=return_covariances,
                       return_particles=return_particles, reduce_particles=reduce_particles, parallel=parallel)
-        if return_covariances:
-            raise NotImplementedError("return_covariances is listed under 'next' (SURVEY.md 8(f) rank 3)")
         time_unit = motion_models[0].time_unit
         for model in motion_models[1:]:
             if model.time_unit != time_unit:
@@ -197,6 +196,8 @@ class Tracker:
             ctx.set_active(None if (uniform and mask.all()) else mask.astype(np.uint8))
 
         lo, hi = int(first[~empty].min()) if (~empty).any() else 0, int(last.max())
+        method = self.resample_method
+        systematic = method == "systematic"
 
         def run(draws):
             """The frame loop (tracker.py:326-357) for all tracks at once."""
@@ -222,7 +223,7 @@ class Tracker:
                 starting = (first == i) & ~empty
                 running = (first < i) & (i <= last)
                 window = starting | running
-                if uniform and running.all() and not (template_indices == i).any():
+                if uniform and running.all() and not (template_indices == i).any() and systematic:
                     # the common frame: every track is running and no template starts here ->
                     # ONE fused launch for evolve + likelihood + resample + moments (glh_step)
                     set_active(window)
@@ -253,11 +254,14 @@ class Tracker:
                         ctx.update_weights(images_of(i))
                         note_skips(i, running)
                         if draws is None:
-                            ctx.resample(seed=seed, step=i)
+                            ctx.resample(seed=seed, step=i, method=method)
                         else:
-                            ctx.resample(u=draws["u"][i])
+                            ctx.resample(u=draws["u"][i], method=method)
                     set_active(window)
                     ctx.record_moments(i)
+                if return_covariances:
+                    set_active(window)
+                    ctx.record_covariances(i)
                 if return_particles:
                     P_, W_ = ctx.get_particles(), ctx.get_weights()
                     out_p[window, i] = P_[window]
@@ -273,7 +277,7 @@ class Tracker:
             stops = np.stack((last, last), axis=1)
             for _ in range(ntracks + 1):
                 np.random.set_state(state0)
-                draws = self._draw_numpy(ntracks, n, first, last, stops)
+                draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic)
                 out_particles, out_weights, status, err_frame = run(draws)
                 new_stops = np.stack((last, last), axis=1)
                 for p in np.nonzero(status)[0]:
@@ -287,6 +291,9 @@ class Tracker:
         moments = ctx.get_moments(0, ntimes)  # (T, P, 12)
         means = np.ascontiguousarray(np.transpose(moments[:, :, 0:6], (1, 0, 2)))
         sigmas = np.ascontiguousarray(np.transpose(moments[:, :, 6:12], (1, 0, 2)))
+        covariances = None
+        if return_covariances:  # tracker.py:307-308, :352: (P, T, 6, 6) instead of sigmas
+            covariances = np.ascontiguousarray(np.transpose(ctx.get_covariances(0, ntimes), (1, 0, 2, 3)))
         errors = [None] * ntracks
         for p in range(ntracks):
             if status[p]:
@@ -297,6 +304,8 @@ class Tracker:
                 e = int(err_frame[p])
                 means[p, e:] = np.nan
                 sigmas[p, e:] = np.nan
+                if covariances is not None:
+                    covariances[p, e:] = np.nan
                 if return_particles:
                     out_particles[p, e:] = np.nan
                     out_weights[p, e:] = np.nan
@@ -305,7 +314,8 @@ class Tracker:
         # single-track state, like the reference leaves it after the last track
         self.particles = ctx.get_particles()[-1]
         self.weights = ctx.get_weights()[-1]
-        kwargs = dict(time_unit=time_unit, datetimes=datetimes, means=means, sigmas=sigmas,
+        kwargs = dict(time_unit=time_unit, datetimes=datetimes, means=means,
+                      sigmas=None if return_covariances else sigmas, covariances=covariances,
                       particles=None if reduce_particles else out_particles,
                       weights=None if reduce_particles else out_weights, tracker=self, images=matching,
                       params=params, errors=errors,
@@ -316,17 +326,19 @@ class Tracker:
         return tracks
 
     @staticmethod
-    def _draw_numpy(ntracks, n, first, last, stops):
+    def _draw_numpy(ntracks, n, first, last, stops, per_particle_u=False):
         """Consume the legacy global stream exactly like the reference (one track after another):
-        randn(n,2), randn(n), randn(n,3), then per step randn(n,3) and random().  `stops[p]` =
-        (last frame with an evolve draw, last frame with a resample draw) of track p."""
+        randn(n,2), randn(n), randn(n,3), then per step randn(n,3) and random() -- or random(n) for
+        stratified resampling (tracker.py:182) and for np.random.choice, whose n uniforms come from the
+        same global stream (tracker.py:209).  `stops[p]` = (last frame with an evolve draw, last frame
+        with a resample draw) of track p."""
         T = int(max(last.max() + 1, 1))
         nbytes = ntracks * T * n * 3 * 8
         if nbytes > _MAX_HOST_DRAWS_BYTES:
             raise MemoryError(f"rng='numpy' would stage {nbytes / 2**30:.1f} GiB of host draws; use rng='philox'")
         init = np.zeros((ntracks, n, 6))
         evolve = np.zeros((T, ntracks, n, 3))
-        u = np.zeros((T, ntracks))
+        u = np.zeros((T, ntracks, n)) if per_particle_u else np.zeros((T, ntracks))
         for p in range(ntracks):
             if last[p] < first[p]:
                 continue
@@ -337,7 +349,7 @@ class Tracker:
                 if i <= stops[p, 0]:
                     evolve[i, p] = np.random.randn(n, 3)
                 if i <= stops[p, 1]:
-                    u[i, p] = np.random.random()
+                    u[i, p] = np.random.random(n) if per_particle_u else np.random.random()
         return {"init": init, "evolve": evolve, "u": u}
 
     # ---- single-track step methods of the reference's public API ---------------------------------
@@ -385,6 +397,14 @@ class Tracker:
         self._push(ctx)
         ctx.record_moments(0)
         return ctx.get_moments(0, 1)[0, 0, 6:12]
+
+    @property
+    def particle_covariance(self):
+        """tracker.py:78-82: np.cov(particles.T, aweights=weights, ddof=0) (device reduction)."""
+        ctx = self._single()
+        self._push(ctx)
+        ctx.record_covariances(0)
+        return ctx.get_covariances(0, 1)[0, 0]
 
     def initialize_weights(self):
         """tracker.py:121-124."""
@@ -453,11 +473,16 @@ class Tracker:
         return ctx.log_likelihoods(obs)[0]
 
     def resample_particles(self, method=None):
-        """tracker.py:151-223 (systematic), drawing u from the legacy global stream like the reference."""
-        if (method or self.resample_method) != "systematic":
-            raise NotImplementedError("only systematic resampling runs on the GPU path")
+        """tracker.py:151-223 (systematic, stratified, choice), drawing from the legacy global stream like
+        the reference: random() / random(n) / the n uniforms of np.random.choice."""
+        method = method or self.resample_method
+        if method not in _lib.RESAMPLE:
+            raise NotImplementedError(f"resampling method {method!r} is not built on the GPU path")
         ctx = self._single()
         self._push(ctx)
-        ctx.resample(u=np.array([np.random.random()]))
+        if method == "systematic":
+            ctx.resample(u=np.array([np.random.random()]))
+        else:
+            ctx.resample(u=np.random.random(len(self.particles))[None], method=method)
         self.particles = ctx.get_particles()[0]
         self.weights = ctx.get_weights()[0]

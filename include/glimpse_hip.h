@@ -65,6 +65,11 @@ extern "C" {
 #define GLH_OBS_TILE_TOO_LARGE 3 /* search tile exceeds the workspace (build limit)        */
 #define GLH_OBS_NO_TEMPLATE 4
 
+/* ---- resampling methods (track/tracker.py:151-223) ------------------------------------- */
+#define GLH_RESAMPLE_SYSTEMATIC 0 /* one uniform per point          tracker.py:168-176        */
+#define GLH_RESAMPLE_STRATIFIED 1 /* one uniform per particle       tracker.py:178-186        */
+#define GLH_RESAMPLE_CHOICE 2     /* np.random.choice(n, n, p=w)    tracker.py:205-209        */
+
 /* ---- random-number modes ------------------------------------------------------------- */
 #define GLH_RNG_HOST 0   /* caller supplies the normals / uniforms (parity with np.random)  */
 #define GLH_RNG_PHILOX 1 /* counter-based Philox4x32-10 on the device                       */
@@ -157,6 +162,15 @@ int glh_update_weights(glh_ctx* ctx, const int32_t* images /* [O], -1 = None */)
 /* Tracker.resample_particles("systematic") (track/tracker.py:168-176, :222-223).
  * GLH_RNG_HOST: u [P] = the np.random.random() draw of each point.                         */
 int glh_resample(glh_ctx* ctx, int rng_mode, const double* u, uint64_t seed, uint64_t step);
+/* Same with an explicit method (GLH_RESAMPLE_*).  GLH_RNG_HOST: u is [P] for systematic (the
+ * np.random.random() of each point) and [P][N] for stratified (np.random.random(n)) and
+ * choice (the n uniforms RandomState.choice draws).  "residual" is not provided.             */
+int glh_resample_method(glh_ctx* ctx, int method, int rng_mode, const double* u, uint64_t seed,
+                        uint64_t step);
+/* Tracker.particle_covariance (track/tracker.py:78-82; np.cov(aweights=w, ddof=0)) of every
+ * active point into history slot `frame`; glh_get_covariances: out [n_frames][P][36].       */
+int glh_record_covariances(glh_ctx* ctx, int frame);
+int glh_get_covariances(glh_ctx* ctx, int frame0, int n_frames, double* out);
 /* particle_mean + compute_particle_sigma (track/tracker.py:72-76, :89-104) of every active
  * point into history slot `frame` (rows of inactive points keep NaN).                      */
 int glh_record_moments(glh_ctx* ctx, int frame);

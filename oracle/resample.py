@@ -42,6 +42,20 @@ def residual(weights, u):
     return np.hstack((initial_indexes, additional_indexes))
 
 
+def choice(weights, u):
+    """tracker.py:205-209: `np.random.choice(np.arange(n), size=(n,), replace=True, p=weights)` with the n
+    uniforms it draws passed as u.  The legacy `RandomState.choice` (numpy/random/mtrand.pyx, the
+    replace=True / p given branch) computes cdf = p.cumsum(); cdf /= cdf[-1];
+    idx = cdf.searchsorted(random_sample(n), side='right')."""
+    weights = weights / weights.sum()
+    cdf = np.cumsum(weights)
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, np.asarray(u, dtype=float), side="right")
+
+
+METHODS = {"systematic": systematic, "stratified": stratified, "choice": choice}
+
+
 def particle_mean(particles, weights):
     """tracker.py:76."""
     return np.average(particles, weights=weights, axis=0)

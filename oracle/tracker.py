@@ -94,6 +94,7 @@ def track_one(
     draws=None,
     trace=None,
     capture_errors=False,
+    resample_method="systematic",
 ):
     """One track: tracker.py:305-374 (`process`).
 
@@ -168,10 +169,12 @@ def track_one(
                 if replay:
                     u = draws["u"][step]
                 else:
-                    u = np.random.random()
+                    # one uniform (systematic) or n of them (stratified; np.random.choice draws its n
+                    # uniforms from the same global stream)
+                    u = np.random.random() if resample_method == "systematic" else np.random.random(n)
                     if draws is not None:
                         draws["u"].append(u)
-                idx = resample.systematic(weights, u)
+                idx = resample.METHODS[resample_method](weights, u)
                 if tr is not None:
                     tr["idx"] = idx.copy()
                 particles = particles[idx]

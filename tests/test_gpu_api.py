@@ -115,3 +115,63 @@ def test_philox_tracking_recovers_velocity(golden):
     v = tracks.vxyz[:, -1]
     assert np.all(np.abs(v[:, 0] - 0.15) < 0.05), v
     assert np.all(np.abs(v[:, 1]) < 0.05), v
+
+
+@pytest.mark.parametrize("name,tracker_kw,track_kw", [
+    ("g9_cov.npz", {}, dict(return_covariances=True)),
+    ("g9_stratified.npz", dict(resample_method="stratified"), {}),
+    ("g9_choice.npz", dict(resample_method="choice"), {}),
+])
+def test_tracker_api_variants_reproduce_reference(golden, name, tracker_kw, track_kw):
+    """return_covariances (tracker.py:307-308, :352) and resample_method='stratified' / 'choice'
+    (tracker.py:178-186, :205-209) against reference runs with the same seed."""
+    g = golden(name)
+    tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128, **tracker_kw)
+    np.random.seed(int(g["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models_from(g), tile_size=tuple(int(v) for v in g["tile_size"]),
+                               return_particles=True, **track_kw)
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8)
+    if track_kw.get("return_covariances"):
+        assert tracks.sigmas is None and tracks.covariances.shape == g["out_sigmas"].shape
+        np.testing.assert_allclose(tracks.covariances, g["out_sigmas"], rtol=RTOL, atol=1e-9)
+        # the device reduction itself, against NumPy on the device's own particles
+        want = np.cov(tracks.particles[0, -1].T, aweights=tracks.weights[0, -1], ddof=0)
+        np.testing.assert_allclose(tracks.covariances[0, -1], want, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(tracks.xyz_sigma, np.sqrt(g["out_sigmas"][:, :, (0, 1, 2), (0, 1, 2)]), rtol=RTOL)
+    else:
+        np.testing.assert_allclose(tracks.sigmas, g["out_sigmas"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.particles, g["out_particles"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.weights, g["out_weights"], rtol=RTOL, atol=1e-290)
+
+
+def test_single_track_covariance_and_resample_methods(golden):
+    """Tracker.particle_covariance and resample_particles(method) on explicit populations (g5 fixtures)."""
+    g5 = golden("g5_resample.npz")
+    g = golden("g8_c1.npz")
+    tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128)
+    for i in (2, 3, 4):  # n = 100, 129, 1000
+        particles, weights = g5[f"r{i}_particles"], g5[f"r{i}_weights"]
+        # covariance of the reference's systematic resample output
+        tracker.particles = g5[f"r{i}_out_particles"].copy()
+        tracker.weights = g5[f"r{i}_out_weights"].copy()
+        np.testing.assert_allclose(tracker.particle_covariance, g5[f"r{i}_cov"], rtol=1e-9, atol=1e-18)
+        # stratified: same uniforms as the reference -> same indices
+        tracker.particles, tracker.weights = particles.copy(), weights.copy()
+        np.random.seed(1000 + i)
+        tracker.resample_particles(method="stratified")
+        idx = g5[f"r{i}_strat_idx"]
+        np.testing.assert_array_equal(tracker.particles, particles[idx])
+        np.testing.assert_array_equal(tracker.weights, weights[idx])
+        # choice: against NumPy's own RandomState.choice from the same state
+        tracker.particles, tracker.weights = particles.copy(), weights.copy()
+        np.random.seed(2000 + i)
+        tracker.resample_particles(method="choice")
+        np.random.seed(2000 + i)
+        p = weights / weights.sum()
+        want = np.random.choice(np.arange(len(p)), size=(len(p),), replace=True, p=p)
+        np.testing.assert_array_equal(tracker.particles, particles[want])
+    with pytest.raises(NotImplementedError):
+        tracker.resample_particles(method="residual")

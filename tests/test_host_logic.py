@@ -124,3 +124,32 @@ def test_tracks_container():
     valid, first, last = tr.endpoints
     assert list(valid) == [True, False] and list(first) == [1] and list(last) == [2]
     assert list(tr.success) == [True, False]
+
+
+def test_tracks_merge_average_reverse_match_reference(golden):
+    """Tracks.from_multiple / average / reverse (tracks.py:131-213) against the reference's outputs."""
+    import datetime
+
+    from glimpse_amd import Tracks
+
+    g = golden("g10_tracks.npz")
+    t0, day = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    dts = [t0 + i * day for i in range(g["run0_means"].shape[1])]
+    runs = [Tracks(datetimes=dts, time_unit=day, means=g[f"run{r}_means"].copy(), sigmas=g[f"run{r}_sigmas"].copy())
+            for r in range(3)]
+    for flag in (0, 1):
+        merged = Tracks.from_multiple(runs, ignore_nan=bool(flag))
+        np.testing.assert_allclose(merged.means, g[f"merged_means_{flag}"], rtol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(merged.sigmas, g[f"merged_sigmas_{flag}"], rtol=1e-13, equal_nan=True)
+        m, s = merged.average(ignore_nan=bool(flag))
+        np.testing.assert_allclose(m, g[f"merged_avg_means_{flag}"], rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(s, g[f"merged_avg_sigmas_{flag}"], rtol=1e-12, equal_nan=True)
+        m, s = runs[0].average(ignore_nan=bool(flag))
+        np.testing.assert_allclose(m, g[f"run0_avg_means_{flag}"], rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(s, g[f"run0_avg_sigmas_{flag}"], rtol=1e-12, equal_nan=True)
+    runs[0].reverse()
+    np.testing.assert_array_equal(runs[0].means, g["rev_means"])
+    assert [(d - t0).days for d in runs[0].datetimes] == list(g["rev_days"])
+    other = Tracks(datetimes=dts[1:], time_unit=day, means=g["run1_means"][:, 1:], sigmas=g["run1_sigmas"][:, 1:])
+    with pytest.raises(ValueError):
+        Tracks.from_multiple([runs[1], other])

@@ -193,3 +193,18 @@ def test_ssd_c_matches_numpy():
         s = rng.standard_normal((hs, ws)).astype(np.float32)
         t = rng.standard_normal((th, tw)).astype(np.float32)
         np.testing.assert_array_equal(ssd.match_template_sqdiff(s, t), ssd.match_template_sqdiff_numpy(s, t))
+
+
+@pytest.mark.parametrize("name,kw", [("g9_cov.npz", dict(return_covariances=True)),
+                                     ("g9_stratified.npz", dict(resample_method="stratified")),
+                                     ("g9_choice.npz", dict(resample_method="choice"))])
+def test_api_variants_match_reference(golden, name, kw):
+    """Covariance output and the stratified / choice resampling methods, end to end with the oracle
+    consuming the legacy global stream from the reference's seed."""
+
+    g = golden(name)
+    np.random.seed(int(g["seed"]))
+    res = tracker.track(models_from(g), observers_from(g), g["matching"], taus_from(g),
+                         tile_size=tuple(int(v) for v in g["tile_size"]), **kw)
+    np.testing.assert_allclose(res["means"], g["means"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["sigmas"], g["out_sigmas"], rtol=1e-9, atol=1e-14)

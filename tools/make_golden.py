@@ -354,7 +354,7 @@ class Recorder:
 
 
 def run_e2e(name, cams_per_obs, frames_per_obs, sigmas, models_kw, tile_size, seed, maxdt_days=0.0,
-            obs_day_offsets=None, observer_mask=None, return_covariances=False):
+            obs_day_offsets=None, observer_mask=None, return_covariances=False, resample_method="systematic"):
     """Run reference Tracker.track and save everything needed to replay it."""
     day = datetime.timedelta(days=1)
     t0 = datetime.datetime(2020, 1, 1)
@@ -365,7 +365,7 @@ def run_e2e(name, cams_per_obs, frames_per_obs, sigmas, models_kw, tile_size, se
         imgs = [ref_image(frames_per_obs[o][i], cams_per_obs[o][i], t0 + float(offs[i]) * day)
                 for i in range(len(frames_per_obs[o]))]
         observers.append(glimpse.Observer(imgs, sigma=sigmas[o]))
-    tracker = glimpse.Tracker(observers)
+    tracker = glimpse.Tracker(observers, resample_method=resample_method)
     models = [glimpse.CartesianMotion(time_unit=day, **kw) for kw in models_kw]
     np.random.seed(seed)
     with warnings.catch_warnings():
@@ -405,7 +405,11 @@ def run_e2e(name, cams_per_obs, frames_per_obs, sigmas, models_kw, tile_size, se
     out["n_randn"] = len(rec.randn)
     for i, r in enumerate(rec.randn):
         out[f"randn{i}"] = r
-    out["random"] = np.array([float(r) for r in rec.random])
+    if all(np.size(r) == 1 for r in rec.random):
+        out["random"] = np.array([float(r) for r in rec.random])
+    else:  # stratified resampling draws random(n) per step
+        out["random_n"] = np.stack([np.asarray(r, dtype=float) for r in rec.random])
+    out["resample_method"] = resample_method
     # per-step traces; steps are grouped per track in order
     out["track_starts"] = np.array(rec.track_starts)
     out["n_steps"] = len(rec.steps)
@@ -471,7 +475,72 @@ def g8_c5mini():
     print("c5mini v:", tr.means[:, -1, 3:6], "sz:", tr.sigmas[:, -1, 2])
 
 
+def g9_variants():
+    """Small end-to-end runs of the API variants that the g8 files do not cover: covariance output
+    (return_covariances=True) and the stratified / choice resampling methods."""
+    cam = synth.nadir_camera((192, 192), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 4, seed=21, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam, 2, border_px=70.0, seed=4)
+    kws = [dict(xy=tuple(p), dem=0.0, dem_sigma=0.3, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                vxyz_sigma=(0.2, 0.2, 0.02), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01)) for p in pts]
+    args = ([[cam] * 4], [frames], [0.3], kws, (15, 15))
+    tr = run_e2e("g9_cov.npz", *args, seed=51, return_covariances=True)
+    print("g9_cov:", tr.covariances.shape)
+    tr = run_e2e("g9_stratified.npz", *args, seed=52, resample_method="stratified")
+    print("g9_stratified vx:", tr.means[:, -1, 3])
+    tr = run_e2e("g9_choice.npz", *args, seed=53, resample_method="choice")
+    print("g9_choice vx:", tr.means[:, -1, 3])
+
+
+def g10_tracks():
+    """Tracks.reverse / from_multiple / average (tracks.py:131-213) on synthetic result arrays with
+    missing rows, e.g. merging a forward and a backward run."""
+    rng = np.random.default_rng(77)
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    P, T = 5, 7
+    dts = [t0 + i * day for i in range(T)]
+    out = {}
+    runs = []
+    for r in range(3):
+        means = rng.standard_normal((P, T, 6)) * [1, 1, 0.1, 0.2, 0.2, 0.01] + [10, 20, 5, 0.1, 0, 0]
+        sigmas = rng.uniform(0.05, 0.5, (P, T, 6))
+        if r == 0:
+            means[1, :2] = np.nan; sigmas[1, :2] = np.nan
+        if r == 1:
+            means[1, 1:4] = np.nan; sigmas[1, 1:4] = np.nan
+            means[3] = np.nan; sigmas[3] = np.nan
+        if r == 2:
+            means[3] = np.nan; sigmas[3] = np.nan
+            means[4, -1] = np.nan; sigmas[4, -1] = np.nan
+        if r != 2:
+            pass
+        out[f"run{r}_means"], out[f"run{r}_sigmas"] = means, sigmas
+        runs.append(glimpse.Tracks(datetimes=dts, time_unit=day, means=means.copy(), sigmas=sigmas.copy()))
+    # runs 0 and 1 have rows that are all-NaN in both for track 3? make track 3 NaN in run 0 too
+    for flag in (False, True):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            merged = glimpse.Tracks.from_multiple(runs, ignore_nan=flag)
+            am, asd = merged.average(ignore_nan=flag)
+            bm, bsd = runs[0].average(ignore_nan=flag)
+        out[f"merged_means_{int(flag)}"], out[f"merged_sigmas_{int(flag)}"] = merged.means, merged.sigmas
+        out[f"merged_avg_means_{int(flag)}"], out[f"merged_avg_sigmas_{int(flag)}"] = am, asd
+        out[f"run0_avg_means_{int(flag)}"], out[f"run0_avg_sigmas_{int(flag)}"] = bm, bsd
+    rev = glimpse.Tracks(datetimes=dts, time_unit=day, means=out["run0_means"].copy(), sigmas=out["run0_sigmas"].copy())
+    rev.reverse()
+    out["rev_means"] = rev.means
+    out["rev_days"] = np.array([(d - t0).days for d in rev.datetimes])
+    np.savez_compressed(os.path.join(OUT, "g10_tracks.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g10" in sys.argv:
+        g10_tracks()
+        sys.exit(0)
+    if "--g9" in sys.argv:
+        g9_variants()
+        sys.exit(0)
     g1_projection()
     g2_tiles()
     g4_spline()
@@ -480,5 +549,7 @@ if __name__ == "__main__":
     g8_c1()
     g8_c2mini()
     g8_c5mini()
+    g9_variants()
+    g10_tracks()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
