@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("GLH_LIB") or os.path.join(HERE, "lib", "libglimpse_hi
 
 CAM_LEN = 24
 MOTION_LEN = 18
+MOTION_FULL_LEN = 24
+MOTION_KINDS = {"cartesian": 0, "cylindrical": 1, "tangent_cartesian": 2, "tangent_cylindrical": 3}
 RNG_HOST, RNG_PHILOX = 0, 1
 RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2}
 OK = 0
@@ -60,6 +62,7 @@ SIGNATURES = {
     "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
     "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
     "glh_set_motion_cartesian": (_I, [_P, _P]),
+    "glh_set_motion": (_I, [_P, _P]),
     "glh_set_point_offset": (_I, [_P, _I]),
     "glh_set_observer_mask": (_I, [_P, _P]),
     "glh_set_active": (_I, [_P, _P]),
@@ -209,6 +212,11 @@ class Context:
     def set_motion_cartesian(self, params):
         params = _arr(params, np.float64, (self.P, MOTION_LEN))
         check(self.lib.glh_set_motion_cartesian(self.handle, _ptr(params)))
+
+    def set_motion(self, params):
+        """Any mix of motion models: [P][MOTION_FULL_LEN] (include/glimpse_hip.h)."""
+        params = _arr(params, np.float64, (self.P, MOTION_FULL_LEN))
+        check(self.lib.glh_set_motion(self.handle, _ptr(params)))
 
     def set_observer_mask(self, mask):
         m = None if mask is None else _arr(mask, np.uint8, (self.P, self.O))

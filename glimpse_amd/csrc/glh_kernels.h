@@ -109,15 +109,93 @@ __device__ __forceinline__ void evolve_noise(int rng_mode, const double* normals
   }
 }
 
-// CartesianMotion.evolve_particles (motion.py:165-179) for one particle p[6], tau2 = tau * tau
-__device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
-                                                double tau2) {
+// Motion.initialize_particles for one particle from its six normals n = randn(n,2) | randn(n) |
+// randn(n,3) (the tangent models draw randn(n,2) last and leave vz = 0):
+// motion.py:149-163, :262-286, :382-394, :470-488.  m = [GLH_MOTION_FULL_LEN] parameters.
+__device__ __forceinline__ void init_particle(const double* m, const double* n, double* p) {
+  const int kind = (int)m[18];
+  p[0] = m[0] + m[2] * n[0];
+  p[1] = m[1] + m[3] * n[1];
+  if (kind == GLH_MOTION_CARTESIAN || kind == GLH_MOTION_CYLINDRICAL) {
+    double z = m[16];
+    z += m[17] * n[2];
+    p[2] = z;
+  } else {
+    const double z_off = m[17] * n[2];
+    p[2] = m[16] + z_off;
+  }
+  if (kind == GLH_MOTION_CARTESIAN) {
+    p[3] = m[4] + m[7] * n[3];
+    p[4] = m[5] + m[8] * n[4];
+    p[5] = m[6] + m[9] * n[5];
+  } else if (kind == GLH_MOTION_CYLINDRICAL) {
+    const double vr = m[4] + m[7] * n[3], th = m[5] + m[8] * n[4];
+    p[3] = vr * cos(th);
+    p[4] = vr * sin(th);
+    p[5] = m[6] + m[9] * n[5];
+  } else if (kind == GLH_MOTION_TANGENT_CARTESIAN) {
+    p[3] = m[4] + m[7] * n[3];
+    p[4] = m[5] + m[8] * n[4];
+    p[5] = 0.0;
+  } else {
+    const double vr = m[4] + m[7] * n[3], th = m[5] + m[8] * n[4];
+    p[3] = vr * cos(th);
+    p[4] = vr * sin(th);
+    p[5] = 0.0;
+  }
+}
+
+// Motion.evolve_particles for one particle p[6], tau2 = tau * tau, n = the step's three normals
+// (randn(n,3); the tangent models draw randn(n,2) then randn(n)):
+// motion.py:165-179, :288-311, :396-412, :490-522.
+__device__ __forceinline__ void evolve_cartesian(double* p, const double* m, const double* n, double tau,
+                                                 double tau2) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     double acc = m[10 + k] + m[13 + k] * n[k];
     p[k] += tau * p[3 + k] + 0.5 * acc * tau2;
     p[3 + k] += tau * acc;
   }
+}
+__device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
+                                                double tau2) {
+  const int kind = (int)m[18];
+  if (kind == GLH_MOTION_CARTESIAN) {
+    evolve_cartesian(p, m, n, tau, tau2);
+    return;
+  }
+  const bool cyl = kind == GLH_MOTION_CYLINDRICAL || kind == GLH_MOTION_TANGENT_CYLINDRICAL;
+  const bool tangent = kind >= GLH_MOTION_TANGENT_CARTESIAN;
+  double a[3];
+  a[0] = m[10] + m[13] * n[0];
+  a[1] = m[11] + m[14] * n[1];
+  a[2] = tangent ? 0.0 : m[12] + m[15] * n[2];
+  if (cyl) {
+    // (r'', theta') -> (x'', y''): r'' * cos(th) - r' * sin(th) * th',  r'' * sin(th) + r' * cos(th) * th'
+    const double vx = p[3], vy = p[4];
+    const double vr = sqrt(vx * vx + vy * vy);
+    const double ar = a[0], ath = a[1];
+    a[0] = ar * (vx / vr) - vy * ath;
+    a[1] = ar * (vy / vr) + vx * ath;
+  }
+  if (!tangent) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] += tau * p[3 + k] + 0.5 * a[k] * tau2;
+      p[3 + k] += tau * a[k];
+    }
+    return;
+  }
+  // tangent models: the height follows the (constant) surface plus a random walk of the offset
+  const double dx = tau * p[3] + 0.5 * a[0] * tau2;
+  const double dy = tau * p[4] + 0.5 * a[1] * tau2;
+  double z_off = p[2] - m[16];
+  z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
+  p[0] += dx;
+  p[1] += dy;
+  p[2] = m[16] + z_off;
+  p[3] += tau * a[0];
+  p[4] += tau * a[1];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,7 +216,7 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
   if (a.active && !a.active[pt]) return;
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= a.N) return;
-  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+  const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
   double n[6];
   if (a.rng_mode == GLH_RNG_HOST) {
     const double* src = a.normals + ((size_t)pt * a.N + i) * 6;
@@ -151,14 +229,7 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
     philox_normals2(a.seed, i, gp, 2u, 0x494e4954u, n[4], n[5]);
   }
   double* p = a.particles + ((size_t)pt * a.N + i) * 6;
-  p[0] = m[0] + m[2] * n[0];
-  p[1] = m[1] + m[3] * n[1];
-  double z = m[16];
-  z += m[17] * n[2];
-  p[2] = z;
-  p[3] = m[4] + m[7] * n[3];
-  p[4] = m[5] + m[8] * n[4];
-  p[5] = m[6] + m[9] * n[5];
+  init_particle(m, n, p);
   a.weights[(size_t)pt * a.N + i] = 1.0;
 }
 
@@ -197,7 +268,7 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
     double2 v0 = src[0], v1 = src[1], v2 = src[2];
     p[0] = v0.x; p[1] = v0.y; p[2] = v1.x; p[3] = v1.y; p[4] = v2.x; p[5] = v2.y;
     if (a.do_evolve) {
-      const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
+      const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
       double n[3];
       evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, a.N, n);
       evolve_particle(p, m, n, a.tau, a.tau * a.tau);
@@ -1002,9 +1073,14 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   if (a.active && !a.active[pt]) return;
   for (int k = threadIdx.x; k < 16 * GLH_NPOLY; k += BLK) tab[k] = a.poly[k];
   __syncthreads();
-  const double* m = a.motion + (size_t)pt * GLH_MOTION_LEN;
-  const double zs = m[17];
+  const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
+  const bool has_motion_term = (int)m[18] <= GLH_MOTION_CYLINDRICAL;  // tangent models return None
+  const double zs = has_motion_term ? m[17] : 0.0;
   const double dem_scale = zs != 0.0 ? 1.0 / (2.0 * (zs * zs)) : 0.0;
+  bool any_obs = false;  // uniform across the block
+  for (int o = 0; o < a.O; ++o)
+    any_obs |= a.on[o] && a.obs_status[(size_t)o * a.P + pt] == GLH_OBS_OK;
+  if (!has_motion_term && !any_obs && !a.ll_out) return;  // every term is None: weights unchanged (tracker.py:146)
   for (int it = 0; it < WEIGHTS_PER_THREAD; ++it) {
     const int i = (blockIdx.x * WEIGHTS_PER_THREAD + it) * BLK + threadIdx.x;
     if (i >= a.N) break;
@@ -1031,7 +1107,7 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       double d = m[16] - z;
       ll += dem_scale * (d * d);
     }
-    a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
+    if (has_motion_term || any_obs) a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
   }
 }
 

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ int s_box[NOBS][4];
   __shared__ int s_status[NOBS];
   __shared__ CamDev s_cam[NOBS];           // cameras: LDS broadcast reads instead of ~60 live SGPRs each
-  __shared__ double s_m[GLH_MOTION_LEN];  // this point's motion parameters: the loops below store to global
+  __shared__ double s_m[GLH_MOTION_FULL_LEN];  // this point's motion parameters: the loops below store to global
                                           // memory, so reading them through a global pointer would reload
                                           // (and wait for) them on every iteration
   const int pt = blockIdx.x, tid = threadIdx.x;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 
   PT_STAMP(0);
   for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
-  if (tid < GLH_MOTION_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_LEN + tid];
+  if (tid < GLH_MOTION_FULL_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_FULL_LEN + tid];
   {
     static_assert(sizeof(CamDev) % 8 == 0, "CamDev is copied as doubles");
     constexpr int CW = sizeof(CamDev) / 8;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
-    evolve_particle(x, m, n, tau, tau2);
+    evolve_cartesian(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
   };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       if (i < N) {
         double n[3];
         evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
-        evolve_particle(x, m, n, tau, tau2);
+        evolve_cartesian(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
         if (a.has_dem) {

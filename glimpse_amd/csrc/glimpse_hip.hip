@@ -93,6 +93,7 @@ struct glh_ctx {
   bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false, has_dem = false;
   int fused = 1;    // glh_step: 0 staged kernels, 1 fused per-point kernel, 2 fused with tiles forced to HBM (test)
   int pt_base = 0;  // global index of this context's point 0
+  bool all_cartesian = true;  // every point is CartesianMotion (what the fused kernel evolves)
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
@@ -270,7 +271,7 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     A(dalloc(&c->particles[i], P * N * 6));
     A(dalloc(&c->weights[i], P * N));
   }
-  A(dalloc(&c->motion, P * GLH_MOTION_LEN));
+  A(dalloc(&c->motion, P * GLH_MOTION_FULL_LEN));
   A(dalloc(&c->uv, O * P * N * 2));
   A(dalloc(&c->bbox_part, O * P * NBmax * 5));
   A(dalloc(&c->u, P));
@@ -512,14 +513,31 @@ static int need_seq(glh_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
 
+extern "C" int glh_set_motion(glh_ctx* c, const double* params) {
+  CHK(need_seq(c));
+  if (!params) return fail(GLH_E_INVALID, "params is null");
+  c->has_dem = false;
+  c->all_cartesian = true;
+  for (int p = 0; p < c->P; ++p) {
+    const double* m = params + (size_t)p * GLH_MOTION_FULL_LEN;
+    const int kind = (int)m[18];
+    if (m[18] != (double)kind || kind < GLH_MOTION_CARTESIAN || kind > GLH_MOTION_TANGENT_CYLINDRICAL)
+      return fail(GLH_E_INVALID, "point %d: unknown motion kind %g", p, m[18]);
+    if (kind != GLH_MOTION_CARTESIAN) c->all_cartesian = false;
+    if (kind <= GLH_MOTION_CYLINDRICAL && m[17] != 0.0) c->has_dem = true;
+  }
+  UPLOAD(c->motion, params, (size_t)c->P * GLH_MOTION_FULL_LEN, double);
+  return GLH_OK;
+}
+
 extern "C" int glh_set_motion_cartesian(glh_ctx* c, const double* params) {
   CHK(need_seq(c));
   if (!params) return fail(GLH_E_INVALID, "params is null");
-  UPLOAD(c->motion, params, (size_t)c->P * GLH_MOTION_LEN, double);
-  c->has_dem = false;
+  std::vector<double> full((size_t)c->P * GLH_MOTION_FULL_LEN, 0.0);
   for (int p = 0; p < c->P; ++p)
-    if (params[(size_t)p * GLH_MOTION_LEN + 17] != 0.0) c->has_dem = true;
-  return GLH_OK;
+    std::copy(params + (size_t)p * GLH_MOTION_LEN, params + (size_t)(p + 1) * GLH_MOTION_LEN,
+              full.begin() + (size_t)p * GLH_MOTION_FULL_LEN);
+  return glh_set_motion(c, full.data());
 }
 extern "C" int glh_set_point_offset(glh_ctx* c, int offset) {
   CHK(need_seq(c));
@@ -989,7 +1007,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
 
 static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   const int O = c->cfg.n_observers;
-  if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
+  if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE || !c->all_cartesian) return false;
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {

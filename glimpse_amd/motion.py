@@ -1,11 +1,11 @@
 """Motion models (/root/reference/src/glimpse/track/motion.py).
 
-`CartesianMotion` (motion.py:92-204) is the model the GPU path implements natively: the
-Tracker reads its parameters and evolves the particles on the device.  Its methods are kept
-as host NumPy conveniences with the reference's semantics (legacy `np.random` draws in the
-same order) for users who call them directly; the Tracker does not use them.  The other
-models of the reference (Cylindrical, Tangent*) need gridded DEMs and are listed as "next"
-(SURVEY.md 8(f) rank 1).
+`CartesianMotion` (motion.py:92-204), `CylindricalMotion` (:207-311), `TangentCartesianMotion`
+(:314-412) and `TangentCylindricalMotion` (:415-522) with constant (scalar) `dem` / `dem_sigma`
+surfaces: the Tracker reads their parameters (`params_full`) and initialises / evolves the
+particles on the device.  Their methods are kept as host NumPy conveniences with the
+reference's semantics (legacy `np.random` draws in the same order) for users who call them
+directly; the Tracker does not use them.  Gridded DEM rasters are "next" (SURVEY.md 8(f) rank 1).
 """
 import numpy as np
 
@@ -39,6 +39,14 @@ class CartesianMotion(Motion):
         self.axyz = axyz
         self.axyz_sigma = axyz_sigma
 
+    KIND = 0          # GLH_MOTION_CARTESIAN
+    N_INIT_V = 3      # velocity normals drawn by initialize_particles: randn(n, 3)
+    TANGENT = False   # evolve draws randn(n, 3) (False) or randn(n, 2) then randn(n) (True)
+
+    def params_full(self):
+        """GLH_MOTION_FULL_LEN doubles (include/glimpse_hip.h): params() | kind | slope_sigma | 0 0 0 0."""
+        return np.concatenate((self.params(), [self.KIND, getattr(self, "slope_sigma", 0.0), 0, 0, 0, 0]))
+
     def params(self):
         """GLH_MOTION_LEN doubles (include/glimpse_hip.h)."""
         def v(x, n):
@@ -69,3 +77,135 @@ class CartesianMotion(Motion):
         if self.dem_sigma != 0:
             ll[:] = 1 / (2 * self.dem_sigma ** 2) * (self.dem - particles[:, 2]) ** 2
         return ll
+
+
+def _scalar_surface(dem, dem_sigma, cls):
+    if not np.isscalar(dem) or dem_sigma is None or not np.isscalar(dem_sigma):
+        raise NotImplementedError(f"{cls} needs scalar dem and dem_sigma on the GPU path")
+    return float(dem), float(dem_sigma)
+
+
+def _v(x, n):
+    return np.broadcast_to(np.asarray(x, dtype=float), (n,)).astype(float)
+
+
+class CylindricalMotion(CartesianMotion):
+    """motion.py:207-311: like CartesianMotion with velocity / acceleration given as (radius rate,
+    direction theta in radians, dz/dt)."""
+
+    KIND = 1
+
+    def __init__(self, xy, time_unit, dem, dem_sigma=None, n=1000, xy_sigma=(0, 0), vrthz=(0, 0, 0),
+                 vrthz_sigma=(0, 0, 0), arthz=(0, 0, 0), arthz_sigma=(0, 0, 0)):
+        self.dem, self.dem_sigma = _scalar_surface(dem, dem_sigma, "CylindricalMotion")
+        self.xy, self.time_unit, self.n, self.xy_sigma = xy, time_unit, int(n), xy_sigma
+        self.vrthz, self.vrthz_sigma, self.arthz, self.arthz_sigma = vrthz, vrthz_sigma, arthz, arthz_sigma
+
+    def params(self):
+        return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(self.vrthz, 3), _v(self.vrthz_sigma, 3),
+                               _v(self.arthz, 3), _v(self.arthz_sigma, 3), [self.dem, self.dem_sigma]))
+
+    def initialize_particles(self):
+        """motion.py:262-286."""
+        particles = np.zeros((self.n, 6), dtype=float)
+        particles[:, 0:2] = self.xy + self.xy_sigma * np.random.randn(self.n, 2)
+        particles[:, 2] = self.dem
+        particles[:, 2] += self.dem_sigma * np.random.randn(self.n)
+        v = self.vrthz + self.vrthz_sigma * np.random.randn(self.n, 3)
+        particles[:, 3:6] = np.column_stack((v[:, 0] * np.cos(v[:, 1]), v[:, 0] * np.sin(v[:, 1]), v[:, 2]))
+        return particles
+
+    def evolve_particles(self, particles, dt):
+        """motion.py:288-311 (in place)."""
+        n = len(particles)
+        time_units = dt.total_seconds() / self.time_unit.total_seconds()
+        vx, vy = particles[:, 3], particles[:, 4]
+        vr = np.sqrt(vx ** 2 + vy ** 2)
+        arthz = self.arthz + self.arthz_sigma * np.random.randn(n, 3)
+        axyz = np.column_stack((arthz[:, 0] * (vx / vr) - vy * arthz[:, 1],
+                                arthz[:, 0] * (vy / vr) + vx * arthz[:, 1], arthz[:, 2]))
+        particles[:, 0:3] += time_units * particles[:, 3:6] + 0.5 * axyz * time_units ** 2
+        particles[:, 3:6] += time_units * axyz
+
+
+class TangentCartesianMotion(Motion):
+    """motion.py:314-412: particles move tangent to the mean surface; their height keeps its offset
+    from the surface plus a random walk ~ slope_sigma * horizontal distance.  No log likelihood of
+    its own (Motion.compute_log_likelihoods returns None, motion.py:76-89)."""
+
+    KIND = 2
+    N_INIT_V = 2
+    TANGENT = True
+
+    def __init__(self, xy, time_unit, dem, dem_sigma=0, n=1000, xy_sigma=(0, 0), vxy=(0, 0), vxy_sigma=(0, 0),
+                 axy=(0, 0), axy_sigma=(0, 0), slope_sigma=0):
+        self.dem, self.dem_sigma = _scalar_surface(dem, dem_sigma, type(self).__name__)
+        self.xy, self.time_unit, self.n, self.xy_sigma = xy, time_unit, int(n), xy_sigma
+        self.vxy, self.vxy_sigma, self.axy, self.axy_sigma = vxy, vxy_sigma, axy, axy_sigma
+        self.slope_sigma = float(slope_sigma)
+
+    def _v4(self):
+        return self.vxy, self.vxy_sigma, self.axy, self.axy_sigma
+
+    def params(self):
+        v, vs, a, as_ = self._v4()
+        z = [0.0]
+        return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(v, 2), z, _v(vs, 2), z, _v(a, 2), z,
+                               _v(as_, 2), z, [self.dem, self.dem_sigma]))
+
+    def params_full(self):
+        return np.concatenate((self.params(), [self.KIND, self.slope_sigma, 0, 0, 0, 0]))
+
+    def _initial_velocity(self, normals):
+        return self.vxy + self.vxy_sigma * normals
+
+    def _acceleration(self, particles, normals):
+        return self.axy + self.axy_sigma * normals
+
+    def initialize_particles(self):
+        """motion.py:382-394 / :470-488."""
+        particles = np.zeros((self.n, 6), dtype=float)
+        particles[:, 0:2] = self.xy + self.xy_sigma * np.random.randn(self.n, 2)
+        z_offsets = self.dem_sigma * np.random.randn(self.n)
+        particles[:, 2] = self.dem + z_offsets
+        particles[:, 3:5] = self._initial_velocity(np.random.randn(self.n, 2))
+        return particles
+
+    def evolve_particles(self, particles, dt):
+        """motion.py:396-412 / :490-522 (in place)."""
+        n = len(particles)
+        time_units = dt.total_seconds() / self.time_unit.total_seconds()
+        axy = self._acceleration(particles, np.random.randn(n, 2))
+        dxy = time_units * particles[:, 3:5] + 0.5 * axy * time_units ** 2
+        z_offsets = particles[:, 2] - self.dem
+        z_offsets += self.slope_sigma * np.random.randn(n) * (dxy ** 2).sum(axis=1) ** 0.5
+        particles[:, 0:2] += dxy
+        particles[:, 2] = self.dem + z_offsets
+        particles[:, 3:5] += time_units * axy
+
+    def compute_log_likelihoods(self, particles):
+        return None
+
+
+class TangentCylindricalMotion(TangentCartesianMotion):
+    """motion.py:415-522: TangentCartesianMotion with velocity / acceleration as (radius rate, theta)."""
+
+    KIND = 3
+
+    def __init__(self, xy, time_unit, dem, dem_sigma=0, n=1000, xy_sigma=(0, 0), vrth=(0, 0), vrth_sigma=(0, 0),
+                 arth=(0, 0), arth_sigma=(0, 0), slope_sigma=0):
+        super().__init__(xy, time_unit, dem, dem_sigma, n, xy_sigma, slope_sigma=slope_sigma)
+        self.vrth, self.vrth_sigma, self.arth, self.arth_sigma = vrth, vrth_sigma, arth, arth_sigma
+
+    def _v4(self):
+        return self.vrth, self.vrth_sigma, self.arth, self.arth_sigma
+
+    def _initial_velocity(self, normals):
+        vrth = self.vrth + self.vrth_sigma * normals
+        return np.column_stack((vrth[:, 0] * np.cos(vrth[:, 1]), vrth[:, 0] * np.sin(vrth[:, 1])))
+
+    def _acceleration(self, particles, normals):
+        vx, vy = particles[:, 3], particles[:, 4]
+        vr = np.sqrt(vx ** 2 + vy ** 2)
+        arth = self.arth + self.arth_sigma * normals
+        return np.column_stack((arth[:, 0] * (vx / vr) - vy * arth[:, 1], arth[:, 0] * (vy / vr) + vx * arth[:, 1]))

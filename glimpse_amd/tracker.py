@@ -19,7 +19,7 @@ import warnings as _warnings
 import numpy as np
 
 from . import _lib
-from .motion import CartesianMotion
+from .motion import CartesianMotion, TangentCartesianMotion
 from .tracks import Tracks
 
 _ERRORS = (
@@ -154,8 +154,9 @@ class Tracker:
             if model.time_unit != time_unit:
                 raise ValueError("Motion models must have equal time units")
         for model in motion_models:
-            if not isinstance(model, CartesianMotion):
-                raise NotImplementedError(f"{type(model).__name__}: only CartesianMotion runs on the GPU path")
+            if not isinstance(model, (CartesianMotion, TangentCartesianMotion)):
+                raise NotImplementedError(f"{type(model).__name__}: the GPU path evolves Cartesian, Cylindrical, "
+                                          "TangentCartesian and TangentCylindrical motion models")
         self.reset()
         ntracks = len(motion_models)
         raise_errors = ntracks < 2
@@ -202,7 +203,7 @@ class Tracker:
         def run(draws):
             """The frame loop (tracker.py:326-357) for all tracks at once."""
             ctx.begin_sequence(ntracks, n, tile_size)
-            ctx.set_motion_cartesian(np.stack([m.params() for m in motion_models]))
+            ctx.set_motion(np.stack([m.params_full() for m in motion_models]))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
             ctx.set_point_offset(point_offset)
             for w in warn_log:
@@ -277,7 +278,8 @@ class Tracker:
             stops = np.stack((last, last), axis=1)
             for _ in range(ntracks + 1):
                 np.random.set_state(state0)
-                draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic)
+                draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic,
+                                         models=motion_models)
                 out_particles, out_weights, status, err_frame = run(draws)
                 new_stops = np.stack((last, last), axis=1)
                 for p in np.nonzero(status)[0]:
@@ -326,7 +328,7 @@ class Tracker:
         return tracks
 
     @staticmethod
-    def _draw_numpy(ntracks, n, first, last, stops, per_particle_u=False):
+    def _draw_numpy(ntracks, n, first, last, stops, per_particle_u=False, models=None):
         """Consume the legacy global stream exactly like the reference (one track after another):
         randn(n,2), randn(n), randn(n,3), then per step randn(n,3) and random() -- or random(n) for
         stratified resampling (tracker.py:182) and for np.random.choice, whose n uniforms come from the
@@ -342,12 +344,22 @@ class Tracker:
         for p in range(ntracks):
             if last[p] < first[p]:
                 continue
+            # tangent models draw randn(n,2) velocities and, per step, randn(n,2) then randn(n)
+            # (motion.py:393, :404-409); the others randn(n,3) (motion.py:161, :176)
+            tangent = models is not None and models[p].TANGENT
             init[p, :, 0:2] = np.random.randn(n, 2)
             init[p, :, 2] = np.random.randn(n)
-            init[p, :, 3:6] = np.random.randn(n, 3)
+            if tangent:
+                init[p, :, 3:5] = np.random.randn(n, 2)
+            else:
+                init[p, :, 3:6] = np.random.randn(n, 3)
             for i in range(first[p] + 1, last[p] + 1):
                 if i <= stops[p, 0]:
-                    evolve[i, p] = np.random.randn(n, 3)
+                    if tangent:
+                        evolve[i, p, :, 0:2] = np.random.randn(n, 2)
+                        evolve[i, p, :, 2] = np.random.randn(n)
+                    else:
+                        evolve[i, p] = np.random.randn(n, 3)
                 if i <= stops[p, 1]:
                     u[i, p] = np.random.random(n) if per_particle_u else np.random.random()
         return {"init": init, "evolve": evolve, "u": u}
@@ -433,10 +445,10 @@ class Tracker:
     def update_weights(self, imgs, motion_model=None):
         """tracker.py:126-149.  `motion_model` must be a CartesianMotion (its DEM term is added) or None."""
         ctx = self._single()
-        params = np.zeros((1, _lib.MOTION_LEN))
+        params = np.zeros((1, _lib.MOTION_FULL_LEN))
         if motion_model is not None:
-            params[0] = motion_model.params()
-        ctx.set_motion_cartesian(params)
+            params[0] = motion_model.params_full()
+        ctx.set_motion(params)
         for o, img in enumerate(imgs):
             if img is not None:
                 self._single_upload(ctx, o, img)

@@ -51,6 +51,20 @@ extern "C" {
  * [16] dem (constant surface) [17] dem_sigma (constant)                                   */
 #define GLH_MOTION_LEN 18
 
+/* ---- motion parameters, general form (glh_set_motion) -------------------------------- */
+/* [0:18] as above, read per model kind:
+ *   CARTESIAN            (motion.py:92-204)   vxyz, vxyz_sigma, axyz, axyz_sigma
+ *   CYLINDRICAL          (motion.py:207-311)  [4:7] vrthz [7:10] vrthz_sigma [10:13] arthz [13:16] arthz_sigma
+ *   TANGENT_CARTESIAN    (motion.py:314-412)  [4:6] vxy [7:9] vxy_sigma [10:12] axy [13:15] axy_sigma
+ *   TANGENT_CYLINDRICAL  (motion.py:415-522)  [4:6] vrth [7:9] vrth_sigma [10:12] arth [13:15] arth_sigma
+ * [18] kind (GLH_MOTION_*)  [19] slope_sigma (tangent models)  [20:24] reserved.
+ * dem / dem_sigma are constant surfaces (scalars) for every kind.                           */
+#define GLH_MOTION_FULL_LEN 24
+#define GLH_MOTION_CARTESIAN 0
+#define GLH_MOTION_CYLINDRICAL 1
+#define GLH_MOTION_TANGENT_CARTESIAN 2
+#define GLH_MOTION_TANGENT_CYLINDRICAL 3
+
 /* ---- per-point status bits (sticky; the Python Tracker turns them into Tracks.errors) */
 #define GLH_PT_NAN 1u            /* ValueError "missing (NaN) values"      tracker.py:118  */
 #define GLH_PT_TEMPLATE_OOB 2u   /* IndexError "Box extends beyond grid"   raster.py:417   */
@@ -117,6 +131,11 @@ int glh_observer_set_frame_device(glh_ctx* ctx, int obs, int image, const void* 
 int glh_begin_sequence(glh_ctx* ctx, int n_points, int n_particles, int tile_w, int tile_h);
 /* CartesianMotion parameters per point: [P][GLH_MOTION_LEN] (track/motion.py:121-147).     */
 int glh_set_motion_cartesian(glh_ctx* ctx, const double* params);
+/* Any mix of motion models, one per point: [P][GLH_MOTION_FULL_LEN].  The tangent models return
+ * no log likelihood (base Motion.compute_log_likelihoods, motion.py:76-89): a frame on which every
+ * observer is skipped leaves their weights unchanged (tracker.py:146-149).  Points that are not
+ * CartesianMotion run through the staged kernels.                                             */
+int glh_set_motion(glh_ctx* ctx, const double* params);
 /* Global index of this context's point 0 when the tracked points are sharded over several
  * contexts / GPUs (default 0).  The device RNG (GLH_RNG_PHILOX) is keyed on the GLOBAL point
  * index, so a sharded run draws exactly what the unsharded run draws.                        */

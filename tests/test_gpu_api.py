@@ -175,3 +175,61 @@ def test_single_track_covariance_and_resample_methods(golden):
         np.testing.assert_array_equal(tracker.particles, particles[want])
     with pytest.raises(NotImplementedError):
         tracker.resample_particles(method="residual")
+
+
+def test_other_motion_models_on_the_device(golden):
+    """Cylindrical / TangentCartesian / TangentCylindrical motion (motion.py:207-522) on the device:
+    initialise + evolve with the reference's recorded draws (C ABI), then whole tracks through
+    Tracker.track against reference runs with the same seed."""
+    import datetime
+
+    from glimpse_amd import _lib
+    from tests.test_host_logic import _api_models
+
+    g = golden("g11_motion.npz")
+    for name, model in _api_models(g).items():
+        draws = [g[f"{name}_draw{i}"] for i in range(int(g[f"{name}_n_draws"]))]
+        n = model.n
+        if name == "cyl":
+            init = np.column_stack((draws[0], draws[1], draws[2]))
+            ev = [draws[3], draws[4]]
+        else:
+            init = np.column_stack((draws[0], draws[1], draws[2], np.zeros(n)))
+            ev = [np.column_stack((draws[3], draws[4])), np.column_stack((draws[5], draws[6]))]
+        with _lib.Context(1, n, 1, max_search_dim=64, max_frames=2) as ctx:
+            ctx.observer_init(0, 1, 64, 64, 1, 0.3)
+            ctx.begin_sequence(1, n, (15, 15))
+            ctx.set_motion(model.params_full()[None])
+            ctx.init_particles(normals=init[None])
+            np.testing.assert_allclose(ctx.get_particles()[0], g[f"{name}_p0"], rtol=1e-13, atol=1e-14)
+            ctx.evolve(1.5, normals=ev[0][None])
+            np.testing.assert_allclose(ctx.get_particles()[0], g[f"{name}_p1"], rtol=1e-12, atol=1e-13)
+            ctx.evolve(-0.75, normals=ev[1][None])
+            np.testing.assert_allclose(ctx.get_particles()[0], g[f"{name}_p2"], rtol=1e-12, atol=1e-13)
+    e = golden("g11_motion_e2e.npz")
+    t0, day = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    from tests.helpers_api import camera_from
+
+    images = [glimpse_amd.Image("synthetic", cam=camera_from(e["cam"]), datetime=t0 + i * day, array=e["frames"][i])
+              for i in range(len(e["frames"]))]
+    models = {
+        "cyl": glimpse_amd.CylindricalMotion(xy=(0.5, -0.5), time_unit=day, dem=0.0, dem_sigma=0.3, n=150,
+                                             xy_sigma=(0.2, 0.2), vrthz=(0.15, 0.0, 0.0), vrthz_sigma=(0.1, 0.5, 0.02),
+                                             arthz=(0, 0, 0), arthz_sigma=(0.03, 0.2, 0.01)),
+        "tcart": glimpse_amd.TangentCartesianMotion(xy=(-1.0, 1.0), time_unit=day, dem=0.0, dem_sigma=0.2, n=150,
+                                                    xy_sigma=(0.2, 0.2), vxy=(0.15, 0.0), vxy_sigma=(0.2, 0.2),
+                                                    axy=(0, 0), axy_sigma=(0.05, 0.05), slope_sigma=0.1),
+        "tcyl": glimpse_amd.TangentCylindricalMotion(xy=(1.5, 0.5), time_unit=day, dem=0.0, dem_sigma=0.2, n=150,
+                                                     xy_sigma=(0.2, 0.2), vrth=(0.15, 0.0), vrth_sigma=(0.1, 0.5),
+                                                     arth=(0, 0), arth_sigma=(0.03, 0.2), slope_sigma=0.1),
+    }
+    for name, model in models.items():
+        tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+        np.random.seed(910)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track([model], tile_size=(15, 15), return_particles=True)
+        np.testing.assert_allclose(tracks.means, e[f"{name}_means"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.sigmas, e[f"{name}_sigmas"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.particles, e[f"{name}_particles"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.weights, e[f"{name}_weights"], rtol=RTOL, atol=1e-290)

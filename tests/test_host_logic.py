@@ -153,3 +153,39 @@ def test_tracks_merge_average_reverse_match_reference(golden):
     other = Tracks(datetimes=dts[1:], time_unit=day, means=g["run1_means"][:, 1:], sigmas=g["run1_sigmas"][:, 1:])
     with pytest.raises(ValueError):
         Tracks.from_multiple([runs[1], other])
+
+
+def _api_models(g, names=("cyl", "tcart", "tcyl")):
+    def kw(name):
+        return {k[len(name) + 4:]: g[k] for k in g if k.startswith(name + "_kw_")}
+
+    cls = {"cyl": glimpse_amd.CylindricalMotion, "tcart": glimpse_amd.TangentCartesianMotion,
+           "tcyl": glimpse_amd.TangentCylindricalMotion}
+    out = {}
+    for name in names:
+        k = kw(name)
+        k["n"] = int(k["n"])
+        for s in ("dem", "dem_sigma", "slope_sigma"):
+            if s in k:
+                k[s] = float(k[s])
+        out[name] = cls[name](time_unit=DAY, **k)
+    return out
+
+
+def test_other_motion_models_host_methods_match_reference(golden):
+    """CylindricalMotion / TangentCartesianMotion / TangentCylindricalMotion host methods consume the
+    legacy stream like the reference (motion.py:207-522)."""
+    g = golden("g11_motion.npz")
+    for name, model in _api_models(g).items():
+        np.random.seed(900)
+        p0 = model.initialize_particles()
+        np.testing.assert_allclose(p0, g[f"{name}_p0"], rtol=1e-14, atol=1e-15)
+        p1 = p0.copy()
+        model.evolve_particles(p1, dt=datetime.timedelta(days=1.5))
+        np.testing.assert_allclose(p1, g[f"{name}_p1"], rtol=1e-13, atol=1e-14)
+        p2 = p1.copy()
+        model.evolve_particles(p2, dt=datetime.timedelta(days=-0.75))
+        np.testing.assert_allclose(p2, g[f"{name}_p2"], rtol=1e-13, atol=1e-14)
+        ll = model.compute_log_likelihoods(p2)
+        assert (ll is not None) == bool(g[f"{name}_has_ll"])
+        assert model.params_full().shape == (24,) and model.params_full()[18] == model.KIND

@@ -208,3 +208,53 @@ def test_api_variants_match_reference(golden, name, kw):
                          tile_size=tuple(int(v) for v in g["tile_size"]), **kw)
     np.testing.assert_allclose(res["means"], g["means"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(res["sigmas"], g["out_sigmas"], rtol=1e-9, atol=1e-14)
+
+
+def _g11_models(g, module, day):
+    """The three g11 motion models built from `module` (oracle.motion or glimpse_amd)."""
+    def kw(name):
+        return {k[len(name) + 4:]: g[k] for k in g if k.startswith(name + "_kw_")}
+
+    c, t, y = kw("cyl"), kw("tcart"), kw("tcyl")
+    if module is motion:
+        return {
+            "cyl": motion.CylindricalMotion(xy=c["xy"], dem=c["dem"], dem_sigma=c["dem_sigma"], n=int(c["n"]),
+                                            xy_sigma=c["xy_sigma"], vxyz=c["vrthz"], vxyz_sigma=c["vrthz_sigma"],
+                                            axyz=c["arthz"], axyz_sigma=c["arthz_sigma"]),
+            "tcart": motion.TangentCartesianMotion(xy=t["xy"], dem=t["dem"], dem_sigma=t["dem_sigma"], n=int(t["n"]),
+                                                   xy_sigma=t["xy_sigma"], vxy=t["vxy"], vxy_sigma=t["vxy_sigma"],
+                                                   axy=t["axy"], axy_sigma=t["axy_sigma"], slope_sigma=t["slope_sigma"]),
+            "tcyl": motion.TangentCylindricalMotion(xy=y["xy"], dem=y["dem"], dem_sigma=y["dem_sigma"], n=int(y["n"]),
+                                                    xy_sigma=y["xy_sigma"], vxy=y["vrth"], vxy_sigma=y["vrth_sigma"],
+                                                    axy=y["arth"], axy_sigma=y["arth_sigma"],
+                                                    slope_sigma=y["slope_sigma"]),
+        }
+    raise ValueError(module)
+
+
+def test_other_motion_models_match_reference(golden):
+    """Cylindrical / TangentCartesian / TangentCylindrical (motion.py:207-522): init + two evolves with the
+    reference's recorded draws."""
+    g = golden("g11_motion.npz")
+    models = _g11_models(g, motion, 1.0)
+    for name, model in models.items():
+        draws = [g[f"{name}_draw{i}"] for i in range(int(g[f"{name}_n_draws"]))]
+        n = model.n
+        if name == "cyl":
+            init = np.column_stack((draws[0], draws[1], draws[2]))
+            ev = [draws[3], draws[4]]
+        else:
+            init = np.column_stack((draws[0], draws[1], draws[2], np.zeros(n)))
+            ev = [np.column_stack((draws[3], draws[4])), np.column_stack((draws[5], draws[6]))]
+        p0, _ = model.initialize_particles(init)
+        np.testing.assert_allclose(p0, g[f"{name}_p0"], rtol=1e-14, atol=1e-15)
+        p1 = p0.copy()
+        model.evolve_particles(p1, 1.5, ev[0])
+        np.testing.assert_allclose(p1, g[f"{name}_p1"], rtol=1e-13, atol=1e-14)
+        p2 = p1.copy()
+        model.evolve_particles(p2, -0.75, ev[1])
+        np.testing.assert_allclose(p2, g[f"{name}_p2"], rtol=1e-13, atol=1e-14)
+        ll = model.compute_log_likelihoods(p2)
+        assert (ll is not None) == bool(g[f"{name}_has_ll"])
+        if ll is not None:
+            np.testing.assert_allclose(ll, g[f"{name}_ll"], rtol=1e-13)

@@ -492,6 +492,85 @@ def g9_variants():
     print("g9_choice vx:", tr.means[:, -1, 3])
 
 
+def g11_motion_models():
+    """Cylindrical / TangentCartesian / TangentCylindrical motion (motion.py:207-522) with scalar
+    surfaces: unit vectors (init, two evolves) with the draws recorded in call order, and one small
+    end-to-end track per model."""
+    out = {}
+    day = datetime.timedelta(days=1)
+    unit = [
+        ("cyl", glimpse.CylindricalMotion, dict(xy=(10.0, -4.0), dem=3.0, dem_sigma=0.4, n=211, xy_sigma=(0.2, 0.3),
+                                               vrthz=(0.5, 0.3, 0.02), vrthz_sigma=(0.1, 0.2, 0.01),
+                                               arthz=(0.01, 0.02, 0.0), arthz_sigma=(0.05, 0.1, 0.01))),
+        ("tcart", glimpse.TangentCartesianMotion, dict(xy=(499000.5, 6781000.25), dem=450.0, dem_sigma=0.5, n=190,
+                                                      xy_sigma=(0.5, 0.5), vxy=(1.0, -2.0), vxy_sigma=(0.3, 0.2),
+                                                      axy=(0.01, 0.02), axy_sigma=(0.05, 0.05), slope_sigma=0.1)),
+        ("tcyl", glimpse.TangentCylindricalMotion, dict(xy=(-3.0, 8.0), dem=0.0, dem_sigma=0.2, n=130,
+                                                       xy_sigma=(0.2, 0.2), vrth=(0.4, -1.0), vrth_sigma=(0.1, 0.3),
+                                                       arth=(0.0, 0.01), arth_sigma=(0.05, 0.05), slope_sigma=0.05)),
+    ]
+    real_randn = np.random.randn
+    for name, cls, kw in unit:
+        model = cls(time_unit=day, **kw)
+        log = []
+
+        def spy(*shape):
+            r = real_randn(*shape)
+            log.append(np.array(r))
+            return r
+
+        np.random.seed(900)
+        np.random.randn = spy
+        try:
+            p0 = model.initialize_particles()
+            n_init = len(log)
+            p1 = p0.copy()
+            model.evolve_particles(p1, dt=datetime.timedelta(days=1.5))
+            p2 = p1.copy()
+            model.evolve_particles(p2, dt=datetime.timedelta(days=-0.75))
+        finally:
+            np.random.randn = real_randn
+        ll = model.compute_log_likelihoods(p2)
+        out[f"{name}_p0"], out[f"{name}_p1"], out[f"{name}_p2"] = p0, p1, p2
+        out[f"{name}_has_ll"] = ll is not None
+        if ll is not None:
+            out[f"{name}_ll"] = ll
+        out[f"{name}_n_init_draws"] = n_init
+        for i, r in enumerate(log):
+            out[f"{name}_draw{i}"] = r
+        out[f"{name}_n_draws"] = len(log)
+        for k, v in kw.items():
+            out[f"{name}_kw_{k}"] = np.asarray(v, dtype=float)
+    np.savez_compressed(os.path.join(OUT, "g11_motion.npz"), **out)
+    # end to end
+    cam = synth.nadir_camera((192, 192), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 4, seed=21, velocity=(0.15, 0.0))
+    t0 = datetime.datetime(2020, 1, 1)
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(4)]
+    e2e = {"frames": np.stack(frames), "cam": cam}
+    models = {
+        "cyl": glimpse.CylindricalMotion(xy=(0.5, -0.5), time_unit=day, dem=0.0, dem_sigma=0.3, n=150,
+                                         xy_sigma=(0.2, 0.2), vrthz=(0.15, 0.0, 0.0), vrthz_sigma=(0.1, 0.5, 0.02),
+                                         arthz=(0, 0, 0), arthz_sigma=(0.03, 0.2, 0.01)),
+        "tcart": glimpse.TangentCartesianMotion(xy=(-1.0, 1.0), time_unit=day, dem=0.0, dem_sigma=0.2, n=150,
+                                                xy_sigma=(0.2, 0.2), vxy=(0.15, 0.0), vxy_sigma=(0.2, 0.2),
+                                                axy=(0, 0), axy_sigma=(0.05, 0.05), slope_sigma=0.1),
+        "tcyl": glimpse.TangentCylindricalMotion(xy=(1.5, 0.5), time_unit=day, dem=0.0, dem_sigma=0.2, n=150,
+                                                 xy_sigma=(0.2, 0.2), vrth=(0.15, 0.0), vrth_sigma=(0.1, 0.5),
+                                                 arth=(0, 0), arth_sigma=(0.03, 0.2), slope_sigma=0.1),
+    }
+    for name, model in models.items():
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+        np.random.seed(910)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track([model], tile_size=(15, 15), return_particles=True)
+        e2e[f"{name}_means"], e2e[f"{name}_sigmas"] = tracks.means, tracks.sigmas
+        e2e[f"{name}_particles"], e2e[f"{name}_weights"] = tracks.particles, tracks.weights
+    np.savez_compressed(os.path.join(OUT, "g11_motion_e2e.npz"), **e2e)
+    print("g11 e2e vx:", {k: e2e[f"{k}_means"][0, -1, 3] for k in models})
+
+
 def g10_tracks():
     """Tracks.reverse / from_multiple / average (tracks.py:131-213) on synthetic result arrays with
     missing rows, e.g. merging a forward and a backward run."""
@@ -535,6 +614,9 @@ def g10_tracks():
 
 
 if __name__ == "__main__":
+    if "--g11" in sys.argv:
+        g11_motion_models()
+        sys.exit(0)
     if "--g10" in sys.argv:
         g10_tracks()
         sys.exit(0)
@@ -551,5 +633,6 @@ if __name__ == "__main__":
     g8_c5mini()
     g9_variants()
     g10_tracks()
+    g11_motion_models()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
