@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--burn-in", type=int, default=6,
                     help="untimed frames after initialisation, before the warm-up: the particle cloud starts "
                          "from its wide prior and reaches the tracking regime after a few updates")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo gathers host copies and "
+                         "exists to exercise the multi-rank path where ranks share one GPU)")
     ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -134,13 +137,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = int(os.environ.get("GLH_BENCH_DEVICE", local_rank))  # test hook: several ranks on one GPU
+    use_nccl = args.dist_backend == "nccl"
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if use_nccl:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     from glimpse_amd import _lib, workloads
 
     K, W, B = args.steps, args.warmup, max(0, args.burn_in)
@@ -148,7 +156,7 @@ def main():
     wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
                             seed=0)
     frames = [wl.frames(o) for o in range(wl.O)]
-    ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=local_rank, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
+    ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
                        max_frames=T)
     workloads.setup_context(ctx, wl, frames)
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
@@ -173,18 +181,30 @@ def main():
             import torch
 
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_nccl:
+                torch.cuda.synchronize()
 
     gather_list = None
     mom = None
-    if dist is not None:
+
+    def gather_moments():
+        """The one collective of a sequence: every rank's posterior moments [T][P][12] to rank 0."""
         import torch
 
-        ptr, nbytes = ctx.moments_device()
-        mom = torch.as_tensor(DevArray(ptr, (T, wl.P, 12)), device=f"cuda:{local_rank}")
-        if rank == 0:
-            gather_list = [torch.empty_like(mom) for _ in range(world)]
-        dist.gather(mom, gather_list, dst=0)  # warm the communicator up outside the timed region
+        nonlocal gather_list, mom
+        if use_nccl:
+            if mom is None:  # zero-copy view of the library-owned history buffer
+                ptr, nbytes = ctx.moments_device()
+                mom = torch.as_tensor(DevArray(ptr, (T, wl.P, 12)), device=f"cuda:{device}")
+            send = mom
+        else:
+            send = torch.from_numpy(ctx.get_moments(0, T))
+        if rank == 0 and gather_list is None:
+            gather_list = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list, dst=0)
+
+    if dist is not None:
+        gather_moments()  # warm the communicator up outside the timed region
 
     # HIP events around every kernel launch on the context's stream, over the timed region itself
     ctx.profile_enable(True)
@@ -195,13 +215,13 @@ def main():
         ctx.step(i, 1.0, images(i), seed=seed)
     if dist is not None:
         ctx.sync()
-        dist.gather(mom, gather_list, dst=0)  # the one collective: posterior moments to rank 0
+        gather_moments()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=f"cuda:{device}" if use_nccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = ctx.profile_get()
@@ -217,6 +237,13 @@ def main():
     abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
     flops = ssd_flops_per_step(wl.O, wl.tile, boxes, status)
 
+    gathered_ok = None
+    if dist is not None and rank == 0:
+        # every shard's moments arrived and are finite for the timed frames
+        import torch
+
+        allm = torch.stack([g.cpu() for g in gather_list])  # (world, T, P, 12)
+        gathered_ok = bool(torch.isfinite(allm[:, 1 + B + W:1 + B + W + K]).all())
     if rank == 0:
         value = world * wl.P * wl.N * K / elapsed
         out = {
@@ -234,7 +261,8 @@ def main():
             "data": "synthetic",
             "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
                            frames_per_s=K / elapsed, burn_in_steps=B),
-            "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err},
+            "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err,
+                       "gathered_moments_finite": gathered_ok},
         }
         tot = sum(ms for ms, _ in stage_ms.values())
         dom = max(stage_ms, key=lambda k: stage_ms[k][0])
