@@ -30,6 +30,39 @@ constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handl
 constexpr int PT_NSTAMP = 10;
 constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
+// Wave64 reductions on the DPP data path (VALU moves; the canonical row_shr / row_bcast ladder) instead
+// of ds_bpermute shuffles through the LDS crossbar: the result is valid in LANE 63.
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool ZERO_FILL>
+__device__ __forceinline__ double pt_dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  // ZERO_FILL: lanes without a source read 0 (identity of +); otherwise they keep their own value
+  // (identity of min / max)
+  lo = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : lo, lo, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
+  hi = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : hi, hi, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
+  return __hiloint2double(hi, lo);
+}
+// row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+#define PT_DPP_LADDER(OP, ZF)                          \
+  v = OP(v, (pt_dpp_mov<0x111, 0xf, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x112, 0xf, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x114, 0xf, 0xe, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x118, 0xf, 0xc, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x142, 0xa, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x143, 0xc, 0xf, ZF>(v)));
+__device__ __forceinline__ double pt_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double pt_wave_sum63(double v) {
+  PT_DPP_LADDER(pt_add, true)
+  return v;
+}
+__device__ __forceinline__ double pt_wave_min63(double v) {
+  PT_DPP_LADDER(fmin, false)
+  return v;
+}
+__device__ __forceinline__ double pt_wave_max63(double v) {
+  PT_DPP_LADDER(fmax, false)
+  return v;
+}
+
 template <int TB>
 __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -462,9 +495,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll
     for (int o = 0; o < NOBS; ++o) {
       if (!live[o]) continue;
-      const double r0 = wave_min(mn[o][0]), r1 = wave_min(mn[o][1]);
-      const double r2m = wave_max(mx[o][0]), r3 = wave_max(mx[o][1]), r4 = wave_max(nanf[o]);
-      if (lane == 0) {
+      const double r0 = pt_wave_min63(mn[o][0]), r1 = pt_wave_min63(mn[o][1]);
+      const double r2m = pt_wave_max63(mx[o][0]), r3 = pt_wave_max63(mx[o][1]), r4 = pt_wave_max63(nanf[o]);
+      if (lane == WAVE - 1) {
         double* b = bred[o][wave];
         b[0] = r0; b[1] = r1; b[2] = r2m; b[3] = r3; b[4] = r4;
       }
@@ -795,12 +828,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // one pass for the 13 sums: wave shuffles -> LDS [wave][13] -> thread k < 6 finishes component k
     double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (sidx is dead after the gather)
     pt_lds_barrier();  // LDS only: the gather's stores drain in the background
-    const double t0 = wave_sum(s0);
-    if (lane == 0) mred[wave * 13] = t0;
+    const double t0 = pt_wave_sum63(s0);
+    if (lane == WAVE - 1) mred[wave * 13] = t0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double t1 = wave_sum(s1[k]), t2 = wave_sum(s2[k]);
-      if (lane == 0) {
+      const double t1 = pt_wave_sum63(s1[k]), t2 = pt_wave_sum63(s2[k]);
+      if (lane == WAVE - 1) {
         mred[wave * 13 + 1 + k] = t1;
         mred[wave * 13 + 7 + k] = t2;
       }
