@@ -27,7 +27,7 @@ namespace glh {
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
-constexpr int PT_NSTAMP = 10;
+constexpr int PT_NSTAMP = 16;
 constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
 // Wave64 reductions on the DPP data path (VALU moves; the canonical row_shr / row_bcast ladder) instead
@@ -724,6 +724,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     __syncthreads();
   }
+  PT_STAMP(10);
   double total = node[p_roots[0]];
   for (int r = 1; r < a.nroots; ++r) total += node[p_roots[r]];
   const int seg = (N + TB - 1) / TB;
@@ -746,9 +747,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   double base = 0.0;
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   const double excl = base + prev;
+  PT_STAMP(11);
   if (tid > 0)
     for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
   __syncthreads();
+  PT_STAMP(12);
   double u;
   if (a.rng_mode == GLH_RNG_HOST) {
     u = a.u[pt];
@@ -761,25 +764,61 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const double inv_n = 1.0 / (double)N;
   uint16_t* sidx = reinterpret_cast<uint16_t*>(node + a.nnodes);
   {
+    // f(ck) = #{j : pos_j <= ck}, pos_j = (j + u) * (1 / n) exactly as tracker.py:173 rounds it.  The guess
+    // floor(ck * n - u) + 1 is kept in float64 (integer valued, so (double)f == g bit for bit) and
+    // VERIFIED with the two exact comparisons around it; only if one fails (an ulp-level boundary) does
+    // the general walk run.
+    const double dN = (double)N;
     auto count_le = [&](double ck) -> int {
-      double g = floor(ck * (double)N - u) + 1.0;
-      int f = g < 0.0 ? 0 : (g > (double)N ? N : (int)g);
-      while (f < N && ((double)f + u) * inv_n <= ck) ++f;
-      while (f > 0 && ((double)(f - 1) + u) * inv_n > ck) --f;
+      double g = floor(ck * dN - u) + 1.0;
+      g = g < 0.0 ? 0.0 : (g > dN ? dN : g);
+      const bool below_ok = !(g > 0.0) || ((g - 1.0) + u) * inv_n <= ck;  // position g-1 is counted
+      const bool above_ok = !(g < dN) || !((g + u) * inv_n <= ck);        // position g is not
+      int f = (int)g;
+      if (!(below_ok && above_ok)) {
+        while (f < N && ((double)f + u) * inv_n <= ck) ++f;
+        while (f > 0 && ((double)(f - 1) + u) * inv_n > ck) --f;
+      }
       return f;
     };
+    // Source k serves the positions [f(k-1), f(k)).  Runs can be hundreds long when the weights are
+    // peaked, so instead of letting every lane write its own run (the wave would wait for its longest),
+    // each non-empty run writes only its HEAD and an inclusive max-scan fills the rest: the indices
+    // increase with the position, so "the last head at or before j" is the maximum so far.
+    for (int j = tid; j < N; j += TB) sidx[j] = 0;
+    pt_lds_barrier();
     int f_prev = k0 > 0 ? count_le(c[k0 - 1]) : 0;
     for (int k = k0; k < k1; ++k) {
-      int f = count_le(c[k]);
-      for (int j = f_prev; j < f; ++j) sidx[j] = (uint16_t)k;
+      const int f = count_le(c[k]);
+      if (f > f_prev) sidx[f_prev] = (uint16_t)k;
       f_prev = f;
     }
-    if (k1 == N && k0 < N) {
-      if (f_prev < N) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
-      for (int j = f_prev; j < N; ++j) sidx[j] = (uint16_t)(N - 1);
+    if (k1 == N && k0 < N && f_prev < N) {
+      // positions beyond c[N-1] (searchsorted == N: IndexError in the reference): clamp + flag
+      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+      sidx[f_prev] = (uint16_t)(N - 1);
     }
+    pt_lds_barrier();
+    uint32_t runmax = 0;
+    for (int j = k0; j < k1; ++j) {
+      runmax = max(runmax, (uint32_t)sidx[j]);
+      sidx[j] = (uint16_t)runmax;
+    }
+    uint32_t incl_m = runmax;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t t = __shfl_up(incl_m, off, WAVE);
+      if (lane >= off) incl_m = max(incl_m, t);
+    }
+    if (lane == WAVE - 1) scan_tmp[wave] = incl_m;
+    uint32_t before = __shfl_up(incl_m, 1, WAVE);
+    if (lane == 0) before = 0;
+    pt_lds_barrier();
+    for (int w = 0; w < wave; ++w) before = max(before, scan_tmp[w]);
+    if (before > 0)
+      for (int j = k0; j < k1; ++j) sidx[j] = (uint16_t)max((uint32_t)sidx[j], before);
   }
-  __syncthreads();
+  pt_lds_barrier();
 
   PT_STAMP(7);
   // ---------------- E + F: gather with re-evolve, moments --------------------------------------

@@ -206,7 +206,7 @@ int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng
  * particles bit for bit.                                                                      */
 int glh_set_fused(glh_ctx* ctx, int on);
 
-/* Diagnostic: s_memtime stamps [P][10] at the phase boundaries of the fused kernel during the
+/* Diagnostic: s_memtime stamps [P][16] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
 

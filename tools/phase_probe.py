@@ -34,6 +34,8 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     ctx.sync()
     ms = {k: v for k, v in ctx.profile_get().items() if v[0] > 0}
     st = ctx.phase_stamps().astype(np.int64)
+    sub = st[:, 10:13]
+    st = st[:, :10]
     d = np.diff(st, axis=1)  # (P, 9)
     tot = d.sum(axis=1)
     span = st[:, -1].max() - st[:, 0].min()
@@ -46,6 +48,9 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     print(f"  block start ticks percentiles 25/50/75/100: {np.percentile(t0, [25, 50, 75, 100])}; last end {t1.max()}")
     for k in range(9):
         print(f"  {NAMES[k + 1]:18s} median {np.median(d[:, k]):10.0f} ticks  {100 * d[:, k].sum() / tot.sum():5.1f} %")
+    if (sub > 0).all():
+        print(f"  D split (median ticks): sum tree {np.median(sub[:, 0] - st[:, 6]):.0f}, scan {np.median(sub[:, 1] - sub[:, 0]):.0f}, "
+              f"fix-up {np.median(sub[:, 2] - sub[:, 1]):.0f}, search+scatter {np.median(st[:, 7] - sub[:, 2]):.0f}")
     bx = ctx.search_boxes()[0]
     wsz, hsz = bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]
     print("  search tile w x h median:", np.median(wsz), np.median(hsz), "max:", wsz.max(), hsz.max())
