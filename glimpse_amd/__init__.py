@@ -14,9 +14,10 @@ from .image import Image
 from .motion import (CartesianMotion, CylindricalMotion, Motion, TangentCartesianMotion,
                      TangentCylindricalMotion)
 from .observer import Observer
+from .raster import Raster
 from .tracker import Tracker
 from .tracks import Tracks
 
 __all__ = ["Camera", "Image", "Observer", "Motion", "CartesianMotion", "CylindricalMotion",
-           "TangentCartesianMotion", "TangentCylindricalMotion", "Tracker", "Tracks"]
+           "TangentCartesianMotion", "TangentCylindricalMotion", "Raster", "Tracker", "Tracks"]
 __version__ = "0.1.0"

@@ -19,6 +19,8 @@ RNG_HOST, RNG_PHILOX = 0, 1
 RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2}
 OK = 0
 PT_NAN, PT_TEMPLATE_OOB, PT_SAMPLE_OUTSIDE, PT_RESAMPLE_CLAMP, PT_CONST_TILE = 1, 2, 4, 8, 16
+PT_RASTER_OOB, PT_NOT_VISIBLE = 32, 64
+RASTER_DEM, RASTER_DEM_SIGMA, RASTER_VIEWSHED = 0, 1, 2
 OBS_OK, OBS_SKIPPED, OBS_OUT_OF_BOUNDS, OBS_TILE_TOO_LARGE, OBS_NO_TEMPLATE = 0, 1, 2, 3, 4
 NO_ERROR_FRAME = 0x7F7F7F7F
 
@@ -63,6 +65,7 @@ SIGNATURES = {
     "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
     "glh_set_motion_cartesian": (_I, [_P, _P]),
     "glh_set_motion": (_I, [_P, _P]),
+    "glh_set_raster": (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _D, _D, _D, _D]),
     "glh_set_point_offset": (_I, [_P, _I]),
     "glh_set_observer_mask": (_I, [_P, _P]),
     "glh_set_active": (_I, [_P, _P]),
@@ -105,6 +108,7 @@ SIGNATURES = {
     "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
     "glh_stage_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "glh_stage_resample": (_I, [_I, _P, _I, _D, _P]),
+    "glh_stage_raster_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _I, _D, _D, _D, _D, _P, _I, _I, _P, _P]),
 }
 
 _lib = None
@@ -217,6 +221,15 @@ class Context:
         """Any mix of motion models: [P][MOTION_FULL_LEN] (include/glimpse_hip.h)."""
         params = _arr(params, np.float64, (self.P, MOTION_FULL_LEN))
         check(self.lib.glh_set_motion(self.handle, _ptr(params)))
+
+    def set_raster(self, which, raster):
+        """Upload a glimpse_amd.Raster as the context's dem (0), dem_sigma (1) or viewshed (2); None removes it."""
+        if raster is None:
+            check(self.lib.glh_set_raster(self.handle, int(which), None, 0, 0, None, None, 1, 1, 0.0, 0.0, 0.0, 0.0))
+            return
+        z, nx, ny, gx, gy, sx, sy, x0, x1, y0, y1 = raster.device_args()
+        check(self.lib.glh_set_raster(self.handle, int(which), _ptr(z), nx, ny, _ptr(gx), _ptr(gy), sx, sy, x0, x1,
+                                      y0, y1))
 
     def set_observer_mask(self, mask):
         m = None if mask is None else _arr(mask, np.uint8, (self.P, self.O))
@@ -473,3 +486,13 @@ def stage_resample(weights, u, device_id=0):
     idx = np.empty(len(w), dtype=np.int64)
     check(load().glh_stage_resample(device_id, _ptr(w), len(w), float(u), _ptr(idx)))
     return idx
+
+
+def stage_raster_sample(raster, xy, order=1, device_id=0):
+    z, nx, ny, gx, gy, sx, sy, x0, x1, y0, y1 = raster.device_args()
+    xy = _arr(xy, np.float64)
+    vals = np.empty(len(xy))
+    oob = np.empty(len(xy), dtype=np.uint8)
+    check(load().glh_stage_raster_sample(device_id, _ptr(z), nx, ny, _ptr(gx), _ptr(gy), sx, sy, x0, x1, y0, y1,
+                                         _ptr(xy), len(xy), int(order), _ptr(vals), _ptr(oob)))
+    return vals, oob.astype(bool)

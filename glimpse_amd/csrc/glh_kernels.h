@@ -112,17 +112,19 @@ __device__ __forceinline__ void evolve_noise(int rng_mode, const double* normals
 // Motion.initialize_particles for one particle from its six normals n = randn(n,2) | randn(n) |
 // randn(n,3) (the tangent models draw randn(n,2) last and leave vz = 0):
 // motion.py:149-163, :262-286, :382-394, :470-488.  m = [GLH_MOTION_FULL_LEN] parameters.
-__device__ __forceinline__ void init_particle(const double* m, const double* n, double* p) {
+__device__ __forceinline__ void init_particle(const double* m, const double* n, double* p, const Surfaces& surf,
+                                              bool* oob) {
   const int kind = (int)m[18];
   p[0] = m[0] + m[2] * n[0];
   p[1] = m[1] + m[3] * n[1];
+  const double zd = dem_at(m, surf, p[0], p[1], oob), zs = dem_sigma_at(m, surf, p[0], p[1], oob);
   if (kind == GLH_MOTION_CARTESIAN || kind == GLH_MOTION_CYLINDRICAL) {
-    double z = m[16];
-    z += m[17] * n[2];
+    double z = zd;
+    z += zs * n[2];
     p[2] = z;
   } else {
-    const double z_off = m[17] * n[2];
-    p[2] = m[16] + z_off;
+    const double z_off = zs * n[2];
+    p[2] = zd + z_off;
   }
   if (kind == GLH_MOTION_CARTESIAN) {
     p[3] = m[4] + m[7] * n[3];
@@ -145,6 +147,27 @@ __device__ __forceinline__ void init_particle(const double* m, const double* n, 
   }
 }
 
+// Tracker.test_particles beyond the NaN test (tracker.py:114-117): every particle must sit on a
+// visible viewshed cell (nearest-cell lookup).  Returns the status bits to raise.
+__device__ __forceinline__ uint32_t viewshed_bits(const Surfaces& surf, double x, double y) {
+  if (!surf.viewshed.z) return 0u;
+  bool oob = false;
+  const double vis = raster_sample(surf.viewshed, x, y, 0, &oob);
+  if (oob) return GLH_PT_RASTER_OOB;
+  return vis != 0.0 ? 0u : GLH_PT_NOT_VISIBLE;
+}
+
+// CartesianMotion.compute_log_likelihoods (motion.py:181-204) for one (evolved) particle
+__device__ __forceinline__ double dem_log_likelihood(const double* m, const Surfaces& surf, double x, double y,
+                                                     double z, bool* oob) {
+  const double zd = dem_at(m, surf, x, y, oob), zs = dem_sigma_at(m, surf, x, y, oob);
+  if (zs != 0.0) {
+    const double d = zd - z;
+    return (1.0 / (2.0 * (zs * zs))) * (d * d);
+  }
+  return 0.0;
+}
+
 // Motion.evolve_particles for one particle p[6], tau2 = tau * tau, n = the step's three normals
 // (randn(n,3); the tangent models draw randn(n,2) then randn(n)):
 // motion.py:165-179, :288-311, :396-412, :490-522.
@@ -158,7 +181,7 @@ __device__ __forceinline__ void evolve_cartesian(double* p, const double* m, con
   }
 }
 __device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
-                                                double tau2) {
+                                                double tau2, const Surfaces& surf, bool* oob) {
   const int kind = (int)m[18];
   if (kind == GLH_MOTION_CARTESIAN) {
     evolve_cartesian(p, m, n, tau, tau2);
@@ -186,14 +209,14 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
     }
     return;
   }
-  // tangent models: the height follows the (constant) surface plus a random walk of the offset
+  // tangent models: the height follows the surface plus a random walk of the offset
   const double dx = tau * p[3] + 0.5 * a[0] * tau2;
   const double dy = tau * p[4] + 0.5 * a[1] * tau2;
-  double z_off = p[2] - m[16];
+  double z_off = p[2] - dem_at(m, surf, p[0], p[1], oob);
   z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;
   p[1] += dy;
-  p[2] = m[16] + z_off;
+  p[2] = dem_at(m, surf, p[0], p[1], oob) + z_off;
   p[3] += tau * a[0];
   p[4] += tau * a[1];
 }
@@ -209,6 +232,10 @@ struct InitArgs {
   const double* normals;  // [P][N][6] or null
   uint64_t seed;
   int32_t rng_mode, N, pt_base;  // pt_base: global index of point 0 (sharding-invariant Philox streams)
+  int32_t frame;
+  uint32_t* pt_status;
+  int32_t* pt_err_frame;
+  Surfaces surf;
 };
 
 __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
@@ -228,8 +255,15 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
     philox_normals2(a.seed, i, gp, 1u, 0x494e4954u, n[2], n[3]);
     philox_normals2(a.seed, i, gp, 2u, 0x494e4954u, n[4], n[5]);
   }
+  double x[6];
+  bool oob = false;
+  init_particle(m, n, x, a.surf, &oob);
+  uint32_t bits = viewshed_bits(a.surf, x[0], x[1]);
+  if (oob) bits |= GLH_PT_RASTER_OOB;
+  if (bits) flag_point(a.pt_status, a.pt_err_frame, pt, bits, a.frame);
   double* p = a.particles + ((size_t)pt * a.N + i) * 6;
-  init_particle(m, n, p);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p[k] = x[k];
   a.weights[(size_t)pt * a.N + i] = 1.0;
 }
 
@@ -239,7 +273,6 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
 // ------------------------------------------------------------------------------------------
 struct EvolveArgs {
   double* particles;  // [P][N][6] current buffer (updated in place when `store`)
-  double* lldem_out;  // [P][N] DEM log likelihood of the evolved particle (fused step), or null
   const double* motion;
   const uint8_t* active;
   const uint8_t* obs_mask;  // [P][O] or null
@@ -251,6 +284,7 @@ struct EvolveArgs {
   uint64_t seed, step;
   double tau;
   int32_t do_evolve, store, rng_mode, N, P, O, NB, frame, pt_base;
+  Surfaces surf;
   ObsFrame obs[MAX_OBS];
 };
 
@@ -271,22 +305,16 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
       const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
       double n[3];
       evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, a.N, n);
-      evolve_particle(p, m, n, a.tau, a.tau * a.tau);
+      bool oob = false;
+      evolve_particle(p, m, n, a.tau, a.tau * a.tau, a.surf, &oob);
+      uint32_t bits = viewshed_bits(a.surf, p[0], p[1]);
+      if (oob) bits |= GLH_PT_RASTER_OOB;
+      if (bits) flag_point(a.pt_status, a.pt_err_frame, pt, bits, a.frame);
       if (a.store) {
         double2* dst = reinterpret_cast<double2*>(pp);
         dst[0] = make_double2(p[0], p[1]);
         dst[1] = make_double2(p[2], p[3]);
         dst[2] = make_double2(p[4], p[5]);
-      }
-      if (a.lldem_out) {
-        // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
-        const double zs = m[17];
-        double ll = 0.0;
-        if (zs != 0.0) {
-          const double d = m[16] - p[2];
-          ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
-        }
-        a.lldem_out[(size_t)pt * a.N + i] = ll;
       }
     }
     bool bad = false;
@@ -1053,6 +1081,7 @@ struct WeightArgs {
   double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
   int32_t on[MAX_OBS];
   int32_t N, P, O, tw, th, sse_cap, frame;
+  Surfaces surf;
 };
 
 __device__ __forceinline__ void sse_box_of(const int* box, const double* duv, int tw, int th,
@@ -1075,8 +1104,10 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   __syncthreads();
   const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
   const bool has_motion_term = (int)m[18] <= GLH_MOTION_CYLINDRICAL;  // tangent models return None
+  const bool gridded = m[20] != 0.0 || m[21] != 0.0;
   const double zs = has_motion_term ? m[17] : 0.0;
   const double dem_scale = zs != 0.0 ? 1.0 / (2.0 * (zs * zs)) : 0.0;
+  bool oob = false;
   bool any_obs = false;  // uniform across the block
   for (int o = 0; o < a.O; ++o)
     any_obs |= a.on[o] && a.obs_status[(size_t)o * a.P + pt] == GLH_OBS_OK;
@@ -1102,13 +1133,17 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       if (a.ll_out) a.ll_out[slot * a.N + i] = val * a.inv2s2[o];
       ll += val * a.inv2s2[o];
     }
-    if (zs != 0.0) {
+    if (has_motion_term && gridded) {
+      const double* q = a.particles + ((size_t)pt * a.N + i) * 6;
+      ll += dem_log_likelihood(m, a.surf, q[0], q[1], q[2], &oob);
+    } else if (zs != 0.0) {
       double z = a.particles[((size_t)pt * a.N + i) * 6 + 2];
       double d = m[16] - z;
       ll += dem_scale * (d * d);
     }
     if (has_motion_term || any_obs) a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
   }
+  if (oob) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RASTER_OOB, a.frame);
 }
 
 // Test hook: sample a fitted surface (glh_stage_sample); one "point".
@@ -1384,6 +1419,16 @@ __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const
   project(*cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
   uv[2 * i] = u;
   uv[2 * i + 1] = v;
+}
+
+// Test hook: Raster.sample at explicit points
+__global__ __launch_bounds__(BLK) void k_raster_sample(RasterDev r, const double* xy, int n, int order,
+                                                       double* values, uint8_t* oob) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  bool out = false;
+  values[i] = raster_sample(r, xy[2 * i], xy[2 * i + 1], order, &out);
+  oob[i] = out;
 }
 
 __global__ void k_fill_f64(double* p, size_t n, double v) {

@@ -106,6 +106,64 @@ GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, do
   project_f(c, cam_flags(c), x, y, z, u, v);
 }
 
+// ---- gridded surfaces: Raster.sample at points (raster.py:913-1027) --------------------------
+// scipy.interpolate.RegularGridInterpolator over the cell CENTRES (raster.py:891-900), made ascending
+// (`x[::sign]`, `array.T[::sign[0], ::sign[1]]`), with `bounds_error=False, fill_value=None`: linear
+// extrapolation in the half-cell border, after the reference's own bounds test against the OUTER
+// limits (Grid.inbounds_xy, raster.py:313-337).
+struct RasterDev {
+  const double* z;   // [ny][nx] as Raster.array (row 0 = first y), null = no raster
+  const double* gx;  // [nx] ascending cell-centre x (np.linspace, computed by the host like Grid.x)
+  const double* gy;  // [ny] ascending cell-centre y
+  int32_t nx, ny, sx, sy;  // sx, sy = sign of (dx, dy): which way array columns / rows run
+  double xmin, xmax, ymin, ymax;
+};
+
+// find_indices (scipy/interpolate/_rgi_cython.pyx): i = clip(searchsorted(g, x) - 1, 0, n - 2)
+GLH_HD int raster_interval(const double* g, int n, double x) {
+  int lo = 0, hi = n;  // searchsorted side='left': first index with g[idx] >= x
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (g[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int i = lo - 1;
+  if (i < 0) i = 0;
+  if (i > n - 2) i = n - 2;
+  return i;
+}
+
+// order 1: bilinear (RegularGridInterpolator method 'linear'); order 0: 'nearest'.  Sets *oob when the
+// point is outside the raster's outer limits (the reference raises ValueError there).
+GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob) {
+  if (!(x >= r.xmin && x <= r.xmax && y >= r.ymin && y <= r.ymax)) {
+    *oob = true;
+    return NAN;
+  }
+  const int i0 = raster_interval(r.gx, r.nx, x), i1 = raster_interval(r.gy, r.ny, y);
+  const double y0 = (x - r.gx[i0]) / (r.gx[i0 + 1] - r.gx[i0]);
+  const double y1 = (y - r.gy[i1]) / (r.gy[i1 + 1] - r.gy[i1]);
+  auto V = [&](int ix, int iy) -> double {
+    const int col = r.sx > 0 ? ix : r.nx - 1 - ix, row = r.sy > 0 ? iy : r.ny - 1 - iy;
+    return r.z[(size_t)row * r.nx + col];
+  };
+  if (order == 0) return V(y0 <= 0.5 ? i0 : i0 + 1, y1 <= 0.5 ? i1 : i1 + 1);
+  return V(i0, i1) * (1.0 - y0) * (1.0 - y1) + V(i0, i1 + 1) * (1.0 - y0) * y1 + V(i0 + 1, i1) * y0 * (1.0 - y1) +
+         V(i0 + 1, i1 + 1) * y0 * y1;
+}
+
+// The surface height / its sigma under (x, y) for one point: the context's raster when the point's
+// flag says so (m[20] dem, m[21] dem_sigma), else the constant m[16] / m[17] (an infinite 1 x 1
+// raster in the reference, motion.py:136-141, raster.py:1021-1026).
+struct Surfaces {
+  RasterDev dem, dem_sigma, viewshed;
+};
+GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob) {
+  return m[20] != 0.0 ? raster_sample(s.dem, x, y, 1, oob) : m[16];
+}
+GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double y, bool* oob) {
+  return m[21] != 0.0 ? raster_sample(s.dem_sigma, x, y, 1, oob) : m[17];
+}
+
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is
 // inside the image (Camera.inframe, camera.py:700-718), 1 otherwise.  kx = ky = 3.
 GLH_HD int search_box(double minu, double minv, double maxu, double maxv, int has_nan, int tw,

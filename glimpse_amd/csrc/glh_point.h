@@ -136,6 +136,7 @@ struct PointArgs {
   double inv2s2[PT_MAX_OBS];
   ObsFrame obs[PT_MAX_OBS];
   CamDev cam[PT_MAX_OBS];  // by value; copied to LDS once per workgroup
+  Surfaces surf;           // gridded dem / dem_sigma / viewshed (null pointers when absent)
   uint32_t cam_flags[PT_MAX_OBS];  // cam_flags(cam[o]): scalar, so the optional projection terms branch uniformly
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
@@ -354,7 +355,9 @@ __device__ __forceinline__ void pt_lds_barrier() { asm volatile("s_waitcnt lgkmc
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <int TB, int PPT, int MINW, int NOBS>
+// SURF: the context holds gridded surfaces (dem / dem_sigma / viewshed rasters); compiled out otherwise so
+// that the common constant-surface kernel carries none of their registers.
+template <int TB, int PPT, int MINW, int NOBS, bool SURF>
 __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   constexpr int PT_WAVES = TB / WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -431,8 +434,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       mx[o][0] = mx[o][1] = -INFINITY;
       nanf[o] = 0.0;
     }
-    bool bad = false;
+    bool bad = false, raster_oob = false;
+    uint32_t view_bits = 0u;
     const double zs = m[17];
+    const bool gridded = SURF && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
     for (int r = 0; r < NREG; ++r) uv0[r] = make_double2(0.0, 0.0);
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
@@ -462,12 +467,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         if (a.has_dem) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
-          if (zs != 0.0) {
+          if (SURF && gridded) {
+            ll = dem_log_likelihood(m, a.surf, x[0], x[1], x[2], &raster_oob);
+          } else if (zs != 0.0) {
             const double d = m[16] - x[2];
             ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
           }
           W[i] = ll;
         }
+        if (SURF && a.surf.viewshed.z) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
 #pragma unroll
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
@@ -492,6 +500,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
+    if (raster_oob) view_bits |= GLH_PT_RASTER_OOB;
+    if (view_bits) flag_point(a.pt_status, a.pt_err_frame, pt, view_bits, a.frame);
 #pragma unroll
     for (int o = 0; o < NOBS; ++o) {
       if (!live[o]) continue;

@@ -100,6 +100,10 @@ struct glh_ctx {
   double *particles[2] = {nullptr, nullptr}, *weights[2] = {nullptr, nullptr};
   double *motion = nullptr, *uv = nullptr, *bbox_part = nullptr, *normals = nullptr, *u = nullptr;
   double *mean6 = nullptr, *moments = nullptr;
+  struct RasterBuf {
+    double *z = nullptr, *gx = nullptr, *gy = nullptr;
+    RasterDev dev{};
+  } rasters[3];  // GLH_RASTER_DEM, _DEM_SIGMA, _VIEWSHED
   double* covariances = nullptr;  // [max_frames][P][36], allocated on first use
   double* uj = nullptr;           // [P][N] host-fed per-particle uniforms (stratified / choice)
   uint8_t *obs_mask = nullptr, *active = nullptr;
@@ -219,7 +223,10 @@ extern "C" int glh_destroy(glh_ctx* c) {
     dfree(c->weights[i]);
   }
   dfree(c->motion); dfree(c->uv); dfree(c->bbox_part); dfree(c->normals); dfree(c->u);
-  dfree(c->mean6); dfree(c->moments); dfree(c->covariances); dfree(c->uj); dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
+  dfree(c->mean6); dfree(c->moments); dfree(c->covariances); dfree(c->uj);
+  for (auto& r : c->rasters) {
+    dfree(r.z); dfree(r.gx); dfree(r.gy);
+  } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
@@ -326,14 +333,17 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-    for (const void* f : {(const void*)k_point_step<512, 0, 4, 1>, (const void*)k_point_step<512, 0, 4, 2>,
-                          (const void*)k_point_step<512, 4, 4, 1>, (const void*)k_point_step<512, 10, 4, 1>,
-                          (const void*)k_point_step<512, 4, 4, 2>, (const void*)k_point_step<512, 10, 4, 2>,
-                          (const void*)k_point_step<1024, 0, 4, 1>, (const void*)k_point_step<1024, 0, 4, 2>,
-                          (const void*)k_point_step<1024, 10, 4, 1>, (const void*)k_point_step<1024, 10, 4, 2>}) {
+#define GLH_PT_VARIANTS(SURF_)                                                                          \
+  (const void*)k_point_step<512, 0, 4, 1, SURF_>, (const void*)k_point_step<512, 0, 4, 2, SURF_>,          \
+  (const void*)k_point_step<512, 4, 4, 1, SURF_>, (const void*)k_point_step<512, 10, 4, 1, SURF_>,         \
+  (const void*)k_point_step<512, 4, 4, 2, SURF_>, (const void*)k_point_step<512, 10, 4, 2, SURF_>,         \
+  (const void*)k_point_step<1024, 0, 4, 1, SURF_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_>,        \
+  (const void*)k_point_step<1024, 10, 4, 1, SURF_>, (const void*)k_point_step<1024, 10, 4, 2, SURF_>
+    for (const void* f : {GLH_PT_VARIANTS(false), GLH_PT_VARIANTS(true)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
+#undef GLH_PT_VARIANTS
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       rc = fail(GLH_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   }
@@ -513,6 +523,46 @@ static int need_seq(glh_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
 
+static Surfaces surfaces(const glh_ctx* c) {
+  Surfaces s{};
+  s.dem = c->rasters[GLH_RASTER_DEM].dev;
+  s.dem_sigma = c->rasters[GLH_RASTER_DEM_SIGMA].dev;
+  s.viewshed = c->rasters[GLH_RASTER_VIEWSHED].dev;
+  return s;
+}
+
+static int check_raster_args(int nx, int ny, const double* gx, const double* gy, int sx, int sy) {
+  if (nx < 2 || ny < 2) return fail(GLH_E_UNSUPPORTED, "rasters need at least 2 x 2 cells (got %d x %d)", nx, ny);
+  if (!gx || !gy || (sx != 1 && sx != -1) || (sy != 1 && sy != -1)) return fail(GLH_E_INVALID, "bad raster geometry");
+  for (int i = 1; i < nx; ++i)
+    if (!(gx[i] > gx[i - 1])) return fail(GLH_E_INVALID, "gx must be strictly ascending");
+  for (int i = 1; i < ny; ++i)
+    if (!(gy[i] > gy[i - 1])) return fail(GLH_E_INVALID, "gy must be strictly ascending");
+  return GLH_OK;
+}
+
+extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, int ny, const double* gx,
+                              const double* gy, int sx, int sy, double xmin, double xmax, double ymin,
+                              double ymax) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (which < GLH_RASTER_DEM || which > GLH_RASTER_VIEWSHED) return fail(GLH_E_INVALID, "unknown raster slot %d", which);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  auto& r = c->rasters[which];
+  dfree(r.z); dfree(r.gx); dfree(r.gy);
+  r.dev = RasterDev{};
+  if (!z) return GLH_OK;
+  CHK(check_raster_args(nx, ny, gx, gy, sx, sy));
+  CHK(dalloc(&r.z, (size_t)nx * ny));
+  CHK(dalloc(&r.gx, (size_t)nx));
+  CHK(dalloc(&r.gy, (size_t)ny));
+  HIPCHK(hipMemcpy(r.z, z, (size_t)nx * ny * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r.gx, gx, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(r.gy, gy, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
+  r.dev = RasterDev{r.z, r.gx, r.gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax};
+  return GLH_OK;
+}
+
 extern "C" int glh_set_motion(glh_ctx* c, const double* params) {
   CHK(need_seq(c));
   if (!params) return fail(GLH_E_INVALID, "params is null");
@@ -524,7 +574,11 @@ extern "C" int glh_set_motion(glh_ctx* c, const double* params) {
     if (m[18] != (double)kind || kind < GLH_MOTION_CARTESIAN || kind > GLH_MOTION_TANGENT_CYLINDRICAL)
       return fail(GLH_E_INVALID, "point %d: unknown motion kind %g", p, m[18]);
     if (kind != GLH_MOTION_CARTESIAN) c->all_cartesian = false;
-    if (kind <= GLH_MOTION_CYLINDRICAL && m[17] != 0.0) c->has_dem = true;
+    if (m[20] != 0.0 && !c->rasters[GLH_RASTER_DEM].z)
+      return fail(GLH_E_STATE, "point %d uses a dem raster but glh_set_raster(GLH_RASTER_DEM) was not called", p);
+    if (m[21] != 0.0 && !c->rasters[GLH_RASTER_DEM_SIGMA].z)
+      return fail(GLH_E_STATE, "point %d uses a dem_sigma raster but glh_set_raster(GLH_RASTER_DEM_SIGMA) was not called", p);
+    if (kind <= GLH_MOTION_CYLINDRICAL && (m[17] != 0.0 || m[21] != 0.0)) c->has_dem = true;
   }
   UPLOAD(c->motion, params, (size_t)c->P * GLH_MOTION_FULL_LEN, double);
   return GLH_OK;
@@ -672,6 +726,10 @@ extern "C" int glh_init_particles(glh_ctx* c, int rng_mode, const double* normal
   a.rng_mode = rng_mode;
   a.N = c->N;
   a.pt_base = c->pt_base;
+  a.frame = c->frame;
+  a.pt_status = c->pt_status;
+  a.pt_err_frame = c->pt_err_frame;
+  a.surf = surfaces(c);
   {
     StageTimer t(c, ST_INIT);
     hipLaunchKernelGGL(k_init_particles, dim3(c->NB, c->P), dim3(BLK), 0, c->stream, a);
@@ -703,13 +761,12 @@ static int check_images(glh_ctx* c, const int32_t* images) {
 
 // evolve (optional) + project into the given images + bbox partials
 static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng_mode, uint64_t seed,
-                                 uint64_t step, const int32_t* images, bool store = true,
-                                 double* lldem_out = nullptr) {
+                                 uint64_t step, const int32_t* images, bool store = true) {
   if (do_evolve) c->moments_frame = -1;
   EvolveArgs a{};
   a.particles = c->particles[c->cur];
   a.store = store;
-  a.lldem_out = lldem_out;
+  a.surf = surfaces(c);
   a.motion = c->motion;
   a.active = c->have_active ? c->active : nullptr;
   a.obs_mask = c->have_mask ? c->obs_mask : nullptr;
@@ -910,6 +967,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.th = c->th;
   wa.sse_cap = c->sse_cap;
   wa.frame = c->frame;
+  wa.surf = surfaces(c);
   {
     StageTimer t(c, ST_WEIGHTS);
     hipLaunchKernelGGL(k_weights, dim3((c->NB + WEIGHTS_PER_THREAD - 1) / WEIGHTS_PER_THREAD, c->P), dim3(BLK), 0, c->stream, wa);
@@ -1101,6 +1159,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.has_dem = c->has_dem;
   a.r2_bytes = r2_bytes;
   a.pt_base = c->pt_base;
+  a.surf = surfaces(c);
   a.nleaves = c->nleaves;
   a.nnodes = c->nnodes;
   a.nlevels = c->nlevels;
@@ -1118,8 +1177,14 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
     if (big && ppt == 4) ppt = 10;
     if (getenv("GLH_PT_UVLDS")) ppt = 0;
-#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_) \
-  hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_>), grid, block, lds, c->stream, a)
+    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z;
+#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                              \
+  do {                                                                                                  \
+    if (surf)                                                                                           \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true>), grid, block, lds, c->stream, a);    \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false>), grid, block, lds, c->stream, a);   \
+  } while (0)
     if (!big) {
       if (O == 1) {
         if (ppt == 4) GLH_LAUNCH_POINT(512, 4, 1);
@@ -1510,6 +1575,27 @@ extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const
   CHK(finish());
   CHK(dval.down(values, (size_t)n * 8));
   return dout.down(outside, (size_t)n);
+}
+
+extern "C" int glh_stage_raster_sample(int dev, const double* z, int nx, int ny, const double* gx, const double* gy,
+                                       int sx, int sy, double xmin, double xmax, double ymin, double ymax,
+                                       const double* xy, int n, int order, double* values, uint8_t* oob) {
+  if (!z || !xy || !values || !oob || n <= 0 || (order != 0 && order != 1)) return fail(GLH_E_INVALID, "bad argument");
+  CHK(check_raster_args(nx, ny, gx, gy, sx, sy));
+  HIPCHK(hipSetDevice(dev));
+  DevBuf dz, dgx, dgy, dxy, dv, do_;
+  CHK(dz.up(z, (size_t)nx * ny * 8));
+  CHK(dgx.up(gx, (size_t)nx * 8));
+  CHK(dgy.up(gy, (size_t)ny * 8));
+  CHK(dxy.up(xy, (size_t)n * 16));
+  CHK(dv.alloc((size_t)n * 8));
+  CHK(do_.alloc((size_t)n));
+  RasterDev r{dz.as<double>(), dgx.as<double>(), dgy.as<double>(), nx, ny, sx, sy, xmin, xmax, ymin, ymax};
+  hipLaunchKernelGGL(k_raster_sample, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, r, dxy.as<double>(), n, order,
+                     dv.as<double>(), do_.as<uint8_t>());
+  CHK(finish());
+  CHK(dv.down(values, (size_t)n * 8));
+  return do_.down(oob, (size_t)n);
 }
 
 extern "C" int glh_stage_resample(int dev, const double* weights, int n, double u, int64_t* idx) {

@@ -9,6 +9,24 @@ directly; the Tracker does not use them.  Gridded DEM rasters are "next" (SURVEY
 """
 import numpy as np
 
+from .raster import Raster
+
+
+def _surface(value, name, cls):
+    """dem / dem_sigma: a number (constant surface) or a glimpse_amd.Raster."""
+    if isinstance(value, Raster):
+        return value
+    if value is None or not np.isscalar(value):
+        raise NotImplementedError(f"{cls}: {name} must be a number or a glimpse_amd.Raster")
+    return float(value)
+
+
+def _sample(surface, xy):
+    """Raster.sample at points, or the constant (an infinite 1 x 1 raster in the reference)."""
+    if isinstance(surface, Raster):
+        return surface.sample(xy)
+    return np.full(len(xy), surface)
+
 
 class Motion:
     """Interface illustration (motion.py:13-89)."""
@@ -26,12 +44,10 @@ class CartesianMotion(Motion):
         """motion.py:121-147.  `dem` / `dem_sigma` must be numbers (constant surfaces): gridded
         rasters are "next"; `dem_sigma=None` crashes in the reference (KeyError 'buf_xsize',
         SURVEY.md 7.4 item 8), so a number is required here."""
-        if not np.isscalar(dem) or dem_sigma is None or not np.isscalar(dem_sigma):
-            raise NotImplementedError("CartesianMotion needs scalar dem and dem_sigma on the GPU path")
         self.xy = xy
         self.time_unit = time_unit
-        self.dem = float(dem)
-        self.dem_sigma = float(dem_sigma)
+        self.dem = _surface(dem, "dem", "CartesianMotion")
+        self.dem_sigma = _surface(dem_sigma, "dem_sigma", "CartesianMotion")
         self.n = int(n)
         self.xy_sigma = xy_sigma
         self.vxyz = vxyz
@@ -45,21 +61,26 @@ class CartesianMotion(Motion):
 
     def params_full(self):
         """GLH_MOTION_FULL_LEN doubles (include/glimpse_hip.h): params() | kind | slope_sigma | 0 0 0 0."""
-        return np.concatenate((self.params(), [self.KIND, getattr(self, "slope_sigma", 0.0), 0, 0, 0, 0]))
+        return np.concatenate((self.params(), [self.KIND, getattr(self, "slope_sigma", 0.0),
+                                               isinstance(self.dem, Raster), isinstance(self.dem_sigma, Raster), 0, 0]))
+
+    def _surface_scalars(self):
+        return [0.0 if isinstance(self.dem, Raster) else self.dem,
+                0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma]
 
     def params(self):
         """GLH_MOTION_LEN doubles (include/glimpse_hip.h)."""
         def v(x, n):
             return np.broadcast_to(np.asarray(x, dtype=float), (n,))
         return np.concatenate((v(self.xy, 2), v(self.xy_sigma, 2), v(self.vxyz, 3), v(self.vxyz_sigma, 3),
-                               v(self.axyz, 3), v(self.axyz_sigma, 3), [self.dem, self.dem_sigma]))
+                               v(self.axyz, 3), v(self.axyz_sigma, 3), self._surface_scalars()))
 
     def initialize_particles(self):
         """motion.py:149-163."""
         particles = np.zeros((self.n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * np.random.randn(self.n, 2)
-        particles[:, 2] = self.dem
-        particles[:, 2] += self.dem_sigma * np.random.randn(self.n)
+        particles[:, 2] = _sample(self.dem, particles[:, 0:2])
+        particles[:, 2] += _sample(self.dem_sigma, particles[:, 0:2]) * np.random.randn(self.n)
         particles[:, 3:6] = self.vxyz + self.vxyz_sigma * np.random.randn(self.n, 3)
         return particles
 
@@ -73,16 +94,12 @@ class CartesianMotion(Motion):
 
     def compute_log_likelihoods(self, particles):
         """motion.py:181-204."""
+        z = _sample(self.dem, particles[:, 0:2])
+        z_sigma = _sample(self.dem_sigma, particles[:, 0:2])
+        nonzero = np.nonzero(z_sigma)[0]
         ll = np.zeros(len(particles), dtype=float)
-        if self.dem_sigma != 0:
-            ll[:] = 1 / (2 * self.dem_sigma ** 2) * (self.dem - particles[:, 2]) ** 2
+        ll[nonzero] = 1 / (2 * z_sigma[nonzero] ** 2) * (z[nonzero] - particles[nonzero, 2]) ** 2
         return ll
-
-
-def _scalar_surface(dem, dem_sigma, cls):
-    if not np.isscalar(dem) or dem_sigma is None or not np.isscalar(dem_sigma):
-        raise NotImplementedError(f"{cls} needs scalar dem and dem_sigma on the GPU path")
-    return float(dem), float(dem_sigma)
 
 
 def _v(x, n):
@@ -97,20 +114,21 @@ class CylindricalMotion(CartesianMotion):
 
     def __init__(self, xy, time_unit, dem, dem_sigma=None, n=1000, xy_sigma=(0, 0), vrthz=(0, 0, 0),
                  vrthz_sigma=(0, 0, 0), arthz=(0, 0, 0), arthz_sigma=(0, 0, 0)):
-        self.dem, self.dem_sigma = _scalar_surface(dem, dem_sigma, "CylindricalMotion")
+        self.dem = _surface(dem, "dem", "CylindricalMotion")
+        self.dem_sigma = _surface(dem_sigma, "dem_sigma", "CylindricalMotion")
         self.xy, self.time_unit, self.n, self.xy_sigma = xy, time_unit, int(n), xy_sigma
         self.vrthz, self.vrthz_sigma, self.arthz, self.arthz_sigma = vrthz, vrthz_sigma, arthz, arthz_sigma
 
     def params(self):
         return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(self.vrthz, 3), _v(self.vrthz_sigma, 3),
-                               _v(self.arthz, 3), _v(self.arthz_sigma, 3), [self.dem, self.dem_sigma]))
+                               _v(self.arthz, 3), _v(self.arthz_sigma, 3), self._surface_scalars()))
 
     def initialize_particles(self):
         """motion.py:262-286."""
         particles = np.zeros((self.n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * np.random.randn(self.n, 2)
-        particles[:, 2] = self.dem
-        particles[:, 2] += self.dem_sigma * np.random.randn(self.n)
+        particles[:, 2] = _sample(self.dem, particles[:, 0:2])
+        particles[:, 2] += _sample(self.dem_sigma, particles[:, 0:2]) * np.random.randn(self.n)
         v = self.vrthz + self.vrthz_sigma * np.random.randn(self.n, 3)
         particles[:, 3:6] = np.column_stack((v[:, 0] * np.cos(v[:, 1]), v[:, 0] * np.sin(v[:, 1]), v[:, 2]))
         return particles
@@ -139,7 +157,8 @@ class TangentCartesianMotion(Motion):
 
     def __init__(self, xy, time_unit, dem, dem_sigma=0, n=1000, xy_sigma=(0, 0), vxy=(0, 0), vxy_sigma=(0, 0),
                  axy=(0, 0), axy_sigma=(0, 0), slope_sigma=0):
-        self.dem, self.dem_sigma = _scalar_surface(dem, dem_sigma, type(self).__name__)
+        self.dem = _surface(dem, "dem", type(self).__name__)
+        self.dem_sigma = _surface(dem_sigma, "dem_sigma", type(self).__name__)
         self.xy, self.time_unit, self.n, self.xy_sigma = xy, time_unit, int(n), xy_sigma
         self.vxy, self.vxy_sigma, self.axy, self.axy_sigma = vxy, vxy_sigma, axy, axy_sigma
         self.slope_sigma = float(slope_sigma)
@@ -151,10 +170,12 @@ class TangentCartesianMotion(Motion):
         v, vs, a, as_ = self._v4()
         z = [0.0]
         return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(v, 2), z, _v(vs, 2), z, _v(a, 2), z,
-                               _v(as_, 2), z, [self.dem, self.dem_sigma]))
+                               _v(as_, 2), z, [0.0 if isinstance(self.dem, Raster) else self.dem,
+                                               0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma]))
 
     def params_full(self):
-        return np.concatenate((self.params(), [self.KIND, self.slope_sigma, 0, 0, 0, 0]))
+        return np.concatenate((self.params(), [self.KIND, self.slope_sigma, isinstance(self.dem, Raster),
+                                               isinstance(self.dem_sigma, Raster), 0, 0]))
 
     def _initial_velocity(self, normals):
         return self.vxy + self.vxy_sigma * normals
@@ -166,8 +187,8 @@ class TangentCartesianMotion(Motion):
         """motion.py:382-394 / :470-488."""
         particles = np.zeros((self.n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * np.random.randn(self.n, 2)
-        z_offsets = self.dem_sigma * np.random.randn(self.n)
-        particles[:, 2] = self.dem + z_offsets
+        z_offsets = _sample(self.dem_sigma, particles[:, 0:2]) * np.random.randn(self.n)
+        particles[:, 2] = _sample(self.dem, particles[:, 0:2]) + z_offsets
         particles[:, 3:5] = self._initial_velocity(np.random.randn(self.n, 2))
         return particles
 
@@ -177,10 +198,10 @@ class TangentCartesianMotion(Motion):
         time_units = dt.total_seconds() / self.time_unit.total_seconds()
         axy = self._acceleration(particles, np.random.randn(n, 2))
         dxy = time_units * particles[:, 3:5] + 0.5 * axy * time_units ** 2
-        z_offsets = particles[:, 2] - self.dem
+        z_offsets = particles[:, 2] - _sample(self.dem, particles[:, 0:2])
         z_offsets += self.slope_sigma * np.random.randn(n) * (dxy ** 2).sum(axis=1) ** 0.5
         particles[:, 0:2] += dxy
-        particles[:, 2] = self.dem + z_offsets
+        particles[:, 2] = _sample(self.dem, particles[:, 0:2]) + z_offsets
         particles[:, 3:5] += time_units * axy
 
     def compute_log_likelihoods(self, particles):

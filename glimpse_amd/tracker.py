@@ -20,10 +20,13 @@ import numpy as np
 
 from . import _lib
 from .motion import CartesianMotion, TangentCartesianMotion
+from .raster import Raster
 from .tracks import Tracks
 
 _ERRORS = (
     (_lib.PT_NAN, ValueError, "Some particles have missing (NaN) values"),
+    (_lib.PT_NOT_VISIBLE, ValueError, "Some particles are on non-visible viewshed cells"),
+    (_lib.PT_RASTER_OOB, ValueError, "Some of the sampling coordinates are out of bounds"),
     (_lib.PT_TEMPLATE_OOB, IndexError, "Box extends beyond grid bounds"),
     (_lib.PT_CONST_TILE, ValueError, "Template tile has zero variance"),
     (_lib.PT_SAMPLE_OUTSIDE, ValueError, "Some sampling points are outside box"),
@@ -47,8 +50,8 @@ class Tracker:
                  interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=320):  # noqa: B006
         """tracker.py:52-70 (+ `device`, `max_search_dim`: GPU ordinal and search-tile workspace)."""
         self.observers = list(observers)
-        if viewshed is not None:
-            raise NotImplementedError("viewshed lookups are listed under 'next' (SURVEY.md 8(f) rank 1)")
+        if viewshed is not None and not isinstance(viewshed, Raster):
+            raise TypeError("viewshed must be a glimpse_amd.Raster")
         if resample_method not in _lib.RESAMPLE:
             raise NotImplementedError(f"resample_method {resample_method!r}: the GPU path provides "
                                       f"{sorted(_lib.RESAMPLE)} ('residual' is not built)")
@@ -140,6 +143,16 @@ class Tracker:
                     ctx.observer_upload_frame(o, int(img), obs.images[img].read())
                     self._uploaded.add((o, img))
 
+    def _upload_surfaces(self, ctx, motion_models):
+        """One gridded dem, one dem_sigma (shared by every model that uses a raster) and the viewshed."""
+        for which, attr in ((_lib.RASTER_DEM, "dem"), (_lib.RASTER_DEM_SIGMA, "dem_sigma")):
+            rasters = {id(getattr(m, attr)): getattr(m, attr) for m in motion_models
+                       if isinstance(getattr(m, attr), Raster)}
+            if len(rasters) > 1:
+                raise NotImplementedError(f"all motion models must share one {attr} raster")
+            ctx.set_raster(which, next(iter(rasters.values())) if rasters else None)
+        ctx.set_raster(_lib.RASTER_VIEWSHED, self.viewshed)
+
     # ---- the tracking loop (tracker.py:225-417) ------------------------------------------------
     def track(self, motion_models, datetimes=None, maxdt=datetime.timedelta(0), tile_size=(15, 15),
               observer_mask=None, return_covariances=False, return_particles=False, reduce_particles=None,
@@ -203,6 +216,7 @@ class Tracker:
         def run(draws):
             """The frame loop (tracker.py:326-357) for all tracks at once."""
             ctx.begin_sequence(ntracks, n, tile_size)
+            self._upload_surfaces(ctx, motion_models)
             ctx.set_motion(np.stack([m.params_full() for m in motion_models]))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
             ctx.set_point_offset(point_offset)
@@ -275,17 +289,22 @@ class Tracker:
             # The reference stops drawing for a track at the frame where it fails, which shifts
             # the stream of the tracks after it: replay until the assumed consumption is consistent.
             state0 = np.random.get_state()
-            stops = np.stack((last, last), axis=1)
+            stops = np.stack((last, last, last), axis=1)
             for _ in range(ntracks + 1):
                 np.random.set_state(state0)
                 draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic,
                                          models=motion_models)
                 out_particles, out_weights, status, err_frame = run(draws)
-                new_stops = np.stack((last, last), axis=1)
+                new_stops = np.stack((last, last, last), axis=1)
                 for p in np.nonzero(status)[0]:
                     e = int(err_frame[p])
+                    # a dem / dem_sigma raster that does not cover the initial positions raises inside
+                    # initialize_particles right after randn(n, 2) (motion.py:158): nothing else is drawn
+                    gridded = isinstance(motion_models[p].dem, Raster) or isinstance(motion_models[p].dem_sigma, Raster)
+                    if e == first[p] and status[p] & _lib.PT_RASTER_OOB and gridded:
+                        new_stops[p, 2] = -1
                     new_stops[p, 0] = e
-                    new_stops[p, 1] = e if (status[p] & _lib.PT_RESAMPLE_CLAMP and not status[p] & 0x17) else e - 1
+                    new_stops[p, 1] = e if (status[p] & _lib.PT_RESAMPLE_CLAMP and not status[p] & 0x77) else e - 1
                 if (new_stops == stops).all():
                     break
                 stops = new_stops
@@ -348,6 +367,8 @@ class Tracker:
             # (motion.py:393, :404-409); the others randn(n,3) (motion.py:161, :176)
             tangent = models is not None and models[p].TANGENT
             init[p, :, 0:2] = np.random.randn(n, 2)
+            if stops.shape[1] > 2 and stops[p, 2] < 0:
+                continue  # initialize_particles raised after its first draw (see track())
             init[p, :, 2] = np.random.randn(n)
             if tangent:
                 init[p, :, 3:5] = np.random.randn(n, 2)

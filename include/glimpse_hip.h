@@ -57,8 +57,9 @@ extern "C" {
  *   CYLINDRICAL          (motion.py:207-311)  [4:7] vrthz [7:10] vrthz_sigma [10:13] arthz [13:16] arthz_sigma
  *   TANGENT_CARTESIAN    (motion.py:314-412)  [4:6] vxy [7:9] vxy_sigma [10:12] axy [13:15] axy_sigma
  *   TANGENT_CYLINDRICAL  (motion.py:415-522)  [4:6] vrth [7:9] vrth_sigma [10:12] arth [13:15] arth_sigma
- * [18] kind (GLH_MOTION_*)  [19] slope_sigma (tangent models)  [20:24] reserved.
- * dem / dem_sigma are constant surfaces (scalars) for every kind.                           */
+ * [18] kind (GLH_MOTION_*)  [19] slope_sigma (tangent models)
+ * [20] 1 = this point's dem is the context's GLH_RASTER_DEM raster (then [16] is ignored)
+ * [21] 1 = this point's dem_sigma is the GLH_RASTER_DEM_SIGMA raster  [22:24] reserved.       */
 #define GLH_MOTION_FULL_LEN 24
 #define GLH_MOTION_CARTESIAN 0
 #define GLH_MOTION_CYLINDRICAL 1
@@ -71,6 +72,8 @@ extern "C" {
 #define GLH_PT_SAMPLE_OUTSIDE 4u /* ValueError "sampling points outside"   observer.py:201 */
 #define GLH_PT_RESAMPLE_CLAMP 8u /* searchsorted returned n (IndexError in the reference)  */
 #define GLH_PT_CONST_TILE 16u    /* zero-variance template tile (reference yields NaNs)    */
+#define GLH_PT_RASTER_OOB 32u    /* ValueError "sampling coordinates are out of bounds" raster.py:961-973 */
+#define GLH_PT_NOT_VISIBLE 64u   /* ValueError "non-visible viewshed cells"  tracker.py:114-117 */
 
 /* ---- per-(observer, point) status of the last likelihood evaluation ------------------ */
 #define GLH_OBS_OK 0
@@ -136,6 +139,16 @@ int glh_set_motion_cartesian(glh_ctx* ctx, const double* params);
  * observer is skipped leaves their weights unchanged (tracker.py:146-149).  Points that are not
  * CartesianMotion run through the staged kernels.                                             */
 int glh_set_motion(glh_ctx* ctx, const double* params);
+/* Gridded surfaces (Raster, raster.py:613-): `which` = GLH_RASTER_DEM / _DEM_SIGMA (sampled
+ * bilinearly at every particle, Raster.sample order 1, raster.py:913-1027) or _VIEWSHED (nearest
+ * cell, order 0, Tracker.test_particles tracker.py:114-117).  z [ny][nx] is Raster.array; gx / gy are
+ * the ASCENDING cell-centre coordinates (Grid.x / Grid.y reversed where dx / dy < 0); sx, sy the signs
+ * of dx, dy; the limits are Grid.min / Grid.max.  z = NULL removes the raster.  nx, ny >= 2.        */
+#define GLH_RASTER_DEM 0
+#define GLH_RASTER_DEM_SIGMA 1
+#define GLH_RASTER_VIEWSHED 2
+int glh_set_raster(glh_ctx* ctx, int which, const double* z, int nx, int ny, const double* gx,
+                   const double* gy, int sx, int sy, double xmin, double xmax, double ymin, double ymax);
 /* Global index of this context's point 0 when the tracked points are sharded over several
  * contexts / GPUs (default 0).  The device RNG (GLH_RNG_PHILOX) is keyed on the GLOBAL point
  * index, so a sharded run draws exactly what the unsharded run draws.                        */
@@ -261,6 +274,12 @@ int glh_stage_ssd(int device_id, const float* search, int hs, int ws, const floa
  * uv [n][2] -> values [n]; outside [n] flags points outside the box.                         */
 int glh_stage_sample(int device_id, const float* sse, int ho, int wo, const double* box,
                      const double* uv, int n, double* values, uint8_t* outside);
+/* Raster.sample(xy, order) (raster.py:913-1027) at n points: values [n], oob [n] = 1 where the
+ * reference would raise (outside the outer limits).                                            */
+int glh_stage_raster_sample(int device_id, const double* z, int nx, int ny, const double* gx,
+                            const double* gy, int sx, int sy, double xmin, double xmax, double ymin,
+                            double ymax, const double* xy, int n, int order, double* values,
+                            uint8_t* oob);
 /* Tracker.resample_particles("systematic") on one population: idx int64 [n].                 */
 int glh_stage_resample(int device_id, const double* weights, int n, double u, int64_t* idx);
 

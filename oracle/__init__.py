@@ -27,4 +27,4 @@ Pinning (how far the oracle itself is trusted)
   once to float32.  PARITY IS UNPINNED at that single boundary: no reference
   test or fixture holds an OpenCV output for this path.
 """
-from . import camera, motion, resample, spline, ssd, tiles, tracker  # noqa: F401
+from . import camera, motion, raster, resample, spline, ssd, tiles, tracker  # noqa: F401

@@ -11,6 +11,12 @@ the very same numbers can be fed to the HIP path.
 """
 import numpy as np
 
+from .raster import Raster, sample as _surf
+
+
+def _surface(v):
+    return v if isinstance(v, Raster) else float(v)
+
 
 class CartesianMotion:
     def __init__(
@@ -28,8 +34,8 @@ class CartesianMotion:
     ):
         self.xy = np.asarray(xy, dtype=float)
         self.time_unit = time_unit
-        self.dem = float(dem)
-        self.dem_sigma = float(dem_sigma)
+        self.dem = _surface(dem)
+        self.dem_sigma = _surface(dem_sigma)
         self.n = int(n)
         self.xy_sigma = np.asarray(xy_sigma, dtype=float)
         self.vxyz = np.asarray(vxyz, dtype=float)
@@ -53,8 +59,8 @@ class CartesianMotion:
             )
         particles = np.zeros((n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * normals[:, 0:2]
-        particles[:, 2] = np.full(n, self.dem)
-        z_sigma = np.full(n, self.dem_sigma)
+        particles[:, 2] = _surf(self.dem, particles[:, 0:2])
+        z_sigma = _surf(self.dem_sigma, particles[:, 0:2])
         particles[:, 2] += z_sigma * normals[:, 2]
         particles[:, 3:6] = self.vxyz + self.vxyz_sigma * normals[:, 3:6]
         return particles, normals
@@ -71,8 +77,8 @@ class CartesianMotion:
 
     def compute_log_likelihoods(self, particles):
         """motion.py:181-204."""
-        z = np.full(len(particles), self.dem)
-        z_sigma = np.full(len(particles), self.dem_sigma)
+        z = _surf(self.dem, particles[:, 0:2])
+        z_sigma = _surf(self.dem_sigma, particles[:, 0:2])
         nonzero = np.nonzero(z_sigma)[0]
         log_likelihoods = np.zeros(len(particles), dtype=float)
         log_likelihoods[nonzero] = (
@@ -112,8 +118,8 @@ class CylindricalMotion(CartesianMotion):
             normals = np.column_stack((np.random.randn(n, 2), np.random.randn(n), np.random.randn(n, 3)))
         particles = np.zeros((n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * normals[:, 0:2]
-        particles[:, 2] = np.full(n, self.dem)
-        particles[:, 2] += np.full(n, self.dem_sigma) * normals[:, 2]
+        particles[:, 2] = _surf(self.dem, particles[:, 0:2])
+        particles[:, 2] += _surf(self.dem_sigma, particles[:, 0:2]) * normals[:, 2]
         particles[:, 3:6] = _cyl_velocity(self.vxyz + self.vxyz_sigma * normals[:, 3:6])
         return particles, normals
 
@@ -137,7 +143,7 @@ class TangentCartesianMotion:
                  vxy_sigma=(0, 0), axy=(0, 0), axy_sigma=(0, 0), slope_sigma=0.0):
         self.xy = np.asarray(xy, dtype=float)
         self.time_unit = time_unit
-        self.dem, self.dem_sigma, self.n = float(dem), float(dem_sigma), int(n)
+        self.dem, self.dem_sigma, self.n = _surface(dem), _surface(dem_sigma), int(n)
         self.xy_sigma = np.asarray(xy_sigma, dtype=float)
         self.vxy, self.vxy_sigma = np.asarray(vxy, dtype=float), np.asarray(vxy_sigma, dtype=float)
         self.axy, self.axy_sigma = np.asarray(axy, dtype=float), np.asarray(axy_sigma, dtype=float)
@@ -150,8 +156,8 @@ class TangentCartesianMotion:
             normals = np.column_stack((np.random.randn(n, 2), np.random.randn(n), np.random.randn(n, 2), np.zeros(n)))
         particles = np.zeros((n, 6), dtype=float)
         particles[:, 0:2] = self.xy + self.xy_sigma * normals[:, 0:2]
-        z_offsets = np.full(n, self.dem_sigma) * normals[:, 2]
-        particles[:, 2] = np.full(n, self.dem) + z_offsets
+        z_offsets = _surf(self.dem_sigma, particles[:, 0:2]) * normals[:, 2]
+        particles[:, 2] = _surf(self.dem, particles[:, 0:2]) + z_offsets
         v = self.vxy + self.vxy_sigma * normals[:, 3:5]
         particles[:, 3:5] = _cyl_velocity(v) if self.CYL else v
         return particles, normals
@@ -164,10 +170,10 @@ class TangentCartesianMotion:
         a = self.axy + self.axy_sigma * normals[:, 0:2]
         axy = _cyl_acceleration(particles, a) if self.CYL else a
         dxy = time_units * particles[:, 3:5] + 0.5 * axy * time_units ** 2
-        z_offsets = particles[:, 2] - np.full(n, self.dem)
+        z_offsets = particles[:, 2] - _surf(self.dem, particles[:, 0:2])
         z_offsets += self.slope_sigma * normals[:, 2] * (dxy ** 2).sum(axis=1) ** 0.5
         particles[:, 0:2] += dxy
-        particles[:, 2] = np.full(n, self.dem) + z_offsets
+        particles[:, 2] = _surf(self.dem, particles[:, 0:2]) + z_offsets
         particles[:, 3:5] += time_units * axy
         return normals
 

@@ -82,6 +82,14 @@ def update_weights(observers, imgs, templates, particles, weights, motion_model,
     return weights
 
 
+def _test_visible(viewshed, particles):
+    """Tracker.test_particles, viewshed half (tracker.py:114-117): nearest-cell lookup."""
+    if viewshed is not None:
+        is_visible = viewshed.sample(particles[:, 0:2], order=0)
+        if not all(is_visible):
+            raise ValueError("Some particles are on non-visible viewshed cells")
+
+
 def track_one(
     motion_model,
     observers,
@@ -95,6 +103,7 @@ def track_one(
     trace=None,
     capture_errors=False,
     resample_method="systematic",
+    viewshed=None,
 ):
     """One track: tracker.py:305-374 (`process`).
 
@@ -141,6 +150,7 @@ def track_one(
                     draws["init"] = normals
                 if np.isnan(particles).any():
                     raise ValueError("Some particles have missing (NaN) values")
+                _test_visible(viewshed, particles)
                 weights = np.ones(n)
             else:
                 normals = motion_model.evolve_particles(
@@ -150,6 +160,7 @@ def track_one(
                     draws["evolve"].append(normals)
                 if np.isnan(particles).any():
                     raise ValueError("Some particles have missing (NaN) values")
+                _test_visible(viewshed, particles)
             if tr is not None:
                 tr["evolved"] = particles.copy()
             at_template = observer_mask & (template_indices == i)

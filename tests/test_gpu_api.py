@@ -233,3 +233,66 @@ def test_other_motion_models_on_the_device(golden):
         np.testing.assert_allclose(tracks.sigmas, e[f"{name}_sigmas"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.particles, e[f"{name}_particles"], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.weights, e[f"{name}_weights"], rtol=RTOL, atol=1e-290)
+
+
+def test_raster_sample_on_the_device(golden):
+    """glimpse_amd.Raster.sample (glh_stage_raster_sample) against the reference: bilinear and nearest, grids
+    with decreasing y / decreasing x, half-cell border extrapolation, bounds errors (raster.py:913-1027)."""
+    g = golden("g12_raster.npz")
+    for i in range(3):
+        r = glimpse_amd.Raster(g[f"r{i}_z"], x=g[f"r{i}_xlim"], y=g[f"r{i}_ylim"])
+        np.testing.assert_array_equal(r.x, g[f"r{i}_x"])
+        np.testing.assert_array_equal(r.y, g[f"r{i}_y"])
+        np.testing.assert_allclose(r.d, g[f"r{i}_d"], rtol=1e-15)
+        np.testing.assert_allclose(r.sample(g[f"r{i}_xy"]), g[f"r{i}_linear"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_array_equal(r.sample(g[f"r{i}_xy"], order=0), g[f"r{i}_nearest"])
+        np.testing.assert_array_equal(r.inbounds_xy(g[f"r{i}_mixed_xy"]), g[f"r{i}_mixed_in"])
+        with pytest.raises(ValueError):
+            r.sample(g[f"r{i}_mixed_xy"])
+        filled = r.sample(g[f"r{i}_mixed_xy"], bounds_error=False, fill_value=-7.0)
+        assert (filled[~g[f"r{i}_mixed_in"]] == -7.0).all() and (filled[g[f"r{i}_mixed_in"]] != -7.0).all()
+
+
+def test_gridded_surfaces_end_to_end(golden):
+    """Tracker.track on a gridded dem / dem_sigma (CartesianMotion), a tangent model on a gridded dem, and a
+    viewshed (tracker.py:114-117), incl. tracks the surfaces do not cover (ValueError captured, NaN rows),
+    against reference runs with the same seeds."""
+    import datetime
+
+    from tests.helpers_api import camera_from
+
+    g = golden("g12_raster_e2e.npz")
+    t0, day = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    images = [glimpse_amd.Image("synthetic", cam=camera_from(g["cam"]), datetime=t0 + i * day, array=g["frames"][i])
+              for i in range(len(g["frames"]))]
+    dem = glimpse_amd.Raster(g["dem"], x=g["xlim"], y=g["ylim"])
+    dem_sigma = glimpse_amd.Raster(g["dem_sigma"], x=g["xlim"], y=g["ylim"])
+    viewshed = glimpse_amd.Raster(g["viewshed"], x=g["xlim"], y=g["ylim"])
+    cart = dict(time_unit=day, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02),
+                axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01))
+    cases = {
+        "cart": (1301, [glimpse_amd.CartesianMotion(xy=xy, dem=dem, dem_sigma=dem_sigma, **cart)
+                        for xy in [(0.5, -0.5), (-2.0, 1.5), (7.5, 0.0)]], {}),
+        "tcart": (1302, [glimpse_amd.TangentCartesianMotion(xy=xy, time_unit=day, dem=dem, dem_sigma=0.2, n=150,
+                                                            xy_sigma=(0.2, 0.2), vxy=(0.15, 0.0), vxy_sigma=(0.2, 0.2),
+                                                            axy=(0, 0), axy_sigma=(0.05, 0.05), slope_sigma=0.1)
+                         for xy in [(-1.0, 1.0), (1.5, 0.5)]], {}),
+        "view": (1303, [glimpse_amd.CartesianMotion(xy=xy, dem=0.0, dem_sigma=0.3, **cart)
+                        for xy in [(0.5, -0.5), (3.5, 1.0)]], dict(viewshed=viewshed)),
+    }
+    for name, (seed, models, kw) in cases.items():
+        tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128, **kw)
+        np.random.seed(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+        errors = g[f"{name}_errors"].astype(bool)
+        assert [e is not None for e in tracks.errors] == list(errors), name
+        for p in np.nonzero(errors)[0]:
+            assert type(tracks.errors[p]).__name__ == str(g[f"{name}_error_types"][p])
+            assert np.isnan(tracks.means[p]).all()
+        ok = ~errors
+        np.testing.assert_allclose(tracks.means[ok], g[f"{name}_means"][ok], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.sigmas[ok], g[f"{name}_sigmas"][ok], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.particles[ok], g[f"{name}_particles"][ok], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(tracks.weights[ok], g[f"{name}_weights"][ok], rtol=RTOL, atol=1e-290)

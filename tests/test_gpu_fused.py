@@ -181,3 +181,54 @@ def test_fused_step_edge_cases_match_staged(lib):
         np.testing.assert_array_equal(o["w"], ref["w"])
         ok = [0, 1, 2, 3, 5]
         np.testing.assert_allclose(o["m"][:, ok], ref["m"][:, ok], rtol=1e-12, atol=1e-13)
+
+
+def test_fused_step_with_gridded_surfaces_equals_staged(lib):
+    """Gridded dem / dem_sigma (bilinear Raster.sample per particle, raster.py:913-1027) and a viewshed inside
+    the fused kernel (its SURF variant) against the staged kernels, device RNG."""
+    import glimpse_amd
+    from glimpse_amd import workloads
+
+    T, P, N = 4, 5, 1300
+    wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [wl.frames(0)]
+    rng = np.random.default_rng(9)
+    lim = (-40.0, 40.0)
+    dem = glimpse_amd.Raster(0.05 * rng.standard_normal((33, 41)), x=lim, y=(40.0, -40.0))
+    dem_sigma = glimpse_amd.Raster(0.3 + 0.1 * rng.random((17, 19)), x=lim, y=lim)
+    vis = np.ones((16, 16))
+    vis[:, :2] = 0  # western strip hidden: points there raise the NOT_VISIBLE bit
+    viewshed = glimpse_amd.Raster(vis, x=lim, y=lim)
+    params = np.zeros((P, lib.MOTION_FULL_LEN))
+    params[:, :18] = wl.params
+    params[:, 7:10] = (0.2, 0.2, 0.05)
+    params[:, 13:16] = (0.05, 0.05, 0.01)
+    params[:, 20] = 1.0
+    params[:, 21] = 1.0
+    params[3, 0:2] = (-31.0, 3.0)  # inside the hidden strip (and far from the image border)
+    out = []
+    for mode in (1, 0):
+        with lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
+            workloads.setup_context(ctx, wl, frames)
+            ctx.set_raster(lib.RASTER_DEM, dem)
+            ctx.set_raster(lib.RASTER_DEM_SIGMA, dem_sigma)
+            ctx.set_raster(lib.RASTER_VIEWSHED, viewshed)
+            ctx.set_motion(params)
+            ctx.set_fused(mode)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=21)
+            ctx.init_templates(0, 0)
+            ctx.record_moments(0)
+            for i in range(1, T):
+                ctx.step(i, 1.0, [i], seed=21)
+            out.append(dict(p=ctx.get_particles(), w=ctx.get_weights(), st=ctx.point_status(),
+                            ef=ctx.point_error_frame(), m=ctx.get_moments(0, T)))
+    fused, staged = out
+    assert staged["st"][3] & lib.PT_NOT_VISIBLE and staged["st"][0] == 0
+    np.testing.assert_array_equal(fused["st"], staged["st"])
+    np.testing.assert_array_equal(fused["ef"], staged["ef"])
+    np.testing.assert_array_equal(fused["p"], staged["p"])
+    np.testing.assert_array_equal(fused["w"], staged["w"])
+    np.testing.assert_allclose(fused["m"], staged["m"], rtol=1e-12, atol=1e-13)
+    # the DEM term acts: z stays near the surface (sigma ~0.3) although vz noise accumulates
+    assert np.abs(fused["m"][-1, 0, 2]) < 1.0

@@ -258,3 +258,58 @@ def test_other_motion_models_match_reference(golden):
         assert (ll is not None) == bool(g[f"{name}_has_ll"])
         if ll is not None:
             np.testing.assert_allclose(ll, g[f"{name}_ll"], rtol=1e-13)
+
+
+def test_raster_sampling_matches_reference(golden):
+    """Raster.sample at points, orders 0 and 1, on grids with decreasing y / decreasing x (raster.py:913-1027)."""
+    from oracle import raster as oraster
+
+    g = golden("g12_raster.npz")
+    for i in range(3):
+        r = oraster.Raster(g[f"r{i}_z"], x=g[f"r{i}_xlim"], y=g[f"r{i}_ylim"])
+        np.testing.assert_array_equal(r._centres(0), g[f"r{i}_x"])
+        np.testing.assert_array_equal(r._centres(1), g[f"r{i}_y"])
+        np.testing.assert_allclose(r.sample(g[f"r{i}_xy"]), g[f"r{i}_linear"], rtol=1e-13, atol=1e-14)
+        np.testing.assert_array_equal(r.sample(g[f"r{i}_xy"], order=0), g[f"r{i}_nearest"])
+        with pytest.raises(ValueError):
+            r.sample(g[f"r{i}_mixed_xy"])
+
+
+def _e2e_rasters(g, mod):
+    dem = mod.Raster(g["dem"], x=g["xlim"], y=g["ylim"])
+    dem_sigma = mod.Raster(g["dem_sigma"], x=g["xlim"], y=g["ylim"])
+    viewshed = mod.Raster(g["viewshed"], x=g["xlim"], y=g["ylim"])
+    return dem, dem_sigma, viewshed
+
+
+def test_gridded_surfaces_end_to_end_match_reference(golden):
+    """Tracks on a gridded dem / dem_sigma, a tangent model on a gridded dem, a viewshed, and surfaces
+    that do not cover a track (ValueError captured, NaN rows), with the oracle on the reference's seeds."""
+    from oracle import raster as oraster
+
+    g = golden("g12_raster_e2e.npz")
+    dem, dem_sigma, viewshed = _e2e_rasters(g, oraster)
+    T = len(g["frames"])
+    observers = [tracker.Observer(list(g["frames"]), np.tile(g["cam"], (T, 1)), 0.3)]
+    matching, taus = np.arange(T)[:, None], np.ones(T - 1)
+    cart = dict(n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02), axyz=(0, 0, 0),
+                axyz_sigma=(0.05, 0.05, 0.01))
+    cases = {
+        "cart": (1301, [motion.CartesianMotion(xy=xy, dem=dem, dem_sigma=dem_sigma, **cart)
+                        for xy in [(0.5, -0.5), (-2.0, 1.5), (7.5, 0.0)]], {}),
+        "tcart": (1302, [motion.TangentCartesianMotion(xy=xy, dem=dem, dem_sigma=0.2, n=150, xy_sigma=(0.2, 0.2),
+                                                       vxy=(0.15, 0.0), vxy_sigma=(0.2, 0.2), axy=(0, 0),
+                                                       axy_sigma=(0.05, 0.05), slope_sigma=0.1)
+                         for xy in [(-1.0, 1.0), (1.5, 0.5)]], {}),
+        "view": (1303, [motion.CartesianMotion(xy=xy, dem=0.0, dem_sigma=0.3, **cart) for xy in [(0.5, -0.5), (3.5, 1.0)]],
+                 dict(viewshed=viewshed)),
+    }
+    for name, (seed, models, kw) in cases.items():
+        np.random.seed(seed)
+        res = tracker.track(models, observers, matching, taus, tile_size=(15, 15), **kw)
+        errors = g[f"{name}_errors"].astype(bool)
+        assert [e is not None for e in res["errors"]] == list(errors)
+        ok = ~errors
+        np.testing.assert_allclose(res["means"][ok], g[f"{name}_means"][ok], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(res["sigmas"][ok], g[f"{name}_sigmas"][ok], rtol=1e-9, atol=1e-14)
+        assert np.isnan(res["means"][errors]).all()

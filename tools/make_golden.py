@@ -571,6 +571,87 @@ def g11_motion_models():
     print("g11 e2e vx:", {k: e2e[f"{k}_means"][0, -1, 3] for k in models})
 
 
+def _dem_field(nx, ny, xlim, ylim, seed):
+    """A gentle sloping surface with bumps on the cell centres of a grid."""
+    rng = np.random.default_rng(seed)
+    r = glimpse.Raster(np.zeros((ny, nx)), x=xlim, y=ylim)
+    X, Y = r.X, r.Y
+    return 0.05 * X - 0.03 * Y + 0.2 * np.sin(0.7 * X) * np.cos(0.5 * Y) + 0.02 * rng.standard_normal((ny, nx))
+
+
+def g12_rasters():
+    """Gridded surfaces (raster.py:613-1027): Raster.sample unit vectors (orders 0 and 1, decreasing y,
+    decreasing x, half-cell border extrapolation, out-of-bounds mask) and end-to-end tracks with a
+    gridded dem / dem_sigma, a tangent model on a gridded dem, a viewshed and surfaces that do not
+    cover every track."""
+    rng = np.random.default_rng(1212)
+    out = {}
+    specs = [((25, 21), (-12.0, 12.0), (10.0, -10.0)),      # north-up: y decreases along rows
+             ((8, 5), (100.0, 108.0), (50.0, 44.0)),
+             ((6, 9), (3.0, -3.0), (0.0, 4.5))]             # x decreases along columns
+    for i, ((nx, ny), xlim, ylim) in enumerate(specs):
+        Z = _dem_field(nx, ny, xlim, ylim, 40 + i)
+        r = glimpse.Raster(Z, x=xlim, y=ylim)
+        lo, hi = r.min, r.max
+        xy = lo + (hi - lo) * rng.random((300, 2))
+        xy[:8] = [lo, hi, (lo[0], hi[1]), (hi[0], lo[1]), (lo + hi) / 2, r.xy[0] if hasattr(r, "xy") else (lo + hi) / 2,
+                  (r.x[0], r.y[0]), (r.x[-1], r.y[-1])]
+        xy[8:12] = [(r.x[1], r.y[2]), (r.x[2], 0.5 * (r.y[1] + r.y[2])), (0.5 * (r.x[0] + r.x[1]), r.y[1]),
+                    (r.x[0], r.y[-1])]
+        out[f"r{i}_z"], out[f"r{i}_xlim"], out[f"r{i}_ylim"] = Z, np.array(xlim), np.array(ylim)
+        out[f"r{i}_x"], out[f"r{i}_y"], out[f"r{i}_d"] = r.x, r.y, r.d
+        out[f"r{i}_xy"] = xy
+        out[f"r{i}_linear"] = r.sample(xy)
+        out[f"r{i}_nearest"] = r.sample(xy, order=0)
+        far = np.vstack((xy[:20] + (hi - lo) * [1.2, 0], xy[20:40] - (hi - lo) * [0, 1.1], xy[40:60]))
+        out[f"r{i}_mixed_xy"] = far
+        out[f"r{i}_mixed_in"] = r.inbounds_xy(far)
+    np.savez_compressed(os.path.join(OUT, "g12_raster.npz"), **out)
+
+    # ---- end to end
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam = synth.nadir_camera((192, 192), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 4, seed=21, velocity=(0.15, 0.0))
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(4)]
+    xlim, ylim = (-6.0, 6.0), (6.0, -6.0)
+    Zd = 0.1 * _dem_field(24, 24, xlim, ylim, 7)
+    Zs = 0.2 + 0.05 * np.abs(_dem_field(24, 24, xlim, ylim, 8))
+    dem, dem_sigma = glimpse.Raster(Zd, x=xlim, y=ylim), glimpse.Raster(Zs, x=xlim, y=ylim)
+    vis = np.ones((12, 12))
+    vis[:, 9:] = 0  # the eastern quarter of the scene is not visible
+    viewshed = glimpse.Raster(vis, x=xlim, y=ylim)
+    e = {"frames": np.stack(frames), "cam": cam, "dem": Zd, "dem_sigma": Zs, "viewshed": vis,
+         "xlim": np.array(xlim), "ylim": np.array(ylim)}
+
+    def run(name, models, seed, **tracker_kw):
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)], **tracker_kw)
+        np.random.seed(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+        e[f"{name}_means"], e[f"{name}_sigmas"] = tracks.means, tracks.sigmas
+        e[f"{name}_particles"], e[f"{name}_weights"] = tracks.particles, tracks.weights
+        e[f"{name}_errors"] = np.array([0 if x is None else 1 for x in tracks.errors])
+        e[f"{name}_error_types"] = np.array(["" if x is None else type(x).__name__ for x in tracks.errors])
+        print(name, "errors", e[f"{name}_errors"], "vx", tracks.means[:, -1, 3])
+
+    cart = dict(time_unit=day, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02),
+                axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01))
+    # A: gridded dem + gridded dem_sigma; the third track starts outside the rasters (ValueError at init)
+    run("cart", [glimpse.CartesianMotion(xy=xy, dem=dem, dem_sigma=dem_sigma, **cart)
+                 for xy in [(0.5, -0.5), (-2.0, 1.5), (7.5, 0.0)]], 1301)
+    # B: gridded dem, scalar dem_sigma, tangent model
+    run("tcart", [glimpse.TangentCartesianMotion(xy=xy, time_unit=day, dem=dem, dem_sigma=0.2, n=150,
+                                                 xy_sigma=(0.2, 0.2), vxy=(0.15, 0.0), vxy_sigma=(0.2, 0.2),
+                                                 axy=(0, 0), axy_sigma=(0.05, 0.05), slope_sigma=0.1)
+                  for xy in [(-1.0, 1.0), (1.5, 0.5)]], 1302)
+    # C: viewshed: the second track sits in the non-visible strip (ValueError from test_particles)
+    run("view", [glimpse.CartesianMotion(xy=xy, dem=0.0, dem_sigma=0.3, **cart) for xy in [(0.5, -0.5), (3.5, 1.0)]],
+        1303, viewshed=viewshed)
+    np.savez_compressed(os.path.join(OUT, "g12_raster_e2e.npz"), **e)
+
+
 def g10_tracks():
     """Tracks.reverse / from_multiple / average (tracks.py:131-213) on synthetic result arrays with
     missing rows, e.g. merging a forward and a backward run."""
@@ -614,6 +695,9 @@ def g10_tracks():
 
 
 if __name__ == "__main__":
+    if "--g12" in sys.argv:
+        g12_rasters()
+        sys.exit(0)
     if "--g11" in sys.argv:
         g11_motion_models()
         sys.exit(0)
@@ -634,5 +718,6 @@ if __name__ == "__main__":
     g9_variants()
     g10_tracks()
     g11_motion_models()
+    g12_rasters()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
