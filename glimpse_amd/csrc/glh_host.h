@@ -11,6 +11,18 @@
 namespace glh {
 
 inline void expand_camera(const double* v, CamDev* c) {
+  *c = CamDev{};
+  if (v[23] != 0.0) {
+    // georeferenced raster image (Grid, raster.py:25-98): [0:2] (xlim[0], ylim[0]), [6:8] size, [8:10] d
+    c->is_grid = 1;
+    c->xyz[0] = v[0];
+    c->xyz[1] = v[1];
+    c->imgsz[0] = v[6];
+    c->imgsz[1] = v[7];
+    c->f[0] = v[8];
+    c->f[1] = v[9];
+    return;
+  }
   const double d2r = M_PI / 180.0;
   // np.deg2rad(viewdir); C = cos, S = sin (camera.py:261-263)
   double C[3], S[3];

@@ -34,16 +34,21 @@ struct CamDev {
   int32_t any_k;    // any(self.k)              (camera.py:1188)
   int32_t any_kden; // any(self.k[3:6])         (camera.py:1152)
   int32_t any_p;    // any(self.p)
+  int32_t is_grid;  // georeferenced raster image instead of a camera (Grid.xyz_to_uv, raster.py:423-445):
+                    // xyz[0:2] = (xlim[0], ylim[0]), f = d (cell size, signed), imgsz = size
+  int32_t pad_;
 };
 
 // Which optional terms of the projection are active, as one word: the tests of the reference
 // (`if self.correction`, `any(self.k)`, `if self.k[i]`, ... camera.py:1148-1196, :1446) depend on
 // the camera only, so a kernel can take them from a scalar register and branch uniformly.
 enum : uint32_t {
-  CAM_F_CORR = 1u, CAM_F_ANYK = 2u, CAM_F_ANYKDEN = 4u, CAM_F_ANYP = 8u, CAM_F_K0 = 16u  // K0 << i: k[i] != 0
+  CAM_F_CORR = 1u, CAM_F_ANYK = 2u, CAM_F_ANYKDEN = 4u, CAM_F_ANYP = 8u, CAM_F_K0 = 16u,  // K0 << i: k[i] != 0
+  CAM_F_GRID = 1024u
 };
 GLH_HD uint32_t cam_flags(const CamDev& c) {
   uint32_t f = 0;
+  if (c.is_grid) return CAM_F_GRID;
   if (c.has_corr) f |= CAM_F_CORR;
   if (c.any_k) f |= CAM_F_ANYK;
   if (c.any_kden) f |= CAM_F_ANYKDEN;
@@ -56,6 +61,11 @@ GLH_HD uint32_t cam_flags(const CamDev& c) {
 // Camera.xyz_to_uv (camera.py:591-628): _xyz_to_xy (:1435-1470), _distort (:1180-1196 with
 // :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).  `f` = cam_flags(c).
 GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
+  if (f & CAM_F_GRID) {  // Grid.xyz_to_uv: (xy - (xlim[0], ylim[0])) / d
+    u = (x - c.xyz[0]) / c.f[0];
+    v = (y - c.xyz[1]) / c.f[1];
+    return;
+  }
   double dx = x - c.xyz[0];
   double dy = y - c.xyz[1];
   double dz = z - c.xyz[2];

@@ -65,6 +65,35 @@ class Raster:
         """Cell-centre y from the first to the last row (raster.py:149-165)."""
         return self._centres(1)
 
+    # ---- a Raster as an Observer image (orthophoto tracking; observer.py:26, :113, :129, :144)
+    @property
+    def vector24(self):
+        """GLH_CAM_LEN layout in its georeferenced-raster form (include/glimpse_hip.h, entry [23] = 1)."""
+        v = np.zeros(_lib.CAM_LEN)
+        v[0], v[1] = self.xlim[0], self.ylim[0]
+        v[6:8] = self.size
+        v[8:10] = self.d
+        v[23] = 1.0
+        return v
+
+    def xyz_to_uv(self, xyz):
+        """Grid.xyz_to_uv (raster.py:423-445), evaluated by the projection kernel."""
+        xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
+        if xyz.shape[1] == 2:
+            xyz = np.column_stack((xyz, np.zeros(len(xyz))))
+        return _lib.stage_project(self.vector24, xyz)
+
+    def inbounds(self, uv):
+        """Grid.inbounds (raster.py:339-341)."""
+        uv = np.atleast_2d(np.asarray(uv, dtype=float))
+        return np.all((uv >= 0) & (uv <= self.size), axis=1)
+
+    def read(self, box=None, cache=True):
+        """Raster.read of an in-memory array (raster.py:763-837): the window [top:bottom, left:right]."""
+        if box is None:
+            return self.array
+        return self.array[box[1]:box[3], box[0]:box[2]]
+
     def inbounds_xy(self, xy):
         """raster.py:313-337 (points)."""
         xy = np.atleast_2d(np.asarray(xy, dtype=float))

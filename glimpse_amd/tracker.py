@@ -36,6 +36,11 @@ _OOB_WARNING = "Particles too close to or beyond image bounds, skipping image"
 _MAX_HOST_DRAWS_BYTES = 4 << 30
 
 
+def _vector24(img):
+    """Camera vector of an Observer image: an Image's camera, or a Raster's own grid (observer.py:26)."""
+    return img.cam.vector24 if hasattr(img, "cam") else img.vector24
+
+
 def _timestamps(dts):
     return np.array([d.timestamp() for d in dts], dtype=float)
 
@@ -131,7 +136,7 @@ class Tracker:
             h, w = first.shape[:2]
             ch = 1 if first.ndim == 2 else first.shape[2]
             ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
-            ctx.observer_set_cameras(o, np.stack([img.cam.vector24 for img in obs.images]))
+            ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
         self._ctx, self._ctx_key = ctx, key
         self._uploaded = set()
         return ctx
@@ -401,7 +406,7 @@ class Tracker:
                 a0 = obs.images[0].read()
                 ctx.observer_init(o, len(obs.images), a0.shape[1], a0.shape[0], 1 if a0.ndim == 2 else a0.shape[2],
                                   obs.sigma)
-                ctx.observer_set_cameras(o, np.stack([img.cam.vector24 for img in obs.images]))
+                ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
             ctx.begin_sequence(1, n, tile)
             ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
             self._sctx, self._sctx_key, self._single_tile, self._s_uploaded = ctx, key, tuple(tile), set()

@@ -43,7 +43,11 @@ extern "C" {
 /* ---- camera vector ------------------------------------------------------------------ */
 /* [0:3] xyz  [3:6] viewdir(deg)  [6:8] imgsz  [8:10] f  [10:12] c  [12:18] k1..k6
  * [18:20] p1,p2   -- exactly Camera._vector (camera.py:101, :128-198) --
- * [20] correction flag  [21] radius  [22] refraction (camera.py:118-121)  [23] unused     */
+ * [20] correction flag  [21] radius  [22] refraction (camera.py:118-121)
+ * [23] 0 = camera.  1 = georeferenced raster image (an orthophoto observer, Raster as image,
+ *      track/observer.py:26): world -> image is Grid.xyz_to_uv (raster.py:423-445),
+ *      uv = (xy - (xlim[0], ylim[0])) / d, with [0:2] = (xlim[0], ylim[0]), [6:8] = size,
+ *      [8:10] = d (signed cell size); every other entry is ignored.                            */
 #define GLH_CAM_LEN 24
 
 /* ---- motion parameters (CartesianMotion, track/motion.py:121-147) ------------------- */

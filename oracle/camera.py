@@ -15,7 +15,9 @@ A camera is a float64 vector of CAM_LEN = 24 values:
   [0:3]  xyz        [3:6]  viewdir (deg: yaw, pitch, roll)
   [6:8]  imgsz      [8:10] f        [10:12] c
   [12:18] k1..k6    [18:20] p1, p2
-  [20] correction flag (0/1)   [21] radius   [22] refraction   [23] unused
+  [20] correction flag (0/1)   [21] radius   [22] refraction
+  [23] 0 camera; 1 georeferenced raster image (Grid.xyz_to_uv, raster.py:423-445) with
+       [0:2] = (xlim[0], ylim[0]), [6:8] = size, [8:10] = d
 The first 20 entries are exactly the reference's `_vector`.
 """
 import numpy as np
@@ -131,8 +133,21 @@ def distort(cam, xy):
     return dxy
 
 
+def grid_vector(size, xlim, ylim):
+    """CAM_LEN vector of a raster image (an orthophoto observer image)."""
+    v = np.zeros(CAM_LEN, dtype=float)
+    v[0], v[1] = xlim[0], ylim[0]
+    v[6:8] = size
+    v[8:10] = (np.diff(xlim)[0] / size[0], np.diff(ylim)[0] / size[1])
+    v[23] = 1.0
+    return v
+
+
 def xyz_to_uv(cam, xyz):
     """camera.py:591-628 / :1499-1508: uv = distort(xy) * f + (imgsz / 2 + c)."""
+    if cam[23] != 0:  # Grid.xyz_to_uv (raster.py:445)
+        xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
+        return (xyz[:, 0:2] - (cam[0], cam[1])) / cam[8:10]
     xy = xyz_to_xy(cam, np.atleast_2d(xyz))
     xy = distort(cam, xy)
     return xy * cam[8:10] + (cam[6:8] / 2 + cam[10:12])

@@ -296,3 +296,31 @@ def test_gridded_surfaces_end_to_end(golden):
         np.testing.assert_allclose(tracks.sigmas[ok], g[f"{name}_sigmas"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.particles[ok], g[f"{name}_particles"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.weights[ok], g[f"{name}_weights"][ok], rtol=RTOL, atol=1e-290)
+
+
+def test_orthophoto_observer_on_the_device(golden):
+    """Observer([Raster, ...]) (observer.py:26): projection through Grid.xyz_to_uv (raster.py:423-445) on the
+    device and a two-track run against the reference with the same seed."""
+    import datetime
+
+    g = golden("g13_ortho.npz")
+    t0, day = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    rasters = [glimpse_amd.Raster(g["frames"][i], x=g["xlim"], y=g["ylim"], datetime=t0 + i * day)
+               for i in range(len(g["frames"]))]
+    np.testing.assert_allclose(rasters[0].xyz_to_uv(g["xyz"]), g["uv"], rtol=1e-15, atol=1e-13)
+    odd = glimpse_amd.Raster(np.zeros((7, 5)), x=g["odd_xlim"], y=g["odd_ylim"])
+    np.testing.assert_allclose(odd.xyz_to_uv(g["xyz"] + [95, 10, 0]), g["odd_uv"], rtol=1e-15, atol=1e-13)
+    assert rasters[0].inbounds(np.array([[0, 0], [192, 192], [193, 5]])).tolist() == [True, True, False]
+    models = [glimpse_amd.CartesianMotion(xy=xy, time_unit=day, dem=0.0, dem_sigma=0.0, n=150, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0)) for xy in [(0.5, -0.5), (-2.0, 1.5)]]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(rasters, sigma=0.3)], max_search_dim=128)
+    np.random.seed(1314)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.particles, g["particles"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.weights, g["weights"], rtol=RTOL, atol=1e-290)

@@ -313,3 +313,21 @@ def test_gridded_surfaces_end_to_end_match_reference(golden):
         np.testing.assert_allclose(res["means"][ok], g[f"{name}_means"][ok], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(res["sigmas"][ok], g[f"{name}_sigmas"][ok], rtol=1e-9, atol=1e-14)
         assert np.isnan(res["means"][errors]).all()
+
+
+def test_orthophoto_observer_matches_reference(golden):
+    """Raster images as observer images: Grid.xyz_to_uv (raster.py:423-445) and a two-track run."""
+    g = golden("g13_ortho.npz")
+    T = len(g["frames"])
+    vec = camera.grid_vector((192, 192), g["xlim"], g["ylim"])
+    np.testing.assert_allclose(camera.xyz_to_uv(vec, g["xyz"]), g["uv"], rtol=1e-15, atol=1e-13)
+    odd = camera.grid_vector((5, 7), g["odd_xlim"], g["odd_ylim"])
+    np.testing.assert_allclose(camera.xyz_to_uv(odd, g["xyz"] + [95, 10, 0]), g["odd_uv"], rtol=1e-15, atol=1e-13)
+    observers = [tracker.Observer(list(g["frames"]), np.tile(vec, (T, 1)), 0.3)]
+    models = [motion.CartesianMotion(xy=xy, dem=0.0, dem_sigma=0.0, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                                     vxyz_sigma=(0.2, 0.2, 0), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0))
+              for xy in [(0.5, -0.5), (-2.0, 1.5)]]
+    np.random.seed(1314)
+    res = tracker.track(models, observers, np.arange(T)[:, None], np.ones(T - 1), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g["means"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["sigmas"], g["sigmas"], rtol=1e-9, atol=1e-14)

@@ -652,6 +652,35 @@ def g12_rasters():
     np.savez_compressed(os.path.join(OUT, "g12_raster_e2e.npz"), **e)
 
 
+def g13_ortho():
+    """Raster images as Observer images (orthophoto tracking; observer.py:26, Grid.xyz_to_uv raster.py:423-445):
+    projection unit vectors and a two-track run (one RGB orthophoto sequence, y decreasing along rows)."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam = synth.nadir_camera((192, 192), f=1000.0, height=100.0)
+    frames, _ = synth.make_sequence(cam, 4, seed=21, velocity=(0.15, 0.0), channels=1)
+    xlim, ylim = (-9.6, 9.6), (9.6, -9.6)  # the nadir pinhole frame is an orthophoto at 10 px per unit
+    rasters = [glimpse.Raster(frames[i], x=xlim, y=ylim, datetime=t0 + i * day) for i in range(4)]
+    rng = np.random.default_rng(1313)
+    xyz = np.column_stack((rng.uniform(-12, 12, 64), rng.uniform(-12, 12, 64), rng.uniform(-1, 1, 64)))
+    out = {"frames": np.stack(frames), "xlim": np.array(xlim), "ylim": np.array(ylim), "xyz": xyz,
+           "uv": rasters[0].xyz_to_uv(xyz)}
+    odd = glimpse.Raster(np.zeros((7, 5)), x=(100.0, 90.0), y=(3.0, 17.0))  # x decreases along columns
+    out["odd_xlim"], out["odd_ylim"], out["odd_uv"] = np.array((100.0, 90.0)), np.array((3.0, 17.0)), odd.xyz_to_uv(xyz + [95, 10, 0])
+    models = [glimpse.CartesianMotion(xy=xy, time_unit=day, dem=0.0, dem_sigma=0.0, n=150, xy_sigma=(0.2, 0.2),
+                                      vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0), axyz=(0, 0, 0),
+                                      axyz_sigma=(0.05, 0.05, 0)) for xy in [(0.5, -0.5), (-2.0, 1.5)]]
+    tracker = glimpse.Tracker([glimpse.Observer(rasters, sigma=0.3)])
+    np.random.seed(1314)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    out["means"], out["sigmas"] = tracks.means, tracks.sigmas
+    out["particles"], out["weights"] = tracks.particles, tracks.weights
+    print("g13 vx:", tracks.means[:, -1, 3], "errors", tracks.errors)
+    np.savez_compressed(os.path.join(OUT, "g13_ortho.npz"), **out)
+
+
 def g10_tracks():
     """Tracks.reverse / from_multiple / average (tracks.py:131-213) on synthetic result arrays with
     missing rows, e.g. merging a forward and a backward run."""
@@ -695,6 +724,9 @@ def g10_tracks():
 
 
 if __name__ == "__main__":
+    if "--g13" in sys.argv:
+        g13_ortho()
+        sys.exit(0)
     if "--g12" in sys.argv:
         g12_rasters()
         sys.exit(0)
@@ -719,5 +751,6 @@ if __name__ == "__main__":
     g10_tracks()
     g11_motion_models()
     g12_rasters()
+    g13_ortho()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
