@@ -103,6 +103,8 @@ SIGNATURES = {
     "glh_stage_name": (C.c_char_p, [_I]),
     "glh_profile_get": (_I, [_P, _P, _P]),
     "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
+    "glh_stage_project_directions": (_I, [_I, _P, _P, _I, _P]),
+    "glh_stage_unproject": (_I, [_I, _P, _P, _I, _P, _I, _I, _P]),
     "glh_stage_template": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "glh_stage_search_tile": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
@@ -421,12 +423,23 @@ class Context:
 
 
 # ---- stateless stage hooks (parity tests) -----------------------------------------------
-def stage_project(cam, xyz, device_id=0):
+def stage_project(cam, xyz, device_id=0, directions=False):
     cam = _arr(cam, np.float64, (CAM_LEN,))
     xyz = _arr(xyz, np.float64)
     uv = np.empty((len(xyz), 2))
-    check(load().glh_stage_project(device_id, _ptr(cam), _ptr(xyz), len(xyz), _ptr(uv)))
+    fn = load().glh_stage_project_directions if directions else load().glh_stage_project
+    check(fn(device_id, _ptr(cam), _ptr(xyz), len(xyz), _ptr(uv)))
     return uv
+
+
+def stage_unproject(cam, uv, depth=None, directions=True, device_id=0):
+    cam = _arr(cam, np.float64, (CAM_LEN,))
+    uv = _arr(uv, np.float64)
+    d = None if depth is None else _arr(np.atleast_1d(depth), np.float64)
+    xyz = np.empty((len(uv), 3))
+    check(load().glh_stage_unproject(device_id, _ptr(cam), _ptr(uv), len(uv), _ptr(d), 0 if d is None else len(d),
+                                     int(bool(directions)), _ptr(xyz)))
+    return xyz
 
 
 def _frame_dims(frame):

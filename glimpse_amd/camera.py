@@ -3,9 +3,9 @@
 Same constructor and attributes as the reference (/root/reference/src/glimpse/camera.py:77-123,
 state vector `_vector[20]` :101, :128-198).  `xyz_to_uv` (camera.py:591-628) -- the projection
 half that sits on the Tracker hot path -- runs on the GPU through libglimpse_hip.so; there is no
-CPU fallback for it.  The inverse projection (`uv_to_xyz`, camera.py:630-663) is host NumPy: it
-is not on the per-frame path (it is used to render synthetic frames and is listed under
-"next" in SURVEY.md 8(f)).  Calibration / rendering methods are out of scope.
+CPU fallback for it.  The inverse projection (`uv_to_xyz`, camera.py:630-663, with the k1 closed form
+and the Oulu undistortion, :1198-1337) runs on the GPU as well (`glh_stage_unproject`); it is not on
+the per-frame path.  Calibration / rendering methods are out of scope.
 """
 import numpy as np
 
@@ -120,11 +120,11 @@ class Camera:
 
     # ---- projection (hot path: GPU)
     def xyz_to_uv(self, xyz, directions=False, return_depth=False):
-        """camera.py:591-628, evaluated by the `glh_stage_project` kernel."""
-        if directions or return_depth:
-            raise NotImplementedError("directions / return_depth are not on the tracking path")
+        """camera.py:591-628, evaluated by the projection kernel (`directions=True`: xyz are rays, :1448)."""
+        if return_depth:
+            raise NotImplementedError("return_depth is not on the tracking path")
         xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
-        return _lib.stage_project(self.vector24, xyz)
+        return _lib.stage_project(self.vector24, xyz, directions=directions)
 
     def inframe(self, uv):
         """camera.py:700-718."""
@@ -133,20 +133,8 @@ class Camera:
             return np.all((uv >= 0) & (uv <= self.imgsz), axis=1)
 
     def uv_to_xyz(self, uv, directions=True, depth=1):
-        """camera.py:630-663 (host NumPy, Oulu undistortion camera.py:1305-1337); not on the hot path."""
+        """camera.py:630-663 on the device (`glh_stage_unproject`): closed form for k1 alone, else the Oulu
+        fixed point, 20 iterations (camera.py:1198-1337)."""
         uv = np.atleast_2d(np.asarray(uv, dtype=float))
-        cam = self.vector24
-        xy = (uv - (cam[6:8] * 0.5 + cam[10:12])) * (1 / cam[8:10])
-        if np.any(cam[12:20]):
-            u = xy
-            for _ in range(20):
-                dr, dt = synth._distort(cam, u)
-                u = (xy - dt) / dr[:, None]
-            xy = u
-        R = self.R
-        xyz = xy @ R[0:2, :] + R[2, :]
-        if not isinstance(depth, (int, float)) or depth != 1:
-            xyz = xyz * np.atleast_1d(depth).reshape(-1, 1)
-        if not directions:
-            xyz = xyz + self.xyz
-        return xyz
+        d = None if (isinstance(depth, (int, float)) and depth == 1) else depth
+        return _lib.stage_unproject(self.vector24, uv, depth=d, directions=directions)

@@ -1412,13 +1412,28 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
 // Test hook: Camera.xyz_to_uv on explicit points
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const double* xyz, int n,
-                                                        double* uv) {
+                                                        double* uv, int directions) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   double u, v;
-  project(*cam, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], u, v);
+  project_f(*cam, cam_flags(*cam) | (directions ? CAM_F_DIRECTIONS : 0u), xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
+            u, v);
   uv[2 * i] = u;
   uv[2 * i + 1] = v;
+}
+
+// Camera.uv_to_xyz on explicit points; depth null = 1, else [n] (or [1], broadcast)
+__global__ __launch_bounds__(BLK) void k_unproject_points(const CamDev* cam, const double* uv, int n,
+                                                          const double* depth, int n_depth, int directions,
+                                                          double* xyz) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const double d = depth ? depth[n_depth == 1 ? 0 : i] : 1.0;
+  double out[3];
+  unproject(*cam, cam_flags(*cam), uv[2 * i], uv[2 * i + 1], d, directions, out);
+  xyz[3 * i] = out[0];
+  xyz[3 * i + 1] = out[1];
+  xyz[3 * i + 2] = out[2];
 }
 
 // Test hook: Raster.sample at explicit points

@@ -44,7 +44,8 @@ struct CamDev {
 // the camera only, so a kernel can take them from a scalar register and branch uniformly.
 enum : uint32_t {
   CAM_F_CORR = 1u, CAM_F_ANYK = 2u, CAM_F_ANYKDEN = 4u, CAM_F_ANYP = 8u, CAM_F_K0 = 16u,  // K0 << i: k[i] != 0
-  CAM_F_GRID = 1024u
+  CAM_F_GRID = 1024u,
+  CAM_F_DIRECTIONS = 2048u  // xyz are ray directions: no camera offset, no elevation correction (camera.py:1448-1449)
 };
 GLH_HD uint32_t cam_flags(const CamDev& c) {
   uint32_t f = 0;
@@ -66,10 +67,13 @@ GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z,
     v = (y - c.xyz[1]) / c.f[1];
     return;
   }
-  double dx = x - c.xyz[0];
-  double dy = y - c.xyz[1];
-  double dz = z - c.xyz[2];
-  if (f & CAM_F_CORR) {
+  double dx = x, dy = y, dz = z;
+  if (!(f & CAM_F_DIRECTIONS)) {
+    dx = x - c.xyz[0];
+    dy = y - c.xyz[1];
+    dz = z - c.xyz[2];
+  }
+  if ((f & CAM_F_CORR) && !(f & CAM_F_DIRECTIONS)) {
     // helpers.elevation_corrections (helpers.py:1790)
     double sq = dx * dx + dy * dy;
     dz += (c.refraction - 1.0) * sq / (2.0 * c.radius);
@@ -114,6 +118,89 @@ GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z,
 }
 GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, double& v) {
   project_f(c, cam_flags(c), x, y, z, u, v);
+}
+
+// ---- inverse projection: Camera.uv_to_xyz (camera.py:630-663) --------------------------------
+// _radial_distortion / _tangential_distortion (camera.py:1138-1178) of camera coordinates (x, y)
+GLH_HD double radial_factor(const CamDev& c, uint32_t f, double r2) {
+  double dr = 1.0;
+  if (f & (CAM_F_K0 << 0)) dr += c.k[0] * r2;
+  if (f & (CAM_F_K0 << 1)) dr += c.k[1] * r2 * r2;
+  if (f & (CAM_F_K0 << 2)) dr += c.k[2] * r2 * r2 * r2;
+  if (f & CAM_F_ANYKDEN) {
+    double t = 1.0;
+    if (f & (CAM_F_K0 << 3)) t += c.k[3] * r2;
+    if (f & (CAM_F_K0 << 4)) t += c.k[4] * r2 * r2;
+    if (f & (CAM_F_K0 << 5)) t += c.k[5] * r2 * r2 * r2;
+    dr /= t;
+  }
+  return dr;
+}
+GLH_HD void tangential_terms(const CamDev& c, double x, double y, double r2, double& dtx, double& dty) {
+  const double xty = x * y;
+  dtx = 2.0 * xty * c.p[0] + c.p[1] * (r2 + 2.0 * (x * x));
+  dty = c.p[0] * (r2 + 2.0 * (y * y)) + 2.0 * xty * c.p[1];
+}
+
+// Camera._undistort (camera.py:1198-1230): identity, the closed-form cubic when only k1 is set
+// (_undistort_k1, :1232-1264, Numerical Recipes' cubic roots) or the Oulu fixed point, 20 iterations
+// (_undistort_oulu, :1305-1337).
+GLH_HD void undistort(const CamDev& c, uint32_t f, double& x, double& y) {
+  if (!(f & (CAM_F_ANYK | CAM_F_ANYP))) return;
+  const uint32_t kbits = (f / CAM_F_K0) & 63u;
+  if (kbits == 1u && !(f & CAM_F_ANYP)) {
+    const double k1 = c.k[0];
+    const double phi = atan2(y, x);
+    const double Q = -1.0 / (3.0 * k1);
+    const double R = -x / (2.0 * k1 * cos(phi));
+    double r;
+    if (R * R < Q * Q * Q) {
+      const double th = acos(R * pow(Q, -1.5));
+      r = -2.0 * sqrt(Q) * cos((th - 2.0 * M_PI) / 3.0);
+    } else {
+      const double sgn = R > 0.0 ? 1.0 : (R < 0.0 ? -1.0 : 0.0);
+      const double A = -sgn * pow(fabs(R) + sqrt(R * R - Q * Q * Q), 1.0 / 3.0);
+      const double B = A != 0.0 ? Q / A : 0.0;
+      r = A + B;
+    }
+    x = cos(phi) * r;
+    y = sin(phi) * r;
+    return;
+  }
+  double ux = x, uy = y;
+  for (int it = 0; it < 20; ++it) {
+    const double r2 = ux * ux + uy * uy;
+    if ((f & CAM_F_ANYP) && !(f & CAM_F_ANYK)) {
+      double dtx, dty;
+      tangential_terms(c, ux, uy, r2, dtx, dty);
+      ux = x - dtx;
+      uy = y - dty;
+    } else {
+      // (the reference's `any(k) and not any(k)` branch can never be taken, camera.py:1326)
+      double dtx, dty;
+      tangential_terms(c, ux, uy, r2, dtx, dty);
+      const double inv = 1.0 / radial_factor(c, f, r2);
+      ux = (x - dtx) * inv;
+      uy = (y - dty) * inv;
+    }
+  }
+  x = ux;
+  y = uy;
+}
+
+// uv -> ray direction (or world point) at `depth` along the optical axis:
+// _uv_to_xy (camera.py:1510-1519) then _xy_to_xyz (:1472-1497).
+GLH_HD void unproject(const CamDev& c, uint32_t f, double u, double v, double depth, int directions, double* xyz) {
+  double x = (u - c.off[0]) * (1.0 / c.f[0]);
+  double y = (v - c.off[1]) * (1.0 / c.f[1]);
+  undistort(c, f, x, y);
+  for (int k = 0; k < 3; ++k) {
+    double w = c.R[0 * 3 + k] * x + c.R[1 * 3 + k] * y;  // R.T[:, 0:2] @ xy
+    w += c.R[2 * 3 + k];                                  // + R.T[:, 2]
+    if (depth != 1.0) w *= depth;
+    if (!directions) w += c.xyz[k];
+    xyz[k] = w;
+  }
 }
 
 // ---- gridded surfaces: Raster.sample at points (raster.py:913-1027) --------------------------

@@ -1415,7 +1415,7 @@ int finish() {
 }
 }  // namespace
 
-extern "C" int glh_stage_project(int dev, const double* cam, const double* xyz, int n, double* uv) {
+static int stage_project_impl(int dev, const double* cam, const double* xyz, int n, double* uv, int directions) {
   if (!cam || !xyz || !uv || n <= 0) return fail(GLH_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(dev));
   CamDev cd;
@@ -1425,9 +1425,37 @@ extern "C" int glh_stage_project(int dev, const double* cam, const double* xyz, 
   CHK(dx.up(xyz, (size_t)n * 3 * sizeof(double)));
   CHK(du.alloc((size_t)n * 2 * sizeof(double)));
   hipLaunchKernelGGL(k_project_points, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, dc.as<CamDev>(),
-                     dx.as<double>(), n, du.as<double>());
+                     dx.as<double>(), n, du.as<double>(), directions);
   CHK(finish());
   return du.down(uv, (size_t)n * 2 * sizeof(double));
+}
+
+extern "C" int glh_stage_project(int dev, const double* cam, const double* xyz, int n, double* uv) {
+  return stage_project_impl(dev, cam, xyz, n, uv, 0);
+}
+
+extern "C" int glh_stage_project_directions(int dev, const double* cam, const double* xyz, int n, double* uv) {
+  if (cam && cam[23] != 0.0) return fail(GLH_E_INVALID, "ray directions are a camera notion (not a raster grid)");
+  return stage_project_impl(dev, cam, xyz, n, uv, 1);
+}
+
+extern "C" int glh_stage_unproject(int dev, const double* cam, const double* uv, int n, const double* depth,
+                                   int n_depth, int directions, double* xyz) {
+  if (!cam || !uv || !xyz || n <= 0) return fail(GLH_E_INVALID, "bad argument");
+  if (cam[23] != 0.0) return fail(GLH_E_UNSUPPORTED, "uv_to_xyz of a raster grid is not built");
+  if (depth && n_depth != 1 && n_depth != n) return fail(GLH_E_INVALID, "depth must have 1 or n entries");
+  HIPCHK(hipSetDevice(dev));
+  CamDev cd;
+  expand_camera(cam, &cd);
+  DevBuf dc, du, dd, dx;
+  CHK(dc.up(&cd, sizeof cd));
+  CHK(du.up(uv, (size_t)n * 2 * sizeof(double)));
+  if (depth) CHK(dd.up(depth, (size_t)n_depth * sizeof(double)));
+  CHK(dx.alloc((size_t)n * 3 * sizeof(double)));
+  hipLaunchKernelGGL(k_unproject_points, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, dc.as<CamDev>(),
+                     du.as<double>(), n, depth ? dd.as<double>() : nullptr, n_depth, directions, dx.as<double>());
+  CHK(finish());
+  return dx.down(xyz, (size_t)n * 3 * sizeof(double));
 }
 
 static int check_box(const int32_t* box, int width, int height) {

@@ -262,6 +262,12 @@ int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /
 /* ---- stage-level test hooks (stateless; each runs one kernel on explicit inputs) -------- */
 /* Camera.xyz_to_uv (camera.py:591-628): xyz [n][3] -> uv [n][2].                            */
 int glh_stage_project(int device_id, const double* cam, const double* xyz, int n, double* uv);
+/* Same with xyz read as ray directions relative to the camera (directions=True, camera.py:1448).  */
+int glh_stage_project_directions(int device_id, const double* cam, const double* xyz, int n, double* uv);
+/* Camera.uv_to_xyz (camera.py:630-663): uv [n][2] -> xyz [n][3]; depth NULL (= 1), [1] or [n];
+ * undistortion by the closed form for k1 alone, else 20 Oulu iterations (camera.py:1198-1337).   */
+int glh_stage_unproject(int device_id, const double* cam, const double* uv, int n, const double* depth,
+                        int n_depth, int directions, double* xyz);
 /* Tracker.extract_tile(return_histogram=True) (tracker.py:494-534) on a uint8 frame crop
  * `box` (l,t,r,b): tile float64 [h][w], CDF values/quantiles, n entries.                    */
 int glh_stage_template(int device_id, const uint8_t* frame, int width, int height, int channels,

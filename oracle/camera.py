@@ -157,3 +157,81 @@ def inframe(cam, uv):
     """camera.py:700-718."""
     with np.errstate(invalid="ignore"):
         return np.all((uv >= 0) & (uv <= cam[6:8]), axis=1)
+
+
+def _radial(cam, r2):
+    """camera.py:1138-1163."""
+    k = cam[12:18]
+    dr = np.ones_like(r2)
+    if k[0]:
+        dr = dr + k[0] * r2
+    if k[1]:
+        dr = dr + k[1] * r2 * r2
+    if k[2]:
+        dr = dr + k[2] * r2 * r2 * r2
+    if np.any(k[3:6]):
+        temp = np.ones_like(r2)
+        if k[3]:
+            temp = temp + k[3] * r2
+        if k[4]:
+            temp = temp + k[4] * r2 * r2
+        if k[5]:
+            temp = temp + k[5] * r2 * r2 * r2
+        dr = dr / temp
+    return dr[:, None]
+
+
+def _tangential(cam, xy, r2):
+    """camera.py:1165-1178."""
+    p = cam[18:20]
+    xty = xy[:, 0] * xy[:, 1]
+    return np.column_stack((2 * xty * p[0] + p[1] * (r2 + 2 * xy[:, 0] ** 2),
+                            p[0] * (r2 + 2 * xy[:, 1] ** 2) + 2 * xty * p[1]))
+
+
+def undistort(cam, xy):
+    """Camera._undistort (camera.py:1198-1230): identity, the closed-form cubic for k1 alone (:1232-1264),
+    else the Oulu fixed point with 20 iterations (:1305-1337)."""
+    k, p = cam[12:18], cam[18:20]
+    if not np.any(k) and not np.any(p):
+        return xy
+    if k[0] and not np.any(k[1:]) and not np.any(p):
+        phi = np.arctan2(xy[:, 1], xy[:, 0])
+        Q = -1 / (3 * k[0])
+        R = -xy[:, 0] / (2 * k[0] * np.cos(phi))
+        three = R ** 2 < Q ** 3
+        r = np.full(len(xy), np.nan)
+        if np.any(three):
+            th = np.arccos(R[three] * Q ** -1.5)
+            r[three] = -2 * np.sqrt(Q) * np.cos((th - 2 * np.pi) / 3)
+        one = ~three
+        if np.any(one):
+            A = -np.sign(R[one]) * (np.abs(R[one]) + np.sqrt(R[one] ** 2 - Q ** 3)) ** (1.0 / 3)
+            B = np.zeros(A.shape)
+            nz = A != 0
+            B[nz] = Q / A[nz]
+            r[one] = A + B
+        return np.column_stack((np.cos(phi), np.sin(phi))) * r[:, None]
+    uxy = xy
+    for _ in range(20):
+        r2 = np.sum(uxy ** 2, axis=1)
+        if np.any(p) and not np.any(k):
+            uxy = xy - _tangential(cam, uxy, r2)
+        else:
+            uxy = (xy - _tangential(cam, uxy, r2)) * (1 / _radial(cam, r2))
+    return uxy
+
+
+def uv_to_xyz(cam, uv, directions=True, depth=1):
+    """Camera.uv_to_xyz (camera.py:630-663): _uv_to_xy (:1510-1519) then _xy_to_xyz (:1472-1497)."""
+    uv = np.atleast_2d(np.asarray(uv, dtype=float))
+    xy = (uv - (cam[6:8] * 0.5 + cam[10:12])) * (1 / cam[8:10])
+    xy = undistort(cam, xy)
+    R = rotation_matrix(cam[3:6])
+    xyz = np.matmul(R.T[:, 0:2], xy.T).T
+    xyz += R.T[:, 2]
+    if not isinstance(depth, (int, float)) or depth != 1:
+        xyz *= np.atleast_1d(depth).reshape(-1, 1)
+    if not directions:
+        xyz += cam[0:3]
+    return xyz

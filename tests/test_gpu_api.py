@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import glimpse_amd  # noqa: E402
-from tests.helpers_api import DAY, models_from, observers_from  # noqa: E402
+from tests.helpers_api import DAY, camera_from, models_from, observers_from  # noqa: E402
 
 RTOL = 1e-5
 
@@ -324,3 +324,33 @@ def test_orthophoto_observer_on_the_device(golden):
     np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(tracks.particles, g["particles"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(tracks.weights, g["weights"], rtol=RTOL, atol=1e-290)
+
+
+def _pixel_centres(imgsz):
+    u, v = np.meshgrid(np.arange(imgsz[0]) + 0.5, np.arange(imgsz[1]) + 0.5)
+    return np.column_stack((u.ravel(), v.ravel()))
+
+
+def test_inverse_projection_on_the_device(golden):
+    """Camera.uv_to_xyz (camera.py:630-663) on the device against the reference's outputs, and the reference's
+    own round-trip tests (tests/test_camera.py:34-88) restated: project(unproject(pixel centres)) returns
+    the pixel centres within 1e-14 (pinhole) / 1e-12 (k1..k6, p1, p2, and extreme k1 = +-2)."""
+    g = golden("g14_unproject.npz")
+    for vec, uv, depth, xd, xa in zip(g["cams"], g["uv"], g["depth"], g["xyz_directions"], g["xyz_absolute"]):
+        cam = camera_from(vec)
+        np.testing.assert_allclose(cam.uv_to_xyz(uv), xd, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(cam.uv_to_xyz(uv, directions=False, depth=depth), xa, rtol=1e-11, atol=1e-9)
+
+    def reprojection_errors(cam):
+        uv = _pixel_centres(cam.imgsz.astype(int))
+        return np.linalg.norm(cam.xyz_to_uv(cam.uv_to_xyz(uv), directions=True) - uv, axis=1)
+
+    kw = dict(imgsz=(100, 100), f=(100, 100))
+    assert reprojection_errors(glimpse_amd.Camera(**kw)).max() < 1e-14
+    for extra in (dict(k=0.1), dict(k=-0.1), dict(k=[0.1] * 6), dict(p=[0.01] * 2), dict(k=[0.1] * 6, p=[0.01] * 2),
+                  dict(k=2), dict(k=-2)):
+        assert reprojection_errors(glimpse_amd.Camera(**kw, **extra)).max() < 1e-12, extra
+    # default camera: the image centre looks along +y (camera.py:650-655 doctest)
+    cam = glimpse_amd.Camera(imgsz=10, f=10)
+    np.testing.assert_allclose(cam.uv_to_xyz(np.array([(5, 5)])), [[0, 1, 0]], atol=1e-15)
+    np.testing.assert_allclose(cam.uv_to_xyz(np.array([(5, 5)]), depth=10), [[0, 10, 0]], atol=1e-14)

@@ -331,3 +331,12 @@ def test_orthophoto_observer_matches_reference(golden):
     res = tracker.track(models, observers, np.arange(T)[:, None], np.ones(T - 1), tile_size=(15, 15))
     np.testing.assert_allclose(res["means"], g["means"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(res["sigmas"], g["sigmas"], rtol=1e-9, atol=1e-14)
+
+
+def test_inverse_projection_matches_reference(golden):
+    """Camera.uv_to_xyz (camera.py:630-663) incl. the k1 closed form and the Oulu undistortion."""
+    g = golden("g14_unproject.npz")
+    for vec, uv, depth, xd, xa in zip(g["cams"], g["uv"], g["depth"], g["xyz_directions"], g["xyz_absolute"]):
+        np.testing.assert_allclose(camera.uv_to_xyz(vec, uv), xd, rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(camera.uv_to_xyz(vec, uv, directions=False, depth=depth), xa, rtol=1e-13,
+                                   atol=1e-10)

@@ -681,6 +681,31 @@ def g13_ortho():
     np.savez_compressed(os.path.join(OUT, "g13_ortho.npz"), **out)
 
 
+def g14_unproject():
+    """Camera.uv_to_xyz (camera.py:630-663) for the g1 cameras (without their elevation correction:
+    it is not inverted by uv_to_xyz) plus the distortion cases of tests/test_camera.py:42-88."""
+    rng = np.random.default_rng(1414)
+    g1 = np.load(os.path.join(OUT, "g1_projection.npz"))
+    cams = [c.copy() for c in g1["cams"]]
+    for k in ([0.1], [-0.1], [0.1] * 6, [0, 0, 0, 0, 0, 0], [0.1] * 6, [2.0], [-2.0]):
+        cams.append(synth.pack_camera(imgsz=(100, 100), f=(100, 100), k=k + [0] * (6 - len(k))))
+    cams[-4][18:20] = 0.01  # tangential only
+    cams[-3][18:20] = 0.01  # all distortion
+    out = {"cams": np.stack(cams)}
+    uv_all, d_all, xyz_dir, xyz_abs = [], [], [], []
+    for vec in cams:
+        cam = ref_camera(vec)
+        uv = rng.uniform(0, 1, (200, 2)) * vec[6:8]
+        depth = rng.uniform(2, 300, 200)
+        uv_all.append(uv)
+        d_all.append(depth)
+        xyz_dir.append(cam.uv_to_xyz(uv))
+        xyz_abs.append(cam.uv_to_xyz(uv, directions=False, depth=depth))
+    out["uv"], out["depth"] = np.stack(uv_all), np.stack(d_all)
+    out["xyz_directions"], out["xyz_absolute"] = np.stack(xyz_dir), np.stack(xyz_abs)
+    np.savez_compressed(os.path.join(OUT, "g14_unproject.npz"), **out)
+
+
 def g10_tracks():
     """Tracks.reverse / from_multiple / average (tracks.py:131-213) on synthetic result arrays with
     missing rows, e.g. merging a forward and a backward run."""
@@ -724,6 +749,9 @@ def g10_tracks():
 
 
 if __name__ == "__main__":
+    if "--g14" in sys.argv:
+        g14_unproject()
+        sys.exit(0)
     if "--g13" in sys.argv:
         g13_ortho()
         sys.exit(0)
@@ -752,5 +780,6 @@ if __name__ == "__main__":
     g11_motion_models()
     g12_rasters()
     g13_ortho()
+    g14_unproject()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
