@@ -63,8 +63,14 @@ GLH_HD uint32_t cam_flags(const CamDev& c) {
 // :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).  `f` = cam_flags(c).
 GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
   if (f & CAM_F_GRID) {  // Grid.xyz_to_uv: (xy - (xlim[0], ylim[0])) / d
-    u = (x - c.xyz[0]) / c.f[0];
-    v = (y - c.xyz[1]) / c.f[1];
+    double gx = x - c.xyz[0], gy = y - c.xyz[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque to the optimiser: otherwise both division sequences are speculated above this (uniform) branch
+    // and every perspective projection pays for them
+    asm volatile("" : "+v"(gx), "+v"(gy));
+#endif
+    u = gx / c.f[0];
+    v = gy / c.f[1];
     return;
   }
   double dx = x, dy = y, dz = z;

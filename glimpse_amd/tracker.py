@@ -58,6 +58,9 @@ class Tracker:
         if viewshed is not None and not isinstance(viewshed, Raster):
             raise TypeError("viewshed must be a glimpse_amd.Raster")
         if resample_method not in _lib.RESAMPLE:
+            # 'residual' (tracker.py:188-203) subtracts integer repetition counts from NORMALISED weights, so its
+            # cumulative sum is not monotone and np.searchsorted's answer depends on the bisection state it
+            # carries from key to key: not reproduced here.
             raise NotImplementedError(f"resample_method {resample_method!r}: the GPU path provides "
                                       f"{sorted(_lib.RESAMPLE)} ('residual' is not built)")
         if tuple(highpass.get("size", (5, 5))) != (5, 5) or set(highpass) - {"size"}:
