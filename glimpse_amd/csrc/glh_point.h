@@ -2,8 +2,8 @@
 // whole update (tracker.py:331-354), so per frame the particle state is read once from HBM and
 // written once, and everything in between lives in registers and LDS:
 //
-//   A  evolve + NaN test + project every particle; uv of observer 0 stays in registers (PPT per
-//      thread), wave-shuffle / LDS min-max -> integer search box          (motion.py:165-179,
+//   A  evolve + NaN test + project every particle; observer 0's u stays in registers (PPT per
+//      thread) and its v in c[] (LDS), wave-shuffle / LDS min-max -> integer search box (motion.py:165-179,
 //      tracker.py:118, camera.py:591-628, tracker.py:580-603)
 //   B  per observer: crop -> histogram -> CDF-match LUT -> 5x5 median high-pass -> float32 search
 //      tile -> SSD surface -> not-a-knot spline coefficients, all in LDS  (tracker.py:605-614,
@@ -75,26 +75,21 @@ __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   return t;
 }
 
-// uv of observer 0 lives in a per-thread register array; the particle loops stay ROLLED (small
-// code, bounded live ranges) and address it with compare-select chains instead of dynamic
-// indexing (which would send the array to scratch).
+// u of observer 0 lives in a per-thread register array (v is parked in c[i], LDS, which is free until
+// phase C writes the log likelihoods); the particle loops stay ROLLED (small code, bounded live
+// ranges) and address the array with compare-select chains instead of dynamic indexing (which would
+// send it to scratch).
 template <int PPT>
-__device__ __forceinline__ double2 pt_pick(const double2 (&v)[PPT], int r) {
-  double2 q = v[0];
+__device__ __forceinline__ double pt_pick(const double (&v)[PPT], int r) {
+  double q = v[0];
 #pragma unroll
-  for (int k = 1; k < PPT; ++k) {
-    q.x = r == k ? v[k].x : q.x;
-    q.y = r == k ? v[k].y : q.y;
-  }
+  for (int k = 1; k < PPT; ++k) q = r == k ? v[k] : q;
   return q;
 }
 template <int PPT>
-__device__ __forceinline__ void pt_put(double2 (&v)[PPT], int r, double2 q) {
+__device__ __forceinline__ void pt_put(double (&v)[PPT], int r, double q) {
 #pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    v[k].x = r == k ? q.x : v[k].x;
-    v[k].y = r == k ? q.y : v[k].y;
-  }
+  for (int k = 0; k < PPT; ++k) v[k] = r == k ? q : v[k];
 }
 
 struct PointArgs {
@@ -420,12 +415,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
-  // PPT > 0: uv of observer 0 in PPT registers per thread.  PPT == 0: u parked in c[i] (LDS, free until
-  // phase C) and v in the first N doubles of the observer-0 slot of the uv scratch (L2 / Infinity Cache).
+  // Observer 0's uv.  PPT > 0: u in PPT registers per thread, v parked in c[i] (LDS, free until phase C).
+  // PPT == 0: u parked in c[i] and v in the first N doubles of the observer-0 slot of the uv scratch
+  // (L2 / Infinity Cache).
   constexpr int NREG = PPT > 0 ? PPT : 1;
   const int rounds = PPT > 0 ? PPT : (N + TB - 1) / TB;
   double* V0 = a.uv + (size_t)pt * N * 2;
-  double2 uv0[NREG];
+  double u0[NREG];
   {
     double mn[NOBS][2], mx[NOBS][2], nanf[NOBS];
 #pragma unroll
@@ -439,7 +435,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const double zs = m[17];
     const bool gridded = SURF && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) uv0[r] = make_double2(0.0, 0.0);
+    for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
     {
@@ -483,7 +479,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           project_f(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
           if (o == 0) {
             if constexpr (PPT > 0) {
-              pt_put<NREG>(uv0, r, make_double2(u, v));
+              pt_put<NREG>(u0, r, u);
+              c[i] = v;
             } else {
               c[i] = u;
               V0[i] = v;
@@ -547,15 +544,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       s_status[o] = st;
       a.obs_status[slot] = st;
     }
-    if constexpr (PPT > 0)
-      for (int i = tid; i < N; i += TB) c[i] = 0.0;
     __syncthreads();
   }
 
   PT_STAMP(1);
   // ---------------- B + C per observer, in the reference's order (tracker.py:139-146) ----------
   bool outside = false;
-  bool c_ready = PPT > 0;  // uniform: c[] holds log likelihoods (not the parked u coordinates)
+  bool c_ready = false;  // uniform: c[] holds log likelihoods (not observer 0's parked coordinates)
   for (int o = 0; o < NOBS; ++o) {
     if (s_status[o] != GLH_OBS_OK) continue;  // uniform
     const size_t slot = (size_t)o * a.P + pt;
@@ -605,24 +600,19 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           if (i < N) {
             double2 q;
             if constexpr (PPT > 0)
-              q = pt_pick<NREG>(uv0, r);
+              q = make_double2(pt_pick<NREG>(u0, r), c[i]);
             else
               q = make_double2(c[i], V0[i]);
             if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
             const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
-            if constexpr (PPT > 0)
-              c[i] += term;
-            else
-              c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
+            c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           }
         }
         c_ready = true;
       } else {
-        if constexpr (PPT == 0) {
-          if (!c_ready) {  // observer 0 was skipped: c[] still holds its u coordinates
-            for (int i = tid; i < N; i += TB) c[i] = 0.0;
-            c_ready = true;
-          }
+        if (!c_ready) {  // observer 0 was skipped: c[] still holds its parked coordinates
+          for (int i = tid; i < N; i += TB) c[i] = 0.0;
+          c_ready = true;
         }
         for (int i = tid; i < N; i += TB) {
           const double2 q = uvp[i];
@@ -685,10 +675,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     __syncthreads();  // region 2 is free for the next observer
   }
-  if constexpr (PPT == 0) {
-    if (!c_ready)
-      for (int i = tid; i < N; i += TB) c[i] = 0.0;  // every observer skipped (same-thread indices)
-  }
+  if (!c_ready)
+    for (int i = tid; i < N; i += TB) c[i] = 0.0;  // every observer skipped (same-thread indices)
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
   for (int i = tid; i < N; i += TB) {
