@@ -9,7 +9,7 @@
 //      tile -> SSD surface -> not-a-knot spline coefficients, all in LDS  (tracker.py:605-614,
 //      observer.py:210); tiles too large for LDS use the HBM workspaces with the same code
 //   C  sample the spline at every particle, w = exp(-ll) + 1e-300         (tracker.py:622-625, :126-149)
-//   D  NumPy-exact w.sum(), float64 LDS scan, inverse searchsorted         (tracker.py:168-176)
+//   D  NumPy-exact w.sum(), float64 scan (weights stay in LDS), inverse searchsorted (tracker.py:168-176)
 //   E  particles[idx]: re-read the PRE-evolve record of each source (L2 / Infinity-Cache hot:
 //      this workgroup streamed it in phase A) and re-apply its evolve step with the same noise
 //      (host normals or counter-based Philox) -- the evolved state is never stored un-resampled
@@ -95,7 +95,7 @@ __device__ __forceinline__ void pt_put(double (&v)[PPT], int r, double q) {
 struct PointArgs {
   const double* particles_in;  // [P][N][6] state after the previous frame (pre-evolve)
   double* particles_out;       // [P][N][6] evolved + resampled
-  double* weights_tmp;         // [P][N] this frame's weights (scratch: gathered by phase E)
+  double* weights_tmp;         // [P][N] scratch: the motion model's log-likelihood term (has_dem) from phase A to C
   double* weights_out;         // [P][N] weights[idx]
   const double* motion;
   const uint8_t* obs_mask;     // [P][O] or null
@@ -682,9 +682,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   for (int i = tid; i < N; i += TB) {
     double ll = c[i];
     if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
-    const double w = exp(-ll) + 1e-300;
-    W[i] = w;
-    c[i] = w;
+    c[i] = exp(-ll) + 1e-300;  // the weights stay in LDS until the gather of phase E
   }
   __syncthreads();
 
@@ -725,12 +723,20 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(10);
   double total = node[p_roots[0]];
   for (int r = 1; r < a.nroots; ++r) total += node[p_roots[r]];
+  // cumsum(w / total) over contiguous segments, one per thread, WITHOUT storing it: c[] keeps the weights.
+  // PPT > 0 (seg <= PPT): the quotients wait in registers for the second pass; otherwise they are recomputed.
   const int seg = (N + TB - 1) / TB;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   double run = 0.0;
-  for (int k = k0; k < k1; ++k) {
-    run += c[k] / total;
-    c[k] = run;
+  double qn[NREG];
+  if constexpr (PPT > 0) {
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+      qn[j] = k0 + j < k1 ? c[k0 + j] / total : 0.0;
+      if (k0 + j < k1) run += qn[j];
+    }
+  } else {
+    for (int k = k0; k < k1; ++k) run += c[k] / total;
   }
   double incl = run;
 #pragma unroll
@@ -746,9 +752,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
   const double excl = base + prev;
   PT_STAMP(11);
-  if (tid > 0)
-    for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
-  __syncthreads();
+  // element k's cumulative weight: the running sum of its segment, shifted by the segments before it
+  // (thread 0's running sums are used as they are)
+  double* clast = node + a.nnodes;  // [TB] last cumulative weight of every segment
+  clast[tid] = tid > 0 ? excl + run : run;
   PT_STAMP(12);
   double u;
   if (a.rng_mode == GLH_RNG_HOST) {
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     u = u01_halfopen(r[0], r[1]);
   }
   const double inv_n = 1.0 / (double)N;
-  uint16_t* sidx = reinterpret_cast<uint16_t*>(node + a.nnodes);
+  uint16_t* sidx = reinterpret_cast<uint16_t*>(clast + TB);
   {
     // f(ck) = #{j : pos_j <= ck}, pos_j = (j + u) * (1 / n) exactly as tracker.py:173 rounds it.  The guess
     // floor(ck * n - u) + 1 is kept in float64 (integer valued, so (double)f == g bit for bit) and
@@ -785,11 +792,26 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // increase with the position, so "the last head at or before j" is the maximum so far.
     for (int j = tid; j < N; j += TB) sidx[j] = 0;
     pt_lds_barrier();
-    int f_prev = k0 > 0 ? count_le(c[k0 - 1]) : 0;
-    for (int k = k0; k < k1; ++k) {
-      const int f = count_le(c[k]);
-      if (f > f_prev) sidx[f_prev] = (uint16_t)k;
-      f_prev = f;
+    int f_prev = k0 > 0 && k0 < N ? count_le(clast[tid - 1]) : 0;
+    double run2 = 0.0;
+    if constexpr (PPT > 0) {
+#pragma unroll
+      for (int j = 0; j < NREG; ++j) {
+        const int k = k0 + j;
+        if (k < k1) {
+          run2 += qn[j];
+          const int f = count_le(tid > 0 ? excl + run2 : run2);
+          if (f > f_prev) sidx[f_prev] = (uint16_t)k;
+          f_prev = f;
+        }
+      }
+    } else {
+      for (int k = k0; k < k1; ++k) {
+        run2 += c[k] / total;
+        const int f = count_le(tid > 0 ? excl + run2 : run2);
+        if (f > f_prev) sidx[f_prev] = (uint16_t)k;
+        f_prev = f;
+      }
     }
     if (k1 == N && k0 < N && f_prev < N) {
       // positions beyond c[N-1] (searchsorted == N: IndexError in the reference): clamp + flag
@@ -837,7 +859,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
       evolved(lo[g], x[g]);
-      w[g] = W[lo[g]];
+      w[g] = c[lo[g]];
     }
 #pragma unroll
     for (int g = 0; g < GU; ++g) {

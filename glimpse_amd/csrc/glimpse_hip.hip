@@ -1074,7 +1074,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   }
   // c[N] and, behind region 2, the pairwise-sum plan
   const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
-  const int plan = pt_align16(c->nnodes * 8) + pt_align16(c->N * 2);
+  const int plan = pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8 + pt_align16(c->N * 2);  // nodes | clast | sidx
   const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb));
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + 48 * 48 * 2 + 4096;
