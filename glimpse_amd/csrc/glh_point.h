@@ -865,11 +865,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int g = 0; g < GU; ++g) {
       const int j = j0 + g * TB;
       if (j < N) {
-        double2* dst = reinterpret_cast<double2*>(Pout + (size_t)j * 6);
-        dst[0] = make_double2(x[g][0], x[g][1]);
-        dst[1] = make_double2(x[g][2], x[g][3]);
-        dst[2] = make_double2(x[g][4], x[g][5]);
-        Wout[j] = w[g];
+        typedef double pt_d2 __attribute__((ext_vector_type(2)));
+        pt_d2* dst = reinterpret_cast<pt_d2*>(Pout + (size_t)j * 6);
+        // streaming stores: the new state is not read again before the next launch, and should not displace
+        // the pre-evolve records that the other workgroups' gathers are about to re-read from L2 / Infinity Cache
+        __builtin_nontemporal_store(pt_d2{x[g][0], x[g][1]}, dst);
+        __builtin_nontemporal_store(pt_d2{x[g][2], x[g][3]}, dst + 1);
+        __builtin_nontemporal_store(pt_d2{x[g][4], x[g][5]}, dst + 2);
+        __builtin_nontemporal_store(w[g], Wout + j);
         if (a.idx_out) a.idx_out[(size_t)pt * N + j] = lo[g];
         s0 += w[g];
 #pragma unroll
