@@ -172,18 +172,31 @@ struct TileWs {
 // extract_tile(histogram=template CDF) (tracker.py:605-607) into ws.S; see search_tile_from_box.
 template <int TB>
 __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box, int nb, int hist_n, const TileWs& ws,
-                                             uint32_t* scan_tmp) {
+                                             uint32_t* scan_tmp, unsigned long long* stp = nullptr) {
+#define TP_STAMP(k) do { if (stp && threadIdx.x == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   for (int b = tid; b < nb; b += TB) ws.hist[b] = 0;
   __syncthreads();
-  for (int idx = tid; idx < n; idx += TB) {
-    const int r = idx / w, c = idx - r * w;
-    const int key = pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c);
-    ws.keys[idx] = (uint16_t)key;
-    atomicAdd(&ws.hist[key], 1u);
+  // four pixel loads in flight per thread (each is a scattered byte fetch with a full memory latency)
+  for (int base = 0; base < n; base += 4 * TB) {
+    int key[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      const int r = idx / w, c = idx - r * w;
+      key[q] = idx < n ? pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (key[q] >= 0) {
+        ws.keys[base + q * TB + tid] = (uint16_t)key[q];
+        atomicAdd(&ws.hist[key[q]], 1u);
+      }
+    }
   }
   __syncthreads();
+  TP_STAMP(13);
   {
     // inclusive scan of the nb <= 2 * TB bins: two bins per thread + block scan
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
@@ -212,6 +225,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     }
   }
   __syncthreads();
+  TP_STAMP(14);
   const int ld = ws.ld;
   // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
   for (int idx = tid; idx < h * (ld - w); idx += TB) {
@@ -258,7 +272,8 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
 // cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614) from ws.S / ws.T into ws.Z (widened
 // to float64 for the spline fit); arithmetic and summation order of k_ssd.
 template <int TB>
-__device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo, int ho) {
+__device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo, int ho, double* park = nullptr,
+                                       double park_v = 0.0) {
   const int tid = threadIdx.x;
   const int twp = ssd_twp(tw);
   const int spr = (wo + SSD_W - 1) / SSD_W;
@@ -289,6 +304,7 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
       }
     }
   }
+  if (park) *park = park_v;  // a value its caller fetched from memory before the SSD (LU factors)
   __syncthreads();
 }
 
@@ -403,6 +419,26 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   bool live[NOBS];  // uniform across the block
 #pragma unroll
   for (int o = 0; o < NOBS; ++o) live[o] = a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
+  // Template tile (zero padded rows) and template CDF of one observer into the head of region 2: [T | cq | cv].
+  auto load_template = [&](int o) {
+    const size_t slot = (size_t)o * a.P + pt;
+    const int tw = a.tw, th = a.th, twp = ssd_twp(tw);
+    const int hist_n = a.tmpl_hist_n[slot];
+    float* T = reinterpret_cast<float*>(r2);
+    const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
+    for (int idx = tid; idx < th * twp; idx += TB) {
+      const int i = idx / twp, j = idx - i * twp;
+      T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
+    }
+    double* cq = reinterpret_cast<double*>(r2 + pt_align16(th * twp * 4));
+    double* cv = cq + pt_align16(hist_n * 8) / 8;
+    const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
+    const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
+    for (int k = tid; k < hist_n; k += TB) {
+      cq[k] = hq_g[k];
+      cv[k] = hv_g[k];
+    }
+  };
   __syncthreads();
 
   auto evolved = [&](int k, double* x) {
@@ -562,28 +598,22 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
     const int hist_n = a.tmpl_hist_n[slot];
     const int twp = ssd_twp(tw);
-    // ---- LDS carve: [T | S | X] with X = max(hist + cum + lut + keys + cdf, Z + LU)
+    // ---- LDS carve: [T | cq | cv | S | X] with X = max(hist + cum + lut + keys, Z + LU)
     TileWs ws;
-    int off = 0;
-    ws.T = reinterpret_cast<float*>(r2 + off);
-    off += pt_align16(th * twp * 4);
+    const int offT = pt_align16(th * twp * 4), cdfb = pt_align16(hist_n * 8);
+    ws.T = reinterpret_cast<float*>(r2);
+    const int off = offT + 2 * cdfb;
     const int ld_lds = pt_search_ld(ws_);
     const int s_bytes = pt_align16(hs * ld_lds * 4);
     const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
-    const int l1 = hcl + pt_align16(hs * ws_ * 2) + 2 * pt_align16(hist_n * 8);
+    const int l1 = hcl + pt_align16(hs * ws_ * 2);
     const int l2 = pt_align16(ho * wo * 8) + pt_align16(5 * (ho + wo) * 8);
     const bool fits = off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
     const double* fw_g = a.lu + a.lu_off[wo];
-    {
-      const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
-      for (int idx = tid; idx < th * twp; idx += TB) {
-        const int i = idx / twp, j = idx - i * twp;
-        ws.T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
-      }
-    }
+    load_template(o);
     // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
     //      once per branch below so that the coefficient loads keep their address space
     auto sample_all = [&](const double* Z) {
@@ -629,31 +659,35 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
       ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
       ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
-      double* cq = reinterpret_cast<double*>(X + hcl + pt_align16(hs * ws_ * 2));
-      double* cv = cq + pt_align16(hist_n * 8) / 8;
-      for (int k = tid; k < hist_n; k += TB) {
-        cq[k] = hq_g[k];
-        cv[k] = hv_g[k];
-      }
-      ws.cdf_q = cq;
-      ws.cdf_v = cv;
-      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp);  // starts with a barrier: T, cdf visible
+      ws.cdf_q = reinterpret_cast<const double*>(r2 + offT);
+      ws.cdf_v = ws.cdf_q + cdfb / 8;
+      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);  // starts with a barrier: T, cdf visible
       PT_STAMP(2);
       ws.Z = reinterpret_cast<double*>(X);
       double* fl = ws.Z + pt_align16(ho * wo * 8) / 8;
-      // X is reused: the histogram / keys / cdf are dead once the search tile is written
-      for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
-      for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
+      // X is reused: the histogram / keys are dead once the search tile is written.  The LU factors are
+      // fetched before the SSD and parked in LDS after it, so their memory latency hides behind it.
+      const int nfl = 5 * (ho + wo);
+      double fl_v = 0.0;
+      if (nfl <= TB) {
+        if (tid < 5 * ho) fl_v = fh_g[tid];
+        else if (tid < nfl) fl_v = fw_g[tid - 5 * ho];
+      } else {
+        for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
+        for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
+      }
       ws.fh = fl;
       ws.fw = fl + 5 * ho;
-      pt_ssd<TB>(ws, tw, th, wo, ho);
+      pt_ssd<TB>(ws, tw, th, wo, ho, nfl <= TB && tid < nfl ? fl + tid : nullptr, fl_v);
       PT_STAMP(3);
       pt_spline_fit<TB>(ws, wo, ho);
       PT_STAMP(4);
       sample_all(ws.Z);
     } else {
-      // big tile: search / keys / surface in the HBM workspaces, histogram + LUT stay in LDS
-      unsigned char* X = r2 + off;
+      // big tile: search / keys / surface in the HBM workspaces, histogram + LUT stay in LDS (over the LDS
+      // copy of the template CDF: this path reads the CDF from memory)
+      unsigned char* X = r2 + offT;
+      __syncthreads();  // the CDF copy has landed before the histogram is zeroed over it
       ws.hist = reinterpret_cast<uint32_t*>(X);
       ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
       ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
@@ -665,7 +699,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.cdf_v = hv_g;
       ws.fh = fh_g;
       ws.fw = fw_g;
-      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp);
+      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
       PT_STAMP(2);
       pt_ssd<TB>(ws, tw, th, wo, ho);
       PT_STAMP(3);

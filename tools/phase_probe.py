@@ -1,6 +1,6 @@
 """Diagnostic: mean cycles per phase of the fused per-point kernel on a synthetic workload.
 
-    python tools/phase_probe.py [C3] [points] [particles]
+    python tools/phase_probe.py [C3] [points] [particles] [frames]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ from glimpse_amd import _lib, workloads  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else None
 N = int(sys.argv[3]) if len(sys.argv) > 3 else None
-T = 8
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N)
 frames = [wl.frames(o) for o in range(wl.O)]
 NAMES = ["", "A evolve+project", "B tile_prep", "B ssd", "B spline_fit", "C sample", "C exp", "D resample",
@@ -35,6 +35,8 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     ms = {k: v for k, v in ctx.profile_get().items() if v[0] > 0}
     st = ctx.phase_stamps().astype(np.int64)
     sub = st[:, 10:13]
+    tp = st[:, 13:15]
+    print('  tile_prep split (median ticks): fetch+hist', np.median(tp[:,0]-st[:,1]), 'scan+lut', np.median(tp[:,1]-tp[:,0]), 'median+write', np.median(st[:,2]-tp[:,1]))
     st = st[:, :10]
     d = np.diff(st, axis=1)  # (P, 9)
     tot = d.sum(axis=1)
@@ -43,6 +45,9 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     print(f"  last step kernels (ms): {ms}")
     print(f"  kernel span {span} ticks; per-point total: min {tot.min()} median {np.median(tot):.0f} max {tot.max()}")
     print(f"  per-point total percentiles 50/90/99: {np.percentile(tot, [50, 90, 99])}")
+    k_ms = ms["point_step"][0]
+    print(f"  sum of workgroup lifetimes / kernel time = {tot.sum() / (k_ms * 1e-3) / 1e9:.1f} G tick-slots/s "
+          f"(512 resident workgroups at 100 MHz ticks would be 51.2; a dispatch tail shows as less)")
     t0 = st[:, 0] - st[:, 0].min()
     t1 = st[:, -1] - st[:, 0].min()
     print(f"  block start ticks percentiles 25/50/75/100: {np.percentile(t0, [25, 50, 75, 100])}; last end {t1.max()}")
