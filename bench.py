@@ -41,6 +41,9 @@ def parse_args():
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo gathers host copies and "
                          "exists to exercise the multi-rank path where ranks share one GPU)")
     ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
+    ap.add_argument("--frames-per-call", type=int, default=0,
+                    help="frame updates per library call: 0 = all the timed steps in one glh_track call (the frame loop "
+                         "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-workers", type=int, default=min(16, os.cpu_count() or 1),
@@ -223,8 +226,22 @@ def main():
     for o in range(wl.O):
         ctx.init_templates(o, 0)
     ctx.record_moments(0)
-    for i in range(1, 1 + B + W):  # burn-in + warm-up, untimed
-        ctx.step(i, 1.0, images(i), seed=seed)
+    F = K if args.frames_per_call <= 0 else min(args.frames_per_call, K)
+
+    def run(first, count):
+        """`count` consecutive frame updates from frame `first`: glh_track calls of up to F frames each (the frame
+        loop of tracker.py:326-357, one kernel launch per frame), or glh_step per frame when F == 1."""
+        i = first
+        while i < first + count:
+            n = min(F, first + count - i)
+            if n == 1:
+                ctx.step(i, 1.0, images(i), seed=seed)
+            else:
+                ctx.track(list(range(i, i + n)), [1.0] * n, [images(j) for j in range(i, i + n)], seed=seed)
+            i += n
+
+    run(1, B)  # burn-in, untimed
+    run(1 + B, W)  # warm-up, untimed
     ctx.sync()
 
     def barrier():
@@ -263,8 +280,7 @@ def main():
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for i in range(1 + B + W, 1 + B + W + K):
-        ctx.step(i, 1.0, images(i), seed=seed)
+    run(1 + B + W, K)
     if dist is not None:
         ctx.sync()
         gather_moments()
@@ -312,7 +328,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
-                           frames_per_s=K / elapsed, burn_in_steps=B),
+                           frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F),
             "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err,
                        "gathered_moments_finite": gathered_ok},
         }

@@ -88,6 +88,7 @@ SIGNATURES = {
     "glh_get_covariances": (_I, [_P, _I, _I, _P]),
     "glh_record_moments": (_I, [_P, _I]),
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
+    "glh_track": (_I, [_P, _I, _P, _P, _P, _U64]),
     "glh_set_fused": (_I, [_P, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
@@ -336,6 +337,16 @@ class Context:
             n = _arr(normals, np.float64, (self.P, self.N, 3))
             uu = _arr(u, np.float64, (self.P,))
             check(self.lib.glh_step(self.handle, int(frame), float(tau), _ptr(im), RNG_HOST, _ptr(n), _ptr(uu), 0))
+
+    def track(self, frames, taus, images, seed=0):
+        """len(frames) consecutive `step` updates (device RNG) in one call: frames (T,), taus (T,), images (T, O)
+        with -1 / None for "no image" (tracker.py:326-357)."""
+        fr = np.ascontiguousarray(frames, dtype=np.int32).reshape(-1)
+        ta = np.ascontiguousarray(taus, dtype=np.float64).reshape(-1)
+        im = np.array([[-1 if v is None else int(v) for v in row] for row in images], dtype=np.int32)
+        if ta.shape != fr.shape or im.shape != (len(fr), self.O):
+            raise ValueError("frames (T,), taus (T,) and images (T, O) do not agree")
+        check(self.lib.glh_track(self.handle, len(fr), _ptr(fr), _ptr(ta), _ptr(np.ascontiguousarray(im)), seed))
 
     def set_fused(self, mode=1):
         """0 staged kernels, 1 fused per-point kernel (default), 2 fused with tiles forced to HBM (test)."""

@@ -1267,6 +1267,24 @@ extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images
   return glh_record_moments(c, frame);
 }
 
+// The frame loop of every track (tracker.py:326-357) in one call: n_frames consecutive glh_step updates with the
+// device RNG, enqueued back to back on the context's stream (no host synchronisation in between).
+extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const double* taus, const int32_t* images,
+                         uint64_t seed) {
+  CHK(need_seq(c));
+  if (n_frames <= 0 || !frames || !taus || !images)
+    return fail(GLH_E_INVALID, "n_frames must be > 0 and the arrays non-null");
+  const int O = c->cfg.n_observers;
+  for (int k = 0; k < n_frames; ++k) {
+    if (frames[k] < 0 || frames[k] >= c->cfg.max_frames)
+      return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frames[k]);
+    CHK(check_images(c, images + (size_t)k * O));
+  }
+  for (int k = 0; k < n_frames; ++k)
+    CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
+  return GLH_OK;
+}
+
 extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
   CHK(need_seq(c));
   if (!stamps) return fail(GLH_E_INVALID, "null argument");

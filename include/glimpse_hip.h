@@ -214,6 +214,13 @@ int glh_record_moments(glh_ctx* ctx, int frame);
  * track/tracker.py:331-357 for all active points, enqueued back to back.                   */
 int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng_mode,
              const double* normals, const double* u, uint64_t seed);
+/* The whole frame loop of every track (track/tracker.py:326-357: `for i, img in enumerate(...)` of
+ * process()) in one call: n_frames consecutive glh_step updates with GLH_RNG_PHILOX, enqueued back
+ * to back on the context's stream without host synchronisation.  frames [n_frames] = history
+ * slots / Philox steps, taus [n_frames] = dt / time_unit of each update, images [n_frames][O]
+ * (-1 = None).  Same results as the same glh_step calls.                                       */
+int glh_track(glh_ctx* ctx, int n_frames, const int32_t* frames, const double* taus, const int32_t* images,
+              uint64_t seed);
 
 /* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +
  * re-evolving gather + moments in one launch, evolved state never round-trips through HBM)

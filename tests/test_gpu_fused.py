@@ -107,6 +107,52 @@ def test_fused_step_equals_staged_with_device_rng(lib, cfg):
     assert abs(np.median(vx) - 0.15) < 0.05
 
 
+@pytest.mark.parametrize("cfg", [("C2", 16, 2000, 1, 1), ("C3", 6, 5000, 1, 1), ("C5", 4, 3001, 1, 1),
+                                 ("C3", 3, 10240, 1, 1), ("C3", 2, 12000, 1, 1), ("C5", 3, 1500, 3, 1),
+                                 ("C3", 5, 5000, 1, 2), ("C3", 700, 512, 1, 1)])
+def test_track_equals_the_same_steps(lib, cfg):
+    """glh_track (the frame loop of tracker.py:326-357 in one call) leaves exactly what the same glh_step calls
+    leave: particles, weights, every row of the moments history, statuses.  Includes
+    frames an observer skips (image None), tiles forced to the HBM workspaces, non-unit and negative time steps,
+    and more tracks than resident workgroups."""
+    from glimpse_amd import workloads
+
+    name, P, N, channels, mode = cfg
+    T = 7
+    wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [[wl.scene.render(wl.cams[o], float(t), channels=channels) for t in range(T)] for o in range(wl.O)]
+    images = [[i] * wl.O for i in range(1, T)]
+    if wl.O > 1:
+        images[2][1] = None  # observer 1 has no image matching frame 3
+    taus = [1.0] * (T - 1)
+    res = []
+    for how in ("steps", "track", "split"):
+        with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
+            workloads.setup_context(ctx, wl, frames, channels=channels)
+            ctx.set_fused(mode)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=11)
+            for o in range(wl.O):
+                ctx.init_templates(o, 0)
+            ctx.record_moments(0)
+            fr = list(range(1, T))
+            if how == "steps":
+                for i in fr:
+                    ctx.step(i, taus[i - 1], images[i - 1], seed=11)
+            elif how == "track":
+                ctx.track(fr, taus, images, seed=11)
+            else:  # an odd and an even number of frames per call, then a single step
+                ctx.track(fr[:3], taus[:3], images[:3], seed=11)
+                ctx.track(fr[3:5], taus[3:5], images[3:5], seed=11)
+                ctx.step(fr[5], taus[5], images[5], seed=11)
+            res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T), ctx.point_status(),
+                        ctx.observer_status(), ctx.search_boxes()))
+    assert (res[0][3] == 0).all()
+    for other in (1, 2):
+        for k in range(6):
+            np.testing.assert_array_equal(res[0][k], res[other][k])
+
+
 def test_sharded_contexts_reproduce_the_unsharded_run(lib):
     """Device RNG is keyed on the GLOBAL point index (glh_set_point_offset): two contexts tracking
     points [0, 5) and [5, 8) give exactly the particles of one context tracking all 8."""
