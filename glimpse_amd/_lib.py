@@ -393,7 +393,8 @@ class Context:
         return {"box": box, "duv": duv, "tile": tile, "histogram": (hv[: hn.value].copy(), hq[: hn.value].copy())}
 
     def set_debug(self, keep=True):
-        check(self.lib.glh_set_debug(self.handle, int(bool(keep))))
+        """True / 1: SSE surfaces, log likelihoods and resample indices are kept (staged kernels); 2: indices only."""
+        check(self.lib.glh_set_debug(self.handle, int(keep)))
 
     def likelihood_debug(self, obs, point, want_sse=True):
         """uv (N,2), box (4,) or None, search float32 (Hs,Ws), sse float64 (Ho,Wo)."""

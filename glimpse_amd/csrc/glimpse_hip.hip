@@ -678,9 +678,11 @@ extern "C" int glh_get_resample_indices(glh_ctx* c, int32_t* idx) {
 extern "C" int glh_set_debug(glh_ctx* c, int keep) {
   if (!c) return fail(GLH_E_INVALID, "null context");
   HIPCHK(hipSetDevice(c->cfg.device_id));
-  c->keep_sse = keep != 0;
+  if (keep < 0 || keep > 2) return fail(GLH_E_INVALID, "keep must be 0, 1 or 2");
+  c->keep_sse = keep == 1;
   c->keep_idx = keep != 0;
-  if (keep) {
+  if (keep == 2 && !c->idx) CHK(dalloc(&c->idx, (size_t)c->cfg.max_points * c->cfg.max_particles));
+  if (keep == 1) {
     if (!c->sse_copy)
       CHK(dalloc(&c->sse_copy, (size_t)c->cfg.n_observers * c->cfg.max_points * (size_t)c->sse_cap));
     if (!c->idx) CHK(dalloc(&c->idx, (size_t)c->cfg.max_points * c->cfg.max_particles));

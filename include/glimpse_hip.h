@@ -249,8 +249,10 @@ int glh_get_template(glh_ctx* ctx, int obs, int point, int32_t* box, double* duv
  * float32 SSE surface widened, before the spline fit).  Any pointer may be NULL.           */
 int glh_get_likelihood_debug(glh_ctx* ctx, int obs, int point, double* uv, int32_t* box,
                              float* search, double* sse);
-/* Keep a copy of the SSE surface before the in-place spline fit and the resample indices
- * (costs extra passes; off by default, on for parity tests).                                */
+/* keep = 1: keep a copy of the SSE surface before the in-place spline fit, the per-observer log
+ * likelihoods and the resample indices (costs extra passes and takes glh_step through the staged
+ * kernels; off by default, on for parity tests).  keep = 2: the resample indices only (glh_step
+ * stays on the fused kernel).                                                                  */
 int glh_set_debug(glh_ctx* ctx, int keep);
 /* Per-observer log likelihoods of the last glh_update_weights, i.e. the return value of
  * compute_observer_log_likelihoods (track/tracker.py:563-625): ll [P][N], NaN where the
