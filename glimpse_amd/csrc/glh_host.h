@@ -162,6 +162,46 @@ inline void spline_lu(int n, double* out) {
   }
 }
 
+// The same collocation matrix inverted explicitly (row-major n x n): for small surfaces the fit is two
+// dense products, Ih . Z . Iw^T, in which every coefficient is an independent dot product (the banded solves
+// above are two serial chains of n steps per line).  Gauss-Jordan with partial pivoting in long double, rounded
+// once to double; the matrix is diagonally dominant by rows (condition number < 10).
+inline void spline_inverse(int n, double* out) {
+  std::vector<long double> a((size_t)n * n, 0.0L), b((size_t)n * n, 0.0L);
+  for (int i = 0; i < n; ++i) {
+    int q = spline_interval((double)i, n);
+    double h[4];
+    spline_basis((double)i, q, n, 0.0, h);
+    for (int m = 0; m < 4; ++m)
+      if (q + m >= 0 && q + m < n) a[(size_t)i * n + q + m] = (long double)h[m];
+    b[(size_t)i * n + i] = 1.0L;
+  }
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (fabsl(a[(size_t)i * n + k]) > fabsl(a[(size_t)piv * n + k])) piv = i;
+    if (piv != k)
+      for (int j = 0; j < n; ++j) {
+        std::swap(a[(size_t)k * n + j], a[(size_t)piv * n + j]);
+        std::swap(b[(size_t)k * n + j], b[(size_t)piv * n + j]);
+      }
+    const long double d = 1.0L / a[(size_t)k * n + k];
+    for (int j = 0; j < n; ++j) {
+      a[(size_t)k * n + j] *= d;
+      b[(size_t)k * n + j] *= d;
+    }
+    for (int i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const long double m = a[(size_t)i * n + k];
+      if (m == 0.0L) continue;
+      for (int j = 0; j < n; ++j) {
+        a[(size_t)i * n + j] -= m * a[(size_t)k * n + j];
+        b[(size_t)i * n + j] -= m * b[(size_t)k * n + j];
+      }
+    }
+  }
+  for (size_t i = 0; i < (size_t)n * n; ++i) out[i] = (double)b[i];
+}
 // NumPy's pairwise float sum over n contiguous items (np.add.reduce: 8192-item chunks;
 // <= 128-item leaves with 8 interleaved accumulators; split at n/2 rounded down to 8) as a
 // tree the resample kernel can evaluate level by level:

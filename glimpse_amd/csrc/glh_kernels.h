@@ -1014,9 +1014,38 @@ struct SplineFitArgs {
   const int32_t* obs_status;
   const double* lu;          // packed factors: for n, 5 arrays of n at lu_off[n]
   const int64_t* lu_off;     // [max_n + 1]
+  const double* inv;         // explicit inverses for sides 4 .. GLH_SPL_DENSE_MAX at spline_inverse_off(n)
   double* sse;               // in: SSE surface, out: B-spline coefficients
   double* sse_copy;          // optional debug copy of the surface (or null)
 };
+
+// The fit of a small surface as two dense products with the explicit inverses, C = Ih . Z . Iw^T: one
+// independent dot product per coefficient (k ascending, separate multiply and add) instead of two serial chains
+// per line.  Z [ho][wo] in place, Z1 [ho * wo] scratch; whole block, NT threads.  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void spline_fit_dense(double* Z, double* Z1, int wo, int ho, const double* Ih,
+                                                 const double* Iw) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < ho * wo; idx += NT) {
+    const int r = idx / wo, c = idx - r * wo;
+    const double* row = Ih + (size_t)r * ho;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < ho; ++k) acc += row[k] * Z[(size_t)k * wo + c];
+    Z1[idx] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < ho * wo; idx += NT) {
+    const int r = idx / wo, c = idx - r * wo;
+    const double* row = Iw + (size_t)c * wo;
+    const double* zr = Z1 + (size_t)r * wo;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < wo; ++k) acc += zr[k] * row[k];
+    Z[idx] = acc;
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ void solve_line(double* x, int stride, int n, const double* f) {
   const double *l1 = f, *l2 = f + n, *u0i = f + 2 * n, *u1 = f + 3 * n, *u2 = f + 4 * n;
@@ -1051,6 +1080,11 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
     double* cp = a.sse_copy + slot * (size_t)a.sse_cap;
     for (int idx = tid; idx < wo * ho; idx += BLK) cp[idx] = z[idx];
     __syncthreads();
+  }
+  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
+    __shared__ double z1[GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX];
+    spline_fit_dense<BLK>(z, z1, wo, ho, a.inv + spline_inverse_off(ho), a.inv + spline_inverse_off(wo));
+    return;
   }
   const double* fh = a.lu + a.lu_off[ho];
   const double* fw = a.lu + a.lu_off[wo];

@@ -359,6 +359,15 @@ GLH_HD double knot_local(int i, int n) {
 }
 
 // interval q (0 <= q <= n-4) that holds local coordinate xl in [0, n-1]
+// largest SSE-surface side whose spline fit goes through the explicit inverse of the collocation matrix
+// (glh_host.h: spline_inverse); larger surfaces use the banded LU solves
+constexpr int GLH_SPL_DENSE_MAX = 48;
+GLH_HD int64_t spline_inverse_off(int n) {  // offset of the n x n inverse in the packed table (sizes 4 .. MAX)
+  // sum_{m=4}^{n-1} m^2
+  const int64_t k = n - 1;
+  return k * (k + 1) * (2 * k + 1) / 6 - 14;
+}
+
 GLH_HD int spline_interval(double xl, int n) {
   int m = (int)floor(xl) - 1;
   if (m < 0) m = 0;

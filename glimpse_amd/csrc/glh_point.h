@@ -115,6 +115,7 @@ struct PointArgs {
   double* ws_sse;              // [O][P][sse_cap]
   const double* lu;            // spline LU factors by size (glh_host.h)
   const int64_t* lu_off;
+  const double* inv;           // explicit spline-matrix inverses, sides 4 .. GLH_SPL_DENSE_MAX (glh_host.h)
   const double* poly;          // [GLH_NPOLY][16]
   int32_t* idx_out;            // [P][N] or null
   unsigned long long* stamps;  // [P][PT_NSTAMP] s_memtime at the phase boundaries (diagnostic), or null
@@ -162,6 +163,9 @@ struct TileWs {
   float* S;         // [hs][ld] search tile
   uint16_t* keys;   // [hs * ws] raw pixel keys
   double* Z;        // [ho * wo] SSD surface -> spline coefficients
+  double* Z1;       // [ho * wo] scratch of the dense spline fit (sides <= GLH_SPL_DENSE_MAX), always LDS
+  const double* ih;  // explicit inverses of the ho / wo collocation matrices (LDS copy or the global table)
+  const double* iw;
   const double* cdf_q;
   const double* cdf_v;
   const double* fh;  // LU factors for ho / wo
@@ -351,6 +355,10 @@ __device__ __forceinline__ void pt_solve_line(double* x, int stride, int n, cons
 template <int TB>
 __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) {
   const int tid = threadIdx.x;
+  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
+    spline_fit_dense<TB>(ws.Z, ws.Z1, wo, ho, ws.ih, ws.iw);
+    return;
+  }
   for (int c = tid; c < wo; c += TB) pt_solve_line(ws.Z + c, wo, ho, ws.fh);
   __syncthreads();
   for (int r = tid; r < ho; r += TB) pt_solve_line(ws.Z + (size_t)r * wo, 1, wo, ws.fw);
@@ -607,7 +615,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int s_bytes = pt_align16(hs * ld_lds * 4);
     const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
     const int l1 = hcl + pt_align16(hs * ws_ * 2);
-    const int l2 = pt_align16(ho * wo * 8) + pt_align16(5 * (ho + wo) * 8);
+    const bool dense = ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX;  // spline fit by explicit inverses
+    const int zb = pt_align16(ho * wo * 8);
+    // small inverses (one entry per thread) are fetched before the SSD and parked in LDS after it, like the LU
+    // factors of the larger surfaces: no memory latency inside the fit
+    const int ninv = ho * ho + wo * wo;
+    const bool inv_lds = dense && ninv <= TB;
+    const int l2 = dense ? 2 * zb + (inv_lds ? pt_align16(ninv * 8) : 0) : zb + pt_align16(5 * (ho + wo) * 8);
     const bool fits = off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
@@ -664,12 +678,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);  // starts with a barrier: T, cdf visible
       PT_STAMP(2);
       ws.Z = reinterpret_cast<double*>(X);
-      double* fl = ws.Z + pt_align16(ho * wo * 8) / 8;
+      ws.Z1 = ws.Z + zb / 8;
+      double* fl = ws.Z + zb / 8;  // LU factors (larger surfaces only): same place as Z1
+      double* invl = ws.Z1 + zb / 8;
+      ws.ih = a.inv + spline_inverse_off(ho);
+      ws.iw = a.inv + spline_inverse_off(wo);
       // X is reused: the histogram / keys are dead once the search tile is written.  The LU factors are
       // fetched before the SSD and parked in LDS after it, so their memory latency hides behind it.
-      const int nfl = 5 * (ho + wo);
+      const int nfl = dense ? 0 : 5 * (ho + wo);
       double fl_v = 0.0;
-      if (nfl <= TB) {
+      double* park = nullptr;
+      if (inv_lds) {
+        if (tid < ho * ho) fl_v = ws.ih[tid];
+        else if (tid < ninv) fl_v = ws.iw[tid - ho * ho];
+        if (tid < ninv) park = invl + tid;
+      } else if (dense) {
+      } else if (nfl <= TB) {
+        if (tid < nfl) park = fl + tid;
         if (tid < 5 * ho) fl_v = fh_g[tid];
         else if (tid < nfl) fl_v = fw_g[tid - 5 * ho];
       } else {
@@ -678,9 +703,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       ws.fh = fl;
       ws.fw = fl + 5 * ho;
-      pt_ssd<TB>(ws, tw, th, wo, ho, nfl <= TB && tid < nfl ? fl + tid : nullptr, fl_v);
+      pt_ssd<TB>(ws, tw, th, wo, ho, park, fl_v);
       PT_STAMP(3);
-      pt_spline_fit<TB>(ws, wo, ho);
+      if (inv_lds) {  // (its own call: the inverses' address space stays known)
+        ws.ih = invl;
+        ws.iw = invl + ho * ho;
+        pt_spline_fit<TB>(ws, wo, ho);
+      } else {
+        pt_spline_fit<TB>(ws, wo, ho);
+      }
       PT_STAMP(4);
       sample_all(ws.Z);
     } else {
@@ -695,6 +726,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.S = a.ws_search + slot * (size_t)a.search_cap;
       ws.keys = a.ws_keys + slot * (size_t)a.keys_cap;
       ws.Z = a.ws_sse + slot * (size_t)a.sse_cap;
+      ws.Z1 = reinterpret_cast<double*>(X);  // over the histogram / LUT: dead once the search tile is written
+      ws.ih = a.inv + spline_inverse_off(ho);
+      ws.iw = a.inv + spline_inverse_off(wo);
       ws.cdf_q = hq_g;
       ws.cdf_v = hv_g;
       ws.fh = fh_g;

@@ -119,6 +119,7 @@ struct glh_ctx {
   double* lu = nullptr;
   double* poly = nullptr;
   int64_t* lu_off = nullptr;
+  double* spl_inv = nullptr;  // explicit inverses of the collocation matrices, sides 4 .. GLH_SPL_DENSE_MAX
   int32_t *leaf_off = nullptr, *leaf_len = nullptr, *sum_ops = nullptr, *level_off = nullptr, *roots = nullptr;
   int nleaves = 0, nnodes = 0, nlevels = 0, nroots = 0;
   int moments_frame = -1;  // history slot already filled by the fused resample kernel
@@ -230,7 +231,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
-  dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->leaf_off);
+  dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -319,6 +320,13 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
           hipMemcpy(c->lu_off, off.data(), (maxn + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(GLH_E_HIP, "upload of the spline LU table failed");
     }
+  }
+  if (rc == GLH_OK) {
+    std::vector<double> inv((size_t)spline_inverse_off(GLH_SPL_DENSE_MAX + 1));
+    for (int n = 4; n <= GLH_SPL_DENSE_MAX; ++n) spline_inverse(n, inv.data() + spline_inverse_off(n));
+    A(dalloc(&c->spl_inv, inv.size()));
+    if (rc == GLH_OK && hipMemcpy(c->spl_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(GLH_E_HIP, "upload of the spline inverse table failed");
   }
   if (rc == GLH_OK) {
     std::vector<double> tab(16 * GLH_NPOLY);
@@ -927,6 +935,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     sf.obs_status = c->obs_status;
     sf.lu = c->lu;
     sf.lu_off = c->lu_off;
+    sf.inv = c->spl_inv;
     sf.sse = c->sse;
     sf.sse_copy = c->keep_sse ? c->sse_copy : nullptr;
     {
@@ -1077,7 +1086,8 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   // c[N] and, behind region 2, the pairwise-sum plan
   const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
   const int plan = pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8 + pt_align16(c->N * 2);  // nodes | clast | sidx
-  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb));
+  // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
+  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX * 8);
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + 48 * 48 * 2 + 4096;
   int r2;
@@ -1124,6 +1134,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.ws_sse = c->sse;
   a.lu = c->lu;
   a.lu_off = c->lu_off;
+  a.inv = c->spl_inv;
   a.poly = c->poly;
   a.idx_out = c->keep_idx ? c->idx : nullptr;
   a.stamps = c->stamps;
@@ -1591,7 +1602,13 @@ extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const
   }
   std::vector<double> z((size_t)ho * wo);
   for (size_t i = 0; i < z.size(); ++i) z[i] = (double)sse[i];
-  DevBuf dz, dlu, doff, dbox, dst, duv, dval, dout;
+  DevBuf dz, dlu, doff, dbox, dst, duv, dval, dout, dinv;
+  {
+    std::vector<double> inv((size_t)spline_inverse_off(GLH_SPL_DENSE_MAX + 1));
+    for (int m = 4; m <= GLH_SPL_DENSE_MAX; ++m)
+      if (m == ho || m == wo) spline_inverse(m, inv.data() + spline_inverse_off(m));
+    CHK(dinv.up(inv.data(), inv.size() * 8));
+  }
   CHK(dz.up(z.data(), z.size() * 8));
   CHK(dlu.up(lu.data(), lu.size() * 8));
   CHK(doff.up(off.data(), off.size() * 8));
@@ -1606,6 +1623,7 @@ extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const
   sf.obs_status = dst.as<int32_t>();
   sf.lu = dlu.as<double>();
   sf.lu_off = doff.as<int64_t>();
+  sf.inv = dinv.as<double>();
   sf.sse = dz.as<double>();
   sf.sse_copy = nullptr;
   hipLaunchKernelGGL(k_spline_fit, dim3(1), dim3(BLK), 0, 0, sf);

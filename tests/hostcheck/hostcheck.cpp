@@ -48,7 +48,7 @@ void hc_median25(const int* v, int n, int* out) {
 
 int hc_reflect(int i, int n) { return reflect_index(i, n); }
 
-// fit (two passes of banded solves with spline_lu factors) + evaluate
+// fit (explicit inverses for small surfaces, two passes of banded solves with spline_lu factors beyond) + evaluate
 void hc_spline_sample(const double* z, int ho, int wo, const double* box, const double* uv, int n, double* out) {
   std::vector<double> c(z, z + (size_t)ho * wo), fh(5 * (size_t)ho), fw(5 * (size_t)wo);
   spline_lu(ho, fh.data());
@@ -67,8 +67,27 @@ void hc_spline_sample(const double* z, int ho, int wo, const double* box, const 
       x[(size_t)i * stride] = acc * u0i[i];
     }
   };
-  for (int cidx = 0; cidx < wo; ++cidx) solve(c.data() + cidx, wo, ho, fh.data());
-  for (int r = 0; r < ho; ++r) solve(c.data() + (size_t)r * wo, 1, wo, fw.data());
+  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
+    // small surfaces: C = Ih . Z . Iw^T with the explicit inverses (spline_fit_dense of glh_kernels.h)
+    std::vector<double> ih((size_t)ho * ho), iw((size_t)wo * wo), z1((size_t)ho * wo);
+    spline_inverse(ho, ih.data());
+    spline_inverse(wo, iw.data());
+    for (int r = 0; r < ho; ++r)
+      for (int cc = 0; cc < wo; ++cc) {
+        double acc = 0.0;
+        for (int k = 0; k < ho; ++k) acc += ih[(size_t)r * ho + k] * c[(size_t)k * wo + cc];
+        z1[(size_t)r * wo + cc] = acc;
+      }
+    for (int r = 0; r < ho; ++r)
+      for (int cc = 0; cc < wo; ++cc) {
+        double acc = 0.0;
+        for (int k = 0; k < wo; ++k) acc += z1[(size_t)r * wo + k] * iw[(size_t)cc * wo + k];
+        c[(size_t)r * wo + cc] = acc;
+      }
+  } else {
+    for (int cidx = 0; cidx < wo; ++cidx) solve(c.data() + cidx, wo, ho, fh.data());
+    for (int r = 0; r < ho; ++r) solve(c.data() + (size_t)r * wo, 1, wo, fw.data());
+  }
   double cu0 = cell_origin(box[0], box[2], wo), cv0 = cell_origin(box[1], box[3], ho);
   for (int i = 0; i < n; ++i) out[i] = spline_eval(c.data(), wo, ho, wo, cv0, cu0, uv[2 * i], uv[2 * i + 1]);
 }
