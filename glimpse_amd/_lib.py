@@ -61,6 +61,7 @@ SIGNATURES = {
     "glh_observer_init": (_I, [_P, _I, _I, _I, _I, _I, _D]),
     "glh_observer_set_cameras": (_I, [_P, _I, _I, _I, _P]),
     "glh_observer_upload_frame": (_I, [_P, _I, _I, _P]),
+    "glh_observer_upload_frame_async": (_I, [_P, _I, _I, _P]),
     "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
     "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
     "glh_set_motion_cartesian": (_I, [_P, _P]),
@@ -204,6 +205,11 @@ class Context:
     def observer_upload_frame(self, obs, image, pixels):
         pixels = _arr(pixels, np.uint8)
         check(self.lib.glh_observer_upload_frame(self.handle, obs, image, _ptr(pixels)))
+
+    def observer_upload_frame_async(self, obs, image, pixels):
+        """Upload without waiting for the device; `pixels` may be reused as soon as the call returns."""
+        pixels = _arr(pixels, np.uint8)
+        check(self.lib.glh_observer_upload_frame_async(self.handle, obs, image, _ptr(pixels)))
 
     def observer_set_frame_device(self, obs, image, dev_ptr, owner=None):
         if owner is not None:

@@ -87,6 +87,16 @@ struct Observer {
 struct glh_ctx {
   glh_config cfg{};
   hipStream_t stream = nullptr;
+  // frame ingest (glh_observer_upload_frame_async): a copy stream and a ring of pinned staging buffers
+  static constexpr int NSTAGE = 4;
+  hipStream_t copy_stream = nullptr;
+  uint8_t* stage[NSTAGE] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[NSTAGE] = {0, 0, 0, 0};
+  hipEvent_t stage_done[NSTAGE] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy[NSTAGE] = {false, false, false, false};
+  int stage_next = 0;
+  hipEvent_t upload_done = nullptr;  // recorded on copy_stream after the latest upload
+  bool uploads_pending = false;      // the compute stream has not yet been ordered after upload_done
   int P = 0, N = 0, tw = 0, th = 0, NB = 0;
   int cur = 0;  // current particle/weight buffer
   int frame = 0;
@@ -233,6 +243,15 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
+  for (int k = 0; k < glh_ctx::NSTAGE; ++k) {
+    if (c->stage[k]) (void)hipHostFree(c->stage[k]);
+    if (c->stage_done[k]) (void)hipEventDestroy(c->stage_done[k]);
+  }
+  if (c->upload_done) (void)hipEventDestroy(c->upload_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GLH_OK;
@@ -365,8 +384,18 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   return GLH_OK;
 }
 
+// Order the compute stream after the frame uploads enqueued so far (no host wait).
+static int join_uploads(glh_ctx* c) {
+  if (c->uploads_pending) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->upload_done, 0));
+    c->uploads_pending = false;
+  }
+  return GLH_OK;
+}
+
 extern "C" int glh_sync(glh_ctx* c) {
   if (!c) return fail(GLH_E_INVALID, "null context");
+  CHK(join_uploads(c));
   HIPCHK(hipStreamSynchronize(c->stream));
   return GLH_OK;
 }
@@ -437,6 +466,44 @@ extern "C" int glh_observer_upload_frame(glh_ctx* c, int o, int image, const uin
   if (!ob.owned[image]) CHK(dalloc(&ob.owned[image], bytes));
   HIPCHK(hipMemcpyAsync(ob.owned[image], pixels, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  ob.frames[image] = ob.owned[image];
+  return GLH_OK;
+}
+
+// The same upload without waiting for the device: `pixels` is copied into a pinned staging buffer before the call
+// returns (the caller may reuse it at once), the host-to-device copy runs on a copy stream, and the next call that
+// reads frames is ordered after it on the device.  A decoder pool can so keep the PCIe link busy while it decodes.
+extern "C" int glh_observer_upload_frame_async(glh_ctx* c, int o, int image, const uint8_t* pixels) {
+  CHK(check_obs(c, o));
+  Observer& ob = c->obs[o];
+  if (!pixels || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const size_t bytes = (size_t)ob.width * ob.height * ob.channels;
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
+  }
+  const int k = c->stage_next;
+  c->stage_next = (k + 1) % glh_ctx::NSTAGE;
+  if (c->stage_busy[k]) {  // the copy that last used this slot has to be over before it is overwritten
+    HIPCHK(hipEventSynchronize(c->stage_done[k]));
+    c->stage_busy[k] = false;
+  }
+  if (c->stage_bytes[k] < bytes) {
+    if (c->stage[k]) HIPCHK(hipHostFree(c->stage[k]));
+    c->stage[k] = nullptr;
+    c->stage_bytes[k] = 0;
+    HIPCHK(hipHostMalloc((void**)&c->stage[k], bytes, hipHostMallocDefault));
+    c->stage_bytes[k] = bytes;
+  }
+  if (!c->stage_done[k]) HIPCHK(hipEventCreateWithFlags(&c->stage_done[k], hipEventDisableTiming));
+  memcpy(c->stage[k], pixels, bytes);
+  if (!ob.owned[image]) CHK(dalloc(&ob.owned[image], bytes));
+  HIPCHK(hipMemcpyAsync(ob.owned[image], c->stage[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(hipEventRecord(c->stage_done[k], c->copy_stream));
+  HIPCHK(hipEventRecord(c->upload_done, c->copy_stream));
+  c->stage_busy[k] = true;
+  c->uploads_pending = true;
   ob.frames[image] = ob.owned[image];
   return GLH_OK;
 }
@@ -766,7 +833,7 @@ static int check_images(glh_ctx* c, const int32_t* images) {
     if (images[o] >= ob.n_images) return fail(GLH_E_INVALID, "observer %d: image %d out of range", o, images[o]);
     if (!ob.frames[images[o]]) return fail(GLH_E_STATE, "observer %d: image %d has not been uploaded", o, images[o]);
   }
-  return GLH_OK;
+  return join_uploads(c);  // the kernels that follow read the frames
 }
 
 // evolve (optional) + project into the given images + bbox partials
@@ -842,6 +909,7 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   const Observer& ob = c->obs[o];
   if (image < 0 || image >= ob.n_images || !ob.frames[image])
     return fail(GLH_E_STATE, "observer %d: image %d is not resident", o, image);
+  CHK(join_uploads(c));
   CHK(launch_moments(c, c->mean6, 6, 0));  // particle_mean with the carried weights (tracker.py:548)
   TemplateArgs a{};
   a.mean6 = c->mean6;

@@ -14,6 +14,7 @@ gives the reference's particles, indices and posteriors.  `rng="philox"` draws o
 (counter-based Philox4x32-10) and is what large runs use.
 """
 import datetime
+import os
 import warnings as _warnings
 
 import numpy as np
@@ -145,11 +146,34 @@ class Tracker:
         return ctx
 
     def _upload_images(self, ctx, matching):
-        for o, obs in enumerate(self.observers):
-            for img in sorted({m for m in matching[:, o] if m is not None}):
-                if (o, img) not in self._uploaded:
-                    ctx.observer_upload_frame(o, int(img), obs.images[img].read())
-                    self._uploaded.add((o, img))
+        """Frames the run will touch -> HBM, once.  Images that still live in files are decoded by a thread pool
+        (Pillow releases the GIL) while the frames already decoded are on their way to the device
+        (glh_observer_upload_frame_async: pinned staging + copy stream)."""
+        todo = [(o, int(img)) for o, obs in enumerate(self.observers)
+                for img in sorted({m for m in matching[:, o] if m is not None}) if (o, img) not in self._uploaded]
+        if not todo:
+            return
+
+        def pixels(job):
+            o, img = job
+            obs = self.observers[o]
+            a = obs.images[img].read(cache=obs.cache)
+            if a.dtype != np.uint8:
+                raise NotImplementedError("frames must be uint8 (gray or RGB) on the GPU path")
+            return np.ascontiguousarray(a)
+
+        on_disk = [j for j in todo if self.observers[j[0]].images[j[1]].array is None]
+        if len(on_disk) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(on_disk))) as pool:
+                for job, a in zip(todo, pool.map(pixels, todo)):
+                    ctx.observer_upload_frame_async(job[0], job[1], a)
+                    self._uploaded.add(job)
+        else:
+            for job in todo:
+                ctx.observer_upload_frame_async(job[0], job[1], pixels(job))
+                self._uploaded.add(job)
 
     def _upload_surfaces(self, ctx, motion_models):
         """One gridded dem, one dem_sigma (shared by every model that uses a raster) and the viewshed."""

@@ -129,6 +129,10 @@ int glh_observer_set_cameras(glh_ctx* ctx, int obs, int first_image, int n_image
                              const double* cams);
 /* Image.read() cached array (image.py:180-186): uint8 [height][width][channels].          */
 int glh_observer_upload_frame(glh_ctx* ctx, int obs, int image, const uint8_t* pixels);
+/* The same without waiting for the device (frame ingest from files: a decoder pool feeds this call).
+ * `pixels` is copied to a pinned staging buffer before the call returns; the host-to-device copy runs
+ * on a copy stream and every later call that reads frames is ordered after it on the device.      */
+int glh_observer_upload_frame_async(glh_ctx* ctx, int obs, int image, const uint8_t* pixels);
 /* Same, from a buffer that is already on the device (no PCIe in the timed region).        */
 int glh_observer_set_frame_device(glh_ctx* ctx, int obs, int image, const void* dev_pixels);
 

@@ -354,3 +354,31 @@ def test_inverse_projection_on_the_device(golden):
     cam = glimpse_amd.Camera(imgsz=10, f=10)
     np.testing.assert_allclose(cam.uv_to_xyz(np.array([(5, 5)])), [[0, 1, 0]], atol=1e-15)
     np.testing.assert_allclose(cam.uv_to_xyz(np.array([(5, 5)]), depth=10), [[0, 10, 0]], atol=1e-14)
+
+
+def test_tracking_from_image_files_equals_tracking_from_arrays(golden, tmp_path):
+    """Frames that live in files (decoded by a thread pool, staged through pinned buffers, uploaded on a copy
+    stream) give the run of the same frames held as arrays, bit for bit."""
+    PIL = pytest.importorskip("PIL.Image")
+    g = golden("g8_c5mini.npz")
+    tile = tuple(int(v) for v in g["tile_size"])
+
+    def run(observers):
+        tracker = glimpse_amd.Tracker(observers, max_search_dim=128)
+        np.random.seed(int(g["seed"]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return tracker.track(models_from(g), tile_size=tile)
+
+    from_arrays = run(observers_from(g))
+    observers = observers_from(g)
+    for o, obs in enumerate(observers):
+        for i, img in enumerate(obs.images):
+            path = tmp_path / f"o{o}_{i:03d}.png"
+            PIL.fromarray(img.array).save(path)
+            img.path, img.array = str(path), None
+        obs.cache = bool(o % 2)  # one observer keeps the decoded frames, the other does not
+    from_files = run(observers)
+    np.testing.assert_array_equal(from_files.means, from_arrays.means)
+    np.testing.assert_array_equal(from_files.sigmas, from_arrays.sigmas)
+    assert (observers[0].images[1].array is None) and (observers[1].images[1].array is not None)

@@ -187,3 +187,35 @@ def test_other_motion_models_host_methods_match_reference(golden):
         ll = model.compute_log_likelihoods(p2)
         assert (ll is not None) == bool(g[f"{name}_has_ll"])
         assert model.params_full().shape == (24,) and model.params_full()[18] == model.KIND
+
+
+def test_image_reads_files_like_arrays(tmp_path):
+    """Image.read (image.py:137-214) from 8-bit PNG / TIFF / JPEG files: same samples as the decoded file, crops
+    equal slices of the whole image, and the cache semantics of the reference."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    cam = glimpse_amd.Camera(imgsz=(40, 30), f=100)
+    gray = rng.integers(0, 256, (30, 40), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    for name, a in (("g.png", gray), ("c.png", rgb), ("g.tif", gray), ("c.tif", rgb)):
+        path = tmp_path / name
+        PIL.fromarray(a).save(path)
+        img = glimpse_amd.Image(path, cam=cam, datetime=T0)
+        np.testing.assert_array_equal(img.read(cache=False), a)
+        assert img.array is None  # cache=False leaves nothing behind (image.py:211-213)
+        np.testing.assert_array_equal(img.read(box=(3, 5, 20, 17)), a[5:17, 3:20])
+        assert img.array is not None and img.array.shape == a.shape
+    path = tmp_path / "c.jpg"
+    PIL.fromarray(rgb).save(path, quality=95)
+    img = glimpse_amd.Image(path, cam=cam, datetime=T0)
+    with PIL.open(path) as im:
+        want = np.asarray(im)
+    np.testing.assert_array_equal(img.read(), want)
+    # a palette image comes back as its RGB samples
+    path = tmp_path / "p.png"
+    PIL.fromarray(rgb).convert("P").save(path)
+    assert glimpse_amd.Image(path, cam=cam, datetime=T0).read().shape == (30, 40, 3)
+    with pytest.raises(NotImplementedError, match="resized"):
+        glimpse_amd.Image(tmp_path / "g.png", cam=glimpse_amd.Camera(imgsz=(20, 15), f=100), datetime=T0).read()
+    with pytest.raises(ValueError):
+        glimpse_amd.Image(cam=cam, datetime=T0)
