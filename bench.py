@@ -134,7 +134,8 @@ def cpu_baseline(wl, frames, steps, target_seconds):
         "cores": 1,
         "kind": "port",
         "sample": f"{n_pts} of {wl.P} points x {wl.N} particles x {steps} steps of the same workload, "
-                  f"oracle/ (NumPy {np.__version__} + SciPy + C SSD), {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+                  f"oracle/ (NumPy {np.__version__} + SciPy + C SSD), {dt:.1f} s on 1 of {os.cpu_count()} host cores "
+                  f"({cpu_model()})",
     }
 
 
@@ -187,6 +188,17 @@ def cpu_baseline_parallel(wl, steps, per_point_seconds, target_seconds, workers)
     }
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,7 +207,7 @@ def main():
     device = int(os.environ.get("GLH_BENCH_DEVICE", local_rank))  # test hook: several ranks on one GPU
     use_nccl = args.dist_backend == "nccl"
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GLH_BENCH_FORCE_DIST") == "1":  # (test hook: the collective path with one rank)
         import torch
         import torch.distributed as dist
 
@@ -344,7 +356,10 @@ def main():
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": abytes / launches_per_step,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
-                "ssd_fp32_tflops": flops / (tot / K * 1e-3) / 1e12}
+                "ssd_fp32_tflops": flops / (tot / K * 1e-3) / 1e12,
+                # the measured device-copy ceiling of this GPU beside the 8 TB/s spec
+                "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
+        roof["frac_of_measured_copy"] = ach / roof["measured_copy_GBps"]
         out["roofline"] = roof
         out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
         if world == 1 and not args.no_cpu_baseline:

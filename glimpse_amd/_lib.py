@@ -104,6 +104,7 @@ SIGNATURES = {
     "glh_stage_count": (_I, []),
     "glh_stage_name": (C.c_char_p, [_I]),
     "glh_profile_get": (_I, [_P, _P, _P]),
+    "glh_measure_copy_bandwidth": (_I, [_P, _U64, _I, _P]),
     "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
     "glh_stage_project_directions": (_I, [_I, _P, _P, _I, _P]),
     "glh_stage_unproject": (_I, [_I, _P, _P, _I, _P, _I, _I, _P]),
@@ -425,6 +426,12 @@ class Context:
         out = np.empty((self.P, self.N), dtype=np.int32)
         check(self.lib.glh_get_resample_indices(self.handle, _ptr(out)))
         return out
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        """Measured device-to-device copy rate (read + write bytes per second, GB/s)."""
+        out = C.c_double(0.0)
+        check(self.lib.glh_measure_copy_bandwidth(self.handle, int(nbytes), int(iters), C.byref(out)))
+        return out.value
 
     def profile_enable(self, on=True):
         check(self.lib.glh_profile_enable(self.handle, int(bool(on))))

@@ -1366,6 +1366,36 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
   return GLH_OK;
 }
 
+extern "C" int glh_measure_copy_bandwidth(glh_ctx* c, uint64_t bytes, int iters, double* gbps) {
+  if (!c || !gbps || bytes == 0 || iters <= 0) return fail(GLH_E_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  uint8_t *src = nullptr, *dst = nullptr;
+  CHK(dalloc(&src, (size_t)bytes));
+  if (dalloc(&dst, (size_t)bytes) != GLH_OK) {
+    dfree(src);
+    return GLH_E_NOMEM;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.0f;
+  hipError_t err = hipMemsetAsync(src, 1, bytes, c->stream);
+  if (err == hipSuccess) err = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream);  // warm-up
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  if (err == hipSuccess) err = hipEventRecord(e0, c->stream);
+  for (int k = 0; k < iters && err == hipSuccess; ++k)
+    err = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream);
+  if (err == hipSuccess) err = hipEventRecord(e1, c->stream);
+  if (err == hipSuccess) err = hipEventSynchronize(e1);
+  if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  dfree(src);
+  dfree(dst);
+  if (err != hipSuccess) return fail(GLH_E_HIP, "copy bandwidth measurement failed: %s", hipGetErrorString(err));
+  *gbps = 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+  return GLH_OK;
+}
+
 extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
   CHK(need_seq(c));
   if (!stamps) return fail(GLH_E_INVALID, "null argument");

@@ -271,6 +271,9 @@ int glh_profile_reset(glh_ctx* ctx);
 int glh_stage_count(void);
 const char* glh_stage_name(int stage);
 int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /* [stages] */);
+/* Measured device-copy ceiling of this GPU: `iters` device-to-device copies of `bytes`
+ * bytes on the context's stream between two HIP events; *gbps = bytes read + bytes written per second / 1e9. */
+int glh_measure_copy_bandwidth(glh_ctx* ctx, uint64_t bytes, int iters, double* gbps);
 
 /* ---- stage-level test hooks (stateless; each runs one kernel on explicit inputs) -------- */
 /* Camera.xyz_to_uv (camera.py:591-628): xyz [n][3] -> uv [n][2].                            */
