@@ -16,7 +16,7 @@ MOTION_LEN = 18
 MOTION_FULL_LEN = 24
 MOTION_KINDS = {"cartesian": 0, "cylindrical": 1, "tangent_cartesian": 2, "tangent_cylindrical": 3}
 RNG_HOST, RNG_PHILOX = 0, 1
-RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2}
+RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2, "residual": 3}
 OK = 0
 PT_NAN, PT_TEMPLATE_OOB, PT_SAMPLE_OUTSIDE, PT_RESAMPLE_CLAMP, PT_CONST_TILE = 1, 2, 4, 8, 16
 PT_RASTER_OOB, PT_NOT_VISIBLE = 32, 64
@@ -85,6 +85,7 @@ SIGNATURES = {
     "glh_update_weights": (_I, [_P, _P]),
     "glh_resample": (_I, [_P, _I, _P, _U64, _U64]),
     "glh_resample_method": (_I, [_P, _I, _I, _P, _U64, _U64]),
+    "glh_get_residual_draws": (_I, [_P, _P]),
     "glh_record_covariances": (_I, [_P, _I]),
     "glh_get_covariances": (_I, [_P, _I, _I, _P]),
     "glh_record_moments": (_I, [_P, _I]),
@@ -324,6 +325,12 @@ class Context:
         else:
             uu = _arr(u, np.float64, (self.P,) if m == 0 else (self.P, self.N))
             check(self.lib.glh_resample_method(self.handle, m, RNG_HOST, _ptr(uu), 0, step))
+
+    def residual_draws(self):
+        """Uniforms the last residual resampling consumed per point: n - sum(repetitions) (tracker.py:199-201)."""
+        out = np.empty(self.P, dtype=np.int32)
+        check(self.lib.glh_get_residual_draws(self.handle, _ptr(out)))
+        return out
 
     def record_covariances(self, frame):
         check(self.lib.glh_record_covariances(self.handle, int(frame)))

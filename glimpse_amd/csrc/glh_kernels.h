@@ -1217,6 +1217,7 @@ struct ResampleArgs {
   const uint8_t* active;
   const double* u;   // [P] (systematic, host mode) or [P][N] (stratified / choice, host mode) or null
   int32_t* idx_out;  // [P][N] or null
+  int32_t* n_draws;  // [P] residual: uniforms consumed, n - sum(repetitions); or null
   double* moments;   // [P][12] mean | sigma of the resampled set, or null
   uint32_t* pt_status;
   int32_t* pt_err_frame;
@@ -1243,8 +1244,9 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
   // --- stage the weights in LDS with coalesced loads; everything below reads LDS
   for (int k = tid; k < N; k += BLK) c[k] = W[k];
   __syncthreads();
-  // --- w.sum(): leaves of <= 128 items, 8 interleaved accumulators each (8 lanes per leaf)
-  {
+  // --- c.sum() as NumPy's pairwise tree: leaves of <= 128 items, 8 interleaved accumulators each (8 lanes per
+  //     leaf), then the tree level by level.  Starts from data visible to the block, ends with a barrier.
+  auto pairwise_total = [&]() -> double {
     const int sub = tid & 7;
     for (int L = tid >> 3; L < a.nleaves; L += BLK / 8) {
       const int off = a.leaf_off[L], len = a.leaf_len[L];
@@ -1268,44 +1270,134 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       }
       if (sub == 0) node[L] = res;
     }
-  }
-  __syncthreads();
-  for (int l = 0; l < a.nlevels; ++l) {
-    for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += BLK) {
-      const int32_t* op = a.ops + 3 * k;
-      node[op[0]] = node[op[1]] + node[op[2]];
-    }
     __syncthreads();
-  }
-  double total = node[a.roots[0]];
-  for (int r = 1; r < a.nroots; ++r) total += node[a.roots[r]];
-  // --- cumsum(w / total) in place: contiguous segment per thread, block scan of segment sums
+    for (int l = 0; l < a.nlevels; ++l) {
+      for (int k = a.level_off[l] + tid; k < a.level_off[l + 1]; k += BLK) {
+        const int32_t* op = a.ops + 3 * k;
+        node[op[0]] = node[op[1]] + node[op[2]];
+      }
+      __syncthreads();
+    }
+    double t = node[a.roots[0]];
+    for (int r = 1; r < a.nroots; ++r) t += node[a.roots[r]];
+    __syncthreads();  // node[] may be rewritten by the next call
+    return t;
+  };
+  const double total = pairwise_total();
   const int seg = (N + BLK - 1) / BLK;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
-  double run = 0.0;
-  for (int k = k0; k < k1; ++k) {
-    run += c[k] / total;
-    c[k] = run;
-  }
-  double incl = run;
   const int lane = tid & (WAVE - 1);
+  // inclusive cumsum of c[] in place: contiguous segment per thread, block scan of the segment sums; `quot`
+  // divides every element by it first (cumsum(w / total)).  Ends with a barrier.
+  auto cumsum_inplace = [&](bool divide, double quot) {
+    double run = 0.0;
+    for (int k = k0; k < k1; ++k) {
+      run += divide ? c[k] / quot : c[k];
+      c[k] = run;
+    }
+    double incl = run;
 #pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    double t = __shfl_up(incl, off, WAVE);
-    if (lane >= off) incl += t;
-  }
-  if (lane == WAVE - 1) wave_tot[tid / WAVE] = incl;
-  double prev = __shfl_up(incl, 1, WAVE);  // exclusive prefix inside the wave (no subtraction)
-  if (lane == 0) prev = 0.0;
-  __syncthreads();
-  double base = 0.0;
-  for (int w = 0; w < tid / WAVE; ++w) base += wave_tot[w];
-  const double excl = base + prev;
-  if (tid > 0)
-    for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
-  __syncthreads();
-  const double inv_n = 1.0 / (double)N;
+    for (int off = 1; off < WAVE; off <<= 1) {
+      double t = __shfl_up(incl, off, WAVE);
+      if (lane >= off) incl += t;
+    }
+    if (lane == WAVE - 1) wave_tot[tid / WAVE] = incl;
+    double prev = __shfl_up(incl, 1, WAVE);  // exclusive prefix inside the wave (no subtraction)
+    if (lane == 0) prev = 0.0;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < tid / WAVE; ++w) base += wave_tot[w];
+    const double excl = base + prev;
+    if (tid > 0)
+      for (int k = k0; k < k1; ++k) c[k] = excl + c[k];
+    __syncthreads();
+  };
   uint16_t* sidx = reinterpret_cast<uint16_t*>(node + a.nnodes);  // [N], N < 65536
+  if (a.method == GLH_RESAMPLE_RESIDUAL) {
+    // tracker.py:188-203, arithmetic as written there: the integer repetition counts are subtracted from the
+    // NORMALISED weights, so the scaled residuals change sign and their cumulative sum is not monotone;
+    // np.searchsorted then returns whatever its bisection -- which narrows its range with the previous key's
+    // result -- arrives at.  That search is one serial chain over the keys (thread 0).
+    uint16_t* reps = sidx + N;                 // [N] repetitions = (n * weights).astype(int)
+    __shared__ int s_R;
+    int local = 0;
+    for (int k = k0; k < k1; ++k) {
+      const double wn = c[k] / total;          // weights / weights.sum()
+      const int r = (int)((double)N * wn);     // astype(int): truncation
+      reps[k] = (uint16_t)r;
+      c[k] = wn - (double)r;                   // residuals = weights - repetitions
+      local += r;
+    }
+    // exclusive scan of the per-thread repetition totals -> where each thread's copies start
+    int incl_i = local;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const int t = __shfl_up(incl_i, off, WAVE);
+      if (lane >= off) incl_i += t;
+    }
+    __shared__ int wave_rep[NWAVES];
+    if (lane == WAVE - 1) wave_rep[tid / WAVE] = incl_i;
+    __syncthreads();
+    int start = incl_i - local;
+    for (int w = 0; w < tid / WAVE; ++w) start += wave_rep[w];
+    if (tid == BLK - 1) s_R = start + local;
+    // initial_indexes = np.repeat(np.arange(n), repetitions)
+    for (int k = k0; k < k1; ++k) {
+      const int r = reps[k];
+      for (int j = 0; j < r && start + j < N; ++j) sidx[start + j] = (uint16_t)k;
+      start += r;
+    }
+    __syncthreads();
+    const int R = min(s_R, N);
+    if (tid == 0 && a.n_draws) a.n_draws[pt] = N - R;
+    const double S = pairwise_total();         // residuals.sum()
+    const double scale = 1.0 / S;              // residuals *= 1 / residuals.sum()
+    for (int k = k0; k < k1; ++k) c[k] = c[k] * scale;
+    __syncthreads();
+    cumsum_inplace(false, 1.0);                // cumulative_sum = np.cumsum(residuals)
+    if (tid == 0) {
+      c[N - 1] = 1.0;                          // cumulative_sum[-1] = 1.0
+      // np.searchsorted(cumulative_sum, np.random.random(n - len(initial_indexes))), side='left': NumPy's
+      // npy_binsearch keeps [min_idx, max_idx) from one key to the next -- only one end is reset, depending on
+      // whether the key grew (numpy/_core/src/npysort/binsearch.cpp)
+      const int m = N - R;
+      int min_idx = 0, max_idx = N;
+      double last_key = 0.0;
+      bool clamp = false;
+      for (int j = 0; j < m; ++j) {
+        double key;
+        if (a.rng_mode == GLH_RNG_HOST) {
+          key = a.u[(size_t)pt * N + j];
+        } else {
+          uint32_t r[4];
+          philox4x32_10((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x52455344u, (uint32_t)a.seed,
+                        (uint32_t)(a.seed >> 32), r);
+          key = u01_halfopen(r[0], r[1]);
+        }
+        if (j == 0) last_key = key;
+        if (last_key < key) {
+          max_idx = N;
+        } else {
+          min_idx = 0;
+          max_idx = max_idx < N ? max_idx + 1 : N;
+        }
+        last_key = key;
+        while (min_idx < max_idx) {
+          const int mid = min_idx + ((max_idx - min_idx) >> 1);
+          if (c[mid] < key) min_idx = mid + 1; else max_idx = mid;
+        }
+        int res = min_idx;
+        if (res >= N) {  // IndexError in the reference
+          res = N - 1;
+          clamp = true;
+        }
+        sidx[R + j] = (uint16_t)res;
+      }
+      if (clamp) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+    }
+  } else {
+  cumsum_inplace(true, total);
+  const double inv_n = 1.0 / (double)N;
   if (a.method == GLH_RESAMPLE_SYSTEMATIC) {
     // --- positions (tracker.py:173): pos_j = (j + u) * (1 / n)
     double u;
@@ -1381,6 +1473,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     }
     if (clamp) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
   }
+  }  // methods that search the cumulative weights
   __syncthreads();
   // --- gather + moments
   const double* Pin = a.particles_in + (size_t)pt * N * 6;

@@ -123,6 +123,7 @@ struct glh_ctx {
   double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
   float *tmpl_tile32 = nullptr, *search = nullptr;
   unsigned long long* stamps = nullptr;  // phase stamps of the fused kernel (diagnostic)
+  int32_t* resid_draws = nullptr;  // [P] uniforms consumed by the last residual resampling
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
@@ -240,7 +241,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->stamps);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->resid_draws); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
@@ -1070,8 +1071,10 @@ extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const d
                                    uint64_t step) {
   CHK(need_seq(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
-  if (method != GLH_RESAMPLE_SYSTEMATIC && method != GLH_RESAMPLE_STRATIFIED && method != GLH_RESAMPLE_CHOICE)
-    return fail(GLH_E_UNSUPPORTED, "resampling method %d is not provided (systematic, stratified, choice)", method);
+  if (method != GLH_RESAMPLE_SYSTEMATIC && method != GLH_RESAMPLE_STRATIFIED && method != GLH_RESAMPLE_CHOICE &&
+      method != GLH_RESAMPLE_RESIDUAL)
+    return fail(GLH_E_INVALID, "unknown resampling method %d", method);
+  if (method == GLH_RESAMPLE_RESIDUAL && !c->resid_draws) CHK(dalloc(&c->resid_draws, (size_t)c->cfg.max_points));
   const bool per_particle = method != GLH_RESAMPLE_SYSTEMATIC;
   if (rng_mode == GLH_RNG_HOST) {
     if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u (%s)", per_particle ? "[P][N]" : "[P]");
@@ -1094,6 +1097,7 @@ extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const d
   a.active = c->have_active ? c->active : nullptr;
   a.u = per_particle ? c->uj : c->u;
   a.idx_out = c->keep_idx ? c->idx : nullptr;
+  a.n_draws = method == GLH_RESAMPLE_RESIDUAL ? c->resid_draws : nullptr;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
   a.moments = c->moments + (size_t)c->frame * c->P * 12;  // fused particle_mean / sigma of frame c->frame
@@ -1121,7 +1125,10 @@ extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const d
   }
   {
     StageTimer t(c, ST_RESAMPLE);
-    size_t lds = ((size_t)c->N + c->nnodes) * sizeof(double) + (size_t)c->N * sizeof(uint16_t);
+    // c[N] | tree nodes | indices [N] u16 | repetitions [N] u16 (residual)
+    size_t lds = ((size_t)c->N + c->nnodes) * sizeof(double) +
+                 (method == GLH_RESAMPLE_RESIDUAL ? 2 : 1) * (size_t)c->N * sizeof(uint16_t);
+    if (lds > 156 * 1024) return fail(GLH_E_UNSUPPORTED, "residual resampling: %d particles exceed the LDS-resident scan", c->N);
     hipLaunchKernelGGL(k_resample, dim3(c->P), dim3(BLK), lds, c->stream, a);
   }
   HIPCHK(hipGetLastError());
@@ -1290,6 +1297,14 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   c->moments_frame = frame;
+  return GLH_OK;
+}
+
+extern "C" int glh_get_residual_draws(glh_ctx* c, int32_t* draws) {
+  CHK(need_seq(c));
+  if (!draws) return fail(GLH_E_INVALID, "null argument");
+  if (!c->resid_draws) return fail(GLH_E_STATE, "no residual resampling has run");
+  DOWNLOAD(draws, c->resid_draws, (size_t)c->P, int32_t);
   return GLH_OK;
 }
 

@@ -59,11 +59,7 @@ class Tracker:
         if viewshed is not None and not isinstance(viewshed, Raster):
             raise TypeError("viewshed must be a glimpse_amd.Raster")
         if resample_method not in _lib.RESAMPLE:
-            # 'residual' (tracker.py:188-203) subtracts integer repetition counts from NORMALISED weights, so its
-            # cumulative sum is not monotone and np.searchsorted's answer depends on the bisection state it
-            # carries from key to key: not reproduced here.
-            raise NotImplementedError(f"resample_method {resample_method!r}: the GPU path provides "
-                                      f"{sorted(_lib.RESAMPLE)} ('residual' is not built)")
+            raise ValueError(f"resample_method {resample_method!r}: expected one of {sorted(_lib.RESAMPLE)}")
         if tuple(highpass.get("size", (5, 5))) != (5, 5) or set(highpass) - {"size"}:
             raise NotImplementedError("the high-pass filter is the reference default: median, size (5, 5)")
         if interpolation.get("kx", 3) != 3 or interpolation.get("ky", 3) != 3:
@@ -235,6 +231,13 @@ class Tracker:
 
         if rng not in ("numpy", "philox"):
             raise ValueError("rng must be 'numpy' or 'philox'")
+        if self.resample_method == "residual" and rng == "numpy":
+            # tracker.py:199-201 draws n - sum(repetitions) uniforms: how far the legacy global stream advances at
+            # every frame of every track depends on that track's weights, so the stream cannot be staged ahead
+            # for a batch of tracks.  The device RNG has no such coupling; resample_particles("residual") (one
+            # track, one step) does follow np.random exactly.
+            raise NotImplementedError("resample_method='residual' with rng='numpy': use rng='philox', or the step "
+                                      "methods (resample_particles) for np.random parity")
         warn_log = [[] for _ in range(ntracks)]
         images_of = lambda i: [m if m is not None else -1 for m in matching[i]]  # noqa: E731
 
@@ -538,15 +541,22 @@ class Tracker:
         return ctx.log_likelihoods(obs)[0]
 
     def resample_particles(self, method=None):
-        """tracker.py:151-223 (systematic, stratified, choice), drawing from the legacy global stream like
-        the reference: random() / random(n) / the n uniforms of np.random.choice."""
+        """tracker.py:151-223 (systematic, stratified, residual, choice), drawing from the legacy global stream
+        like the reference: random() / random(n) / random(n - sum(repetitions)) / the n uniforms of
+        np.random.choice."""
         method = method or self.resample_method
         if method not in _lib.RESAMPLE:
-            raise NotImplementedError(f"resampling method {method!r} is not built on the GPU path")
+            raise ValueError(f"resampling method {method!r}: expected one of {sorted(_lib.RESAMPLE)}")
         ctx = self._single()
         self._push(ctx)
         if method == "systematic":
             ctx.resample(u=np.array([np.random.random()]))
+        elif method == "residual":
+            # the number of uniforms consumed is known only afterwards: draw n, then rewind and re-draw that many
+            state = np.random.get_state()
+            ctx.resample(u=np.random.random(len(self.particles))[None], method=method)
+            np.random.set_state(state)
+            np.random.random(int(ctx.residual_draws()[0]))
         else:
             ctx.resample(u=np.random.random(len(self.particles))[None], method=method)
         self.particles = ctx.get_particles()[0]

@@ -90,6 +90,7 @@ extern "C" {
 #define GLH_RESAMPLE_SYSTEMATIC 0 /* one uniform per point          tracker.py:168-176        */
 #define GLH_RESAMPLE_STRATIFIED 1 /* one uniform per particle       tracker.py:178-186        */
 #define GLH_RESAMPLE_CHOICE 2     /* np.random.choice(n, n, p=w)    tracker.py:205-209        */
+#define GLH_RESAMPLE_RESIDUAL 3   /* as written in the reference     tracker.py:188-203        */
 
 /* ---- random-number modes ------------------------------------------------------------- */
 #define GLH_RNG_HOST 0   /* caller supplies the normals / uniforms (parity with np.random)  */
@@ -203,12 +204,18 @@ int glh_update_weights(glh_ctx* ctx, const int32_t* images /* [O], -1 = None */)
  * GLH_RNG_HOST: u [P] = the np.random.random() draw of each point.                         */
 int glh_resample(glh_ctx* ctx, int rng_mode, const double* u, uint64_t seed, uint64_t step);
 /* Same with an explicit method (GLH_RESAMPLE_*).  GLH_RNG_HOST: u is [P] for systematic (the
- * np.random.random() of each point) and [P][N] for stratified (np.random.random(n)) and
- * choice (the n uniforms RandomState.choice draws).  "residual" is not provided.             */
+ * np.random.random() of each point) and [P][N] for stratified (np.random.random(n)), choice (the n
+ * uniforms RandomState.choice draws) and residual (np.random.random(n - sum(repetitions)): the first
+ * n - R entries of each row are used; glh_get_residual_draws returns the counts).  Residual follows the
+ * reference's arithmetic literally (repetition counts subtracted from normalised weights, then
+ * np.searchsorted's stateful bisection over a cumulative sum that is not monotone).            */
 int glh_resample_method(glh_ctx* ctx, int method, int rng_mode, const double* u, uint64_t seed,
                         uint64_t step);
 /* Tracker.particle_covariance (track/tracker.py:78-82; np.cov(aweights=w, ddof=0)) of every
  * active point into history slot `frame`; glh_get_covariances: out [n_frames][P][36].       */
+/* Number of uniforms the last GLH_RESAMPLE_RESIDUAL step consumed per point, n - sum(repetitions)
+ * (tracker.py:199-201): draws [P].  Lets a host that feeds np.random keep its stream aligned.   */
+int glh_get_residual_draws(glh_ctx* ctx, int32_t* draws);
 int glh_record_covariances(glh_ctx* ctx, int frame);
 int glh_get_covariances(glh_ctx* ctx, int frame0, int n_frames, double* out);
 /* particle_mean + compute_particle_sigma (track/tracker.py:72-76, :89-104) of every active

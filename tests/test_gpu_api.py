@@ -117,6 +117,25 @@ def test_philox_tracking_recovers_velocity(golden):
     assert np.all(np.abs(v[:, 1]) < 0.05), v
 
 
+@pytest.mark.parametrize("method", ["stratified", "residual", "choice"])
+def test_philox_tracking_with_the_other_resampling_methods(golden, method):
+    """Every resampling method of tracker.py:151-223 drives a whole run on the device RNG; residual resampling
+    with the np.random stream is refused for batches (its draw count per frame depends on the weights)."""
+    g = golden("g8_c2mini.npz")
+    tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128, resample_method=method)
+    models = models_from(g)[:3]
+    for m in models:
+        m.n = 1500
+    tracks = tracker.track(models, tile_size=(15, 15), rng="philox", seed=9)
+    assert all(e is None for e in tracks.errors)
+    v = tracks.vxyz[:, -1]
+    assert np.all(np.abs(v[:, 0] - 0.15) < 0.06), v
+    assert np.all(np.abs(v[:, 1]) < 0.06), v
+    if method == "residual":
+        with pytest.raises(NotImplementedError, match="philox"):
+            tracker.track(models, tile_size=(15, 15))
+
+
 @pytest.mark.parametrize("name,tracker_kw,track_kw", [
     ("g9_cov.npz", {}, dict(return_covariances=True)),
     ("g9_stratified.npz", dict(resample_method="stratified"), {}),
@@ -173,8 +192,17 @@ def test_single_track_covariance_and_resample_methods(golden):
         p = weights / weights.sum()
         want = np.random.choice(np.arange(len(p)), size=(len(p),), replace=True, p=p)
         np.testing.assert_array_equal(tracker.particles, particles[want])
-    with pytest.raises(NotImplementedError):
+        # residual: as written in the reference (tracker.py:188-203), same np.random stream -> same particles,
+        # and the stream is left where the reference leaves it (n - sum(repetitions) uniforms consumed)
+        tracker.particles, tracker.weights = particles.copy(), weights.copy()
+        np.random.seed(int(g5[f"r{i}_resid_seed"]))
         tracker.resample_particles(method="residual")
+        np.testing.assert_array_equal(tracker.particles, g5[f"r{i}_resid_out_particles"])
+        after = np.random.random()
+        np.random.seed(int(g5[f"r{i}_resid_seed"]))
+        from oracle import resample as oresample
+        oresample.residual(weights, np.random.random)
+        assert after == np.random.random()
 
 
 def test_other_motion_models_on_the_device(golden):

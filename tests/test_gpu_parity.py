@@ -160,6 +160,40 @@ def test_end_to_end_free_running(lib, golden, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("n", [7, 100, 129, 1000, 5000, 10000])
+def test_residual_resampling_follows_the_reference_literally(lib, golden, n):
+    """GLH_RESAMPLE_RESIDUAL (tracker.py:188-203 as written: repetition counts subtracted from the normalised
+    weights, np.searchsorted's stateful bisection over a cumulative sum that is not monotone) against the oracle
+    (which is pinned to the reference's own outputs, tests/test_oracle_golden.py) on several points at once:
+    indices and the number of uniforms consumed, bit for bit."""
+    rng = np.random.default_rng(n)
+    P = 5
+    particles = rng.standard_normal((P, n, 6))
+    ll = rng.random((P, n)) * rng.choice([1, 5, 40], (P, n))
+    weights = np.exp(-ll) + 1e-300
+    weights[1] = 1.0  # uniform weights: every repetition count is 1 or 0 at the rounding boundary
+    if n >= 100:
+        weights[2, : n // 2] = 1e-300  # half of the particles at the floor
+    u = rng.random((P, n))
+    with lib.Context(P, n, 1, max_frames=2) as ctx:
+        ctx.begin_sequence(P, n, (15, 15))
+        ctx.set_debug(2)
+        ctx.set_particles(particles)
+        ctx.set_weights(weights)
+        ctx.set_frame(0)
+        ctx.resample(u=u, method="residual")
+        idx = ctx.resample_indices()
+        draws = ctx.residual_draws()
+        out_p, out_w = ctx.get_particles(), ctx.get_weights()
+    for p in range(P):
+        want = oresample.residual(weights[p], u[p])
+        np.testing.assert_array_equal(idx[p], want)
+        wn = weights[p] / weights[p].sum()
+        assert draws[p] == n - (n * wn).astype(int).sum()
+        np.testing.assert_array_equal(out_p[p], particles[p][want])
+        np.testing.assert_array_equal(out_w[p], weights[p][want])
+
+
 def test_library_reports_errors(lib):
     with pytest.raises(lib.GlhError):
         lib.Context(0, 10)

@@ -81,8 +81,8 @@ def test_camera_constructor_contract():
 def test_tracker_guards(golden):
     g = golden("g8_c1.npz")
     observers = observers_from(g)
-    with pytest.raises(NotImplementedError):
-        glimpse_amd.Tracker(observers, resample_method="residual")
+    with pytest.raises(ValueError):
+        glimpse_amd.Tracker(observers, resample_method="multinomial")
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker(observers, highpass={"size": (3, 3)})
     tracker = glimpse_amd.Tracker(observers)
