@@ -108,6 +108,7 @@ SIGNATURES = {
     "glh_measure_copy_bandwidth": (_I, [_P, _U64, _I, _P]),
     "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
     "glh_stage_project_directions": (_I, [_I, _P, _P, _I, _P]),
+    "glh_stage_project_depth": (_I, [_I, _P, _P, _I, _I, _P, _P]),
     "glh_stage_unproject": (_I, [_I, _P, _P, _I, _P, _I, _I, _P]),
     "glh_stage_template": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "glh_stage_search_tile": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
@@ -462,6 +463,16 @@ def stage_project(cam, xyz, device_id=0, directions=False):
     fn = load().glh_stage_project_directions if directions else load().glh_stage_project
     check(fn(device_id, _ptr(cam), _ptr(xyz), len(xyz), _ptr(uv)))
     return uv
+
+
+def stage_project_depth(cam, xyz, directions=False, device_id=0):
+    cam = _arr(cam, np.float64, (CAM_LEN,))
+    xyz = _arr(xyz, np.float64)
+    uv = np.empty((len(xyz), 2))
+    depth = np.empty(len(xyz))
+    check(load().glh_stage_project_depth(device_id, _ptr(cam), _ptr(xyz), len(xyz), int(bool(directions)), _ptr(uv),
+                                         _ptr(depth)))
+    return uv, depth
 
 
 def stage_unproject(cam, uv, depth=None, directions=True, device_id=0):

@@ -121,9 +121,9 @@ class Camera:
     # ---- projection (hot path: GPU)
     def xyz_to_uv(self, xyz, directions=False, return_depth=False):
         """camera.py:591-628, evaluated by the projection kernel (`directions=True`: xyz are rays, :1448)."""
-        if return_depth:
-            raise NotImplementedError("return_depth is not on the tracking path")
         xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
+        if return_depth:  # (uv, distance along the optical axis), camera.py:1468-1469
+            return _lib.stage_project_depth(self.vector24, xyz, directions=directions)
         return _lib.stage_project(self.vector24, xyz, directions=directions)
 
     def inframe(self, uv):

@@ -1539,14 +1539,15 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
 // Test hook: Camera.xyz_to_uv on explicit points
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const double* xyz, int n,
-                                                        double* uv, int directions) {
+                                                        double* uv, int directions, double* depth) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  double u, v;
+  double u, v, d = NAN;
   project_f(*cam, cam_flags(*cam) | (directions ? CAM_F_DIRECTIONS : 0u), xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
-            u, v);
+            u, v, depth ? &d : nullptr);
   uv[2 * i] = u;
   uv[2 * i + 1] = v;
+  if (depth) depth[i] = d;
 }
 
 // Camera.uv_to_xyz on explicit points; depth null = 1, else [n] (or [1], broadcast)

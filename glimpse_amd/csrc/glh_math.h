@@ -61,7 +61,8 @@ GLH_HD uint32_t cam_flags(const CamDev& c) {
 
 // Camera.xyz_to_uv (camera.py:591-628): _xyz_to_xy (:1435-1470), _distort (:1180-1196 with
 // :1138-1163, :1165-1178), _xy_to_uv (:1499-1508).  `f` = cam_flags(c).
-GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
+GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v,
+                      double* depth = nullptr) {  // depth: distance along the optical axis (camera.py:1468-1469)
   if (f & CAM_F_GRID) {  // Grid.xyz_to_uv: (xy - (xlim[0], ylim[0])) / d
     double gx = x - c.xyz[0], gy = y - c.xyz[1];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -87,6 +88,7 @@ GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z,
   double cx = c.R[0] * dx + c.R[1] * dy + c.R[2] * dz;
   double cy = c.R[3] * dx + c.R[4] * dy + c.R[5] * dz;
   double cz = c.R[6] * dx + c.R[7] * dy + c.R[8] * dz;
+  if (depth) *depth = cz;
   if (!(cz > 0.0)) {  // behind the camera (camera.py:1465-1466); NaN depth stays NaN too
     u = v = NAN;
     return;

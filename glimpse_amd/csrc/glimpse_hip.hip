@@ -1559,19 +1559,29 @@ int finish() {
 }
 }  // namespace
 
-static int stage_project_impl(int dev, const double* cam, const double* xyz, int n, double* uv, int directions) {
+static int stage_project_impl(int dev, const double* cam, const double* xyz, int n, double* uv, int directions,
+                              double* depth = nullptr) {
   if (!cam || !xyz || !uv || n <= 0) return fail(GLH_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(dev));
   CamDev cd;
   expand_camera(cam, &cd);
-  DevBuf dc, dx, du;
+  DevBuf dc, dx, du, dd;
   CHK(dc.up(&cd, sizeof cd));
   CHK(dx.up(xyz, (size_t)n * 3 * sizeof(double)));
   CHK(du.alloc((size_t)n * 2 * sizeof(double)));
+  if (depth) CHK(dd.alloc((size_t)n * sizeof(double)));
   hipLaunchKernelGGL(k_project_points, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, dc.as<CamDev>(),
-                     dx.as<double>(), n, du.as<double>(), directions);
+                     dx.as<double>(), n, du.as<double>(), directions, depth ? dd.as<double>() : nullptr);
   CHK(finish());
+  if (depth) CHK(dd.down(depth, (size_t)n * sizeof(double)));
   return du.down(uv, (size_t)n * 2 * sizeof(double));
+}
+
+extern "C" int glh_stage_project_depth(int dev, const double* cam, const double* xyz, int n, int directions,
+                                       double* uv, double* depth) {
+  if (!depth) return fail(GLH_E_INVALID, "bad argument");
+  if (cam && cam[23] != 0.0) return fail(GLH_E_INVALID, "depth is a camera notion (not a raster grid)");
+  return stage_project_impl(dev, cam, xyz, n, uv, directions ? 1 : 0, depth);
 }
 
 extern "C" int glh_stage_project(int dev, const double* cam, const double* xyz, int n, double* uv) {

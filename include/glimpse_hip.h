@@ -287,6 +287,10 @@ int glh_measure_copy_bandwidth(glh_ctx* ctx, uint64_t bytes, int iters, double* 
 int glh_stage_project(int device_id, const double* cam, const double* xyz, int n, double* uv);
 /* Same with xyz read as ray directions relative to the camera (directions=True, camera.py:1448).  */
 int glh_stage_project_directions(int device_id, const double* cam, const double* xyz, int n, double* uv);
+/* Camera.xyz_to_uv(return_depth=True) (camera.py:591-628, :1468-1469): uv [n][2] and the distance of every
+ * point along the optical axis, depth [n] (also for points behind the camera, whose uv are NaN).   */
+int glh_stage_project_depth(int device_id, const double* cam, const double* xyz, int n, int directions,
+                            double* uv, double* depth);
 /* Camera.uv_to_xyz (camera.py:630-663): uv [n][2] -> xyz [n][3]; depth NULL (= 1), [1] or [n];
  * undistortion by the closed form for k1 alone, else 20 Oulu iterations (camera.py:1198-1337).   */
 int glh_stage_unproject(int device_id, const double* cam, const double* uv, int n, const double* depth,

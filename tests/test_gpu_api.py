@@ -369,6 +369,18 @@ def test_inverse_projection_on_the_device(golden):
         np.testing.assert_allclose(cam.uv_to_xyz(uv), xd, rtol=1e-11, atol=1e-12)
         np.testing.assert_allclose(cam.uv_to_xyz(uv, directions=False, depth=depth), xa, rtol=1e-11, atol=1e-9)
 
+        # xyz_to_uv(return_depth=True): unprojecting to depth d along the optical axis and projecting back
+        # returns d (camera.py:1468-1469)
+        uv2, d2 = cam.xyz_to_uv(xa, return_depth=True)
+        np.testing.assert_array_equal(uv2, cam.xyz_to_uv(xa))
+        if not vec[20]:  # (uv_to_xyz does not undo the earth-curvature correction, camera.py:1483-1497)
+            np.testing.assert_allclose(d2, np.broadcast_to(depth, d2.shape), rtol=1e-12)
+    # the doctest of camera.py:622-627, and a point behind the camera: NaN uv, negative depth
+    cam = glimpse_amd.Camera(imgsz=10, f=10)
+    uv, d = cam.xyz_to_uv(np.array([(0.0, 10.0, 0.0), (0.0, -4.0, 0.0)]), return_depth=True)
+    np.testing.assert_array_equal(uv[0], [5.0, 5.0])
+    assert np.isnan(uv[1]).all() and list(d) == [10.0, -4.0]
+
     def reprojection_errors(cam):
         uv = _pixel_centres(cam.imgsz.astype(int))
         return np.linalg.norm(cam.xyz_to_uv(cam.uv_to_xyz(uv), directions=True) - uv, axis=1)
