@@ -184,7 +184,7 @@ class Tracker:
     # ---- the tracking loop (tracker.py:225-417) ------------------------------------------------
     def track(self, motion_models, datetimes=None, maxdt=datetime.timedelta(0), tile_size=(15, 15),
               observer_mask=None, return_covariances=False, return_particles=False, reduce_particles=None,
-              parallel=False, rng="numpy", seed=0, point_offset=0):
+              parallel=False, rng="numpy", seed=0, point_offset=0, _catch_errors=None):
         if reduce_particles:
             return_particles = True
         params = dict(motion_models=motion_models, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
@@ -200,10 +200,16 @@ class Tracker:
                                           "TangentCartesian and TangentCylindrical motion models")
         self.reset()
         ntracks = len(motion_models)
-        raise_errors = ntracks < 2
+        raise_errors = ntracks < 2 if _catch_errors is None else not _catch_errors
         n = motion_models[0].n
         if any(m.n != n for m in motion_models):
-            raise NotImplementedError("all motion models must use the same number of particles (ragged n: later)")
+            # Motion models with different particle counts (each track of the reference has its own n,
+            # tracker.py:305-314): consecutive models with equal n form one batch, the batches run in order -- so
+            # the legacy np.random stream is consumed track after track like the reference -- and are merged.
+            return self._track_runs(motion_models, params, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
+                                    observer_mask=observer_mask, return_covariances=return_covariances,
+                                    return_particles=return_particles, reduce_particles=reduce_particles, rng=rng,
+                                    seed=seed, point_offset=point_offset)
         if datetimes is None:
             datetimes = self.datetimes
         else:
@@ -379,6 +385,30 @@ class Tracker:
         tracks = Tracks(**kwargs)
         if reduce_particles:
             tracks.reduced = [reduce_particles(out_particles[p], out_weights[p]) for p in range(ntracks)]
+        return tracks
+
+    def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0, **kw):
+        ntracks = len(motion_models)
+        if observer_mask is not None:
+            observer_mask = np.asarray(observer_mask, dtype=bool)
+        bounds = [0] + [i for i in range(1, ntracks) if motion_models[i].n != motion_models[i - 1].n] + [ntracks]
+        parts = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            parts.append(self.track(motion_models[a:b], observer_mask=None if observer_mask is None else observer_mask[a:b],
+                                    reduce_particles=reduce_particles, point_offset=point_offset + a,
+                                    _catch_errors=ntracks >= 2, **kw))
+
+        def cat(name):
+            values = [getattr(part, name) for part in parts]
+            return None if values[0] is None else [row for v in values for row in v]
+
+        first = parts[0]
+        tracks = Tracks(datetimes=first.datetimes, time_unit=first.time_unit, means=cat("means"), sigmas=cat("sigmas"),
+                        covariances=cat("covariances"), particles=cat("particles"), weights=cat("weights"),
+                        tracker=self, images=first.images, params=params, errors=cat("errors"),
+                        warnings=cat("warnings"))
+        if reduce_particles:
+            tracks.reduced = [r for part in parts for r in part.reduced]
         return tracks
 
     @staticmethod

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import glimpse_amd  # noqa: E402
-from tests.helpers_api import DAY, camera_from, models_from, observers_from  # noqa: E402
+from tests.helpers_api import DAY, T0, camera_from, models_from, observers_from  # noqa: E402
 
 RTOL = 1e-5
 
@@ -422,3 +422,30 @@ def test_tracking_from_image_files_equals_tracking_from_arrays(golden, tmp_path)
     np.testing.assert_array_equal(from_files.means, from_arrays.means)
     np.testing.assert_array_equal(from_files.sigmas, from_arrays.sigmas)
     assert (observers[0].images[1].array is None) and (observers[1].images[1].array is not None)
+
+
+def test_ragged_particle_counts_reproduce_reference(golden):
+    """Motion models with different n in one Tracker.track call (tracker.py:305-314): runs of equal n are batched,
+    the batches consume np.random in track order, so means, sigmas, the captured error of the track that starts
+    outside the image, reduce_particles results and the position of the stream afterwards match the reference."""
+    g = golden("g15_ragged.npz")
+    cam = camera_from(g["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(g["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=xy, time_unit=DAY, dem=0.0, dem_sigma=0.0, n=int(n), xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy, n in zip(g["xy"], g["n_particles"])]
+    np.random.seed(int(g["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15),
+                               reduce_particles=lambda p, w: (p.shape, float(np.nansum(w))))
+    assert np.random.random() == float(g["random_after"])
+    errors = g["errors"].astype(bool)
+    assert [e is not None for e in tracks.errors] == list(errors)
+    assert isinstance(tracks.errors[3], IndexError)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8, equal_nan=True)
+    assert [r[0][1] for r in tracks.reduced] == list(g["reduced_n"])
+    np.testing.assert_allclose([r[1] for r in tracks.reduced], g["reduced_w"], rtol=RTOL)
+    assert tracks.particles is None and tracks.params["motion_models"] is models

@@ -748,7 +748,42 @@ def g10_tracks():
     np.savez_compressed(os.path.join(OUT, "g10_tracks.npz"), **out)
 
 
+def g15_ragged():
+    """Motion models with different particle counts in one Tracker.track call (each track of the reference has its
+    own n, tracker.py:305-314): the frames of g8_c2mini, five tracks with n = 150, 150, 90, 200, 200 (the fourth
+    starts outside the image), np.random seeded once."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam, 4, border_px=70.0, seed=3)
+    ns = [150, 150, 90, 200, 200]
+    xys = [tuple(pts[0]), tuple(pts[1]), tuple(pts[2]), (100.0, 100.0), tuple(pts[3])]
+    kws = [dict(xy=xy, dem=0.0, dem_sigma=0.0, n=n, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0),
+                axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0)) for xy, n in zip(xys, ns)]
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(6)]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+    models = [glimpse.CartesianMotion(time_unit=day, **kw) for kw in kws]
+    np.random.seed(77)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), reduce_particles=lambda p, w: (p.shape, float(np.nansum(w))))
+    after = np.random.random()
+    out = {
+        "seed": 77, "n_particles": np.array(ns), "xy": np.array(xys), "means": tracks.means, "sigmas": tracks.sigmas,
+        "errors": np.array([0 if e is None else 1 for e in tracks.errors]),
+        "reduced_n": np.array([r[0][1] for r in tracks.reduced]),
+        "reduced_w": np.array([r[1] for r in tracks.reduced]),
+        "random_after": after, "frames": np.stack(frames), "cam": cam,
+    }
+    np.savez_compressed(os.path.join(OUT, "g15_ragged.npz"), **out)
+    print("g15 vx:", tracks.means[:, -1, 3], "errors:", out["errors"])
+
+
 if __name__ == "__main__":
+    if "--g15" in sys.argv:
+        g15_ragged()
+        sys.exit(0)
     if "--g14" in sys.argv:
         g14_unproject()
         sys.exit(0)
@@ -781,5 +816,6 @@ if __name__ == "__main__":
     g12_rasters()
     g13_ortho()
     g14_unproject()
+    g15_ragged()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
