@@ -1536,6 +1536,23 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Run-length compact state (written by the fused step, glh_point.h) -> one record per particle:
+// out[j] = in[uidx[j]] for the particles and the weights.  grid (ceil(N / BLK), P).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_expand_state(const double* pin, const double* win, const uint16_t* uidx,
+                                                      double* pout, double* wout, int N) {
+  const int pt = blockIdx.y, j = blockIdx.x * BLK + threadIdx.x;
+  if (j >= N) return;
+  const size_t base = (size_t)pt * N;
+  const int r = uidx[base + j];
+  const double2* src = reinterpret_cast<const double2*>(pin + (base + r) * 6);
+  double2* dst = reinterpret_cast<double2*>(pout + (base + j) * 6);
+  const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+  dst[0] = v0; dst[1] = v1; dst[2] = v2;
+  wout[base + j] = win[base + r];
+}
+
+// ------------------------------------------------------------------------------------------
 // Test hook: Camera.xyz_to_uv on explicit points
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const double* xyz, int n,

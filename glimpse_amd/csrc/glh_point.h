@@ -93,8 +93,11 @@ __device__ __forceinline__ void pt_put(double (&v)[PPT], int r, double q) {
 }
 
 struct PointArgs {
-  const double* particles_in;  // [P][N][6] state after the previous frame (pre-evolve)
-  double* particles_out;       // [P][N][6] evolved + resampled
+  // The resampled state is stored RUN-LENGTH COMPACT: systematic resampling returns its sources in order, so the
+  // copies of a source are adjacent and identical; only the first of each run is written (records 0 .. U-1) and
+  // uidx[j] names the record of output j.  Expanded on demand (k_expand_state) for everything but this kernel.
+  const double* particles_in;  // [P][N][6] state after the previous frame (pre-evolve), compact if uidx_in
+  double* particles_out;       // [P][N][6] evolved + resampled, compact (uidx_out)
   double* weights_tmp;         // [P][N] scratch: the motion model's log-likelihood term (has_dem) from phase A to C
   double* weights_out;         // [P][N] weights[idx]
   const double* motion;
@@ -117,6 +120,9 @@ struct PointArgs {
   const int64_t* lu_off;
   const double* inv;           // explicit spline-matrix inverses, sides 4 .. GLH_SPL_DENSE_MAX (glh_host.h)
   const double* poly;          // [GLH_NPOLY][16]
+  const uint16_t* uidx_in;     // [P][N] record of particle i in particles_in (run-length compact state), or null:
+                               // particle i is record i
+  uint16_t* uidx_out;          // [P][N] record of output j in particles_out / weights_out
   int32_t* idx_out;            // [P][N] or null
   unsigned long long* stamps;  // [P][PT_NSTAMP] s_memtime at the phase boundaries (diagnostic), or null
   double* moments;             // [P][12]
@@ -449,8 +455,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   };
   __syncthreads();
 
+  const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
   auto evolved = [&](int k, double* x) {
-    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)k * 6);
+    const int rec = uin ? (int)uin[k] : k;
+    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)rec * 6);
     const double2 v0 = src[0], v1 = src[1], v2 = src[2];
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
@@ -480,10 +488,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const bool gridded = SURF && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
+    // record of every particle (compact input state): staged in region 2, which is free until phase B
+    uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
+    for (int k = tid; k < N; k += TB) s_rec[k] = uin ? uin[k] : (uint16_t)k;
+    pt_lds_barrier();
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
     {
-      const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)(tid < N ? tid : 0) * 6);
+      const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)s_rec[tid < N ? tid : 0] * 6);
       nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
     }
 #pragma unroll 1
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
       {
         const int inext = i + TB;
-        const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)(inext < N ? inext : 0) * 6);
+        const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)s_rec[inext < N ? inext : 0] * 6);
         nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
       }
       if (i < N) {
@@ -835,7 +847,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     u = u01_halfopen(r[0], r[1]);
   }
   const double inv_n = 1.0 / (double)N;
-  uint16_t* sidx = reinterpret_cast<uint16_t*>(clast + TB);
+  // Region 2 once the tree nodes and clast are dead: three tables of N uint16 each.
+  const int n16 = pt_align16(N * 2) / 2;
+  uint16_t* ufill = reinterpret_cast<uint16_t*>(r2);  // rank + 1 of the source that serves output j
+  uint16_t* usrc = ufill + n16;                        // source of rank h
+  uint16_t* ucnt = usrc + n16;                         // copies of the source of rank h
+  __shared__ int s_U;
   {
     // f(ck) = #{j : pos_j <= ck}, pos_j = (j + u) * (1 / n) exactly as tracker.py:173 rounds it.  The guess
     // floor(ck * n - u) + 1 is kept in float64 (integer valued, so (double)f == g bit for bit) and
@@ -854,43 +871,101 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       return f;
     };
-    // Source k serves the positions [f(k-1), f(k)).  Runs can be hundreds long when the weights are
-    // peaked, so instead of letting every lane write its own run (the wave would wait for its longest),
-    // each non-empty run writes only its HEAD and an inclusive max-scan fills the rest: the indices
-    // increase with the position, so "the last head at or before j" is the maximum so far.
-    for (int j = tid; j < N; j += TB) sidx[j] = 0;
-    pt_lds_barrier();
-    int f_prev = k0 > 0 && k0 < N ? count_le(clast[tid - 1]) : 0;
-    double run2 = 0.0;
-    if constexpr (PPT > 0) {
+    // Source k serves the positions [f(k-1), f(k)): np.searchsorted by its inverse.  The sources that serve at
+    // least one position (the survivors) are RANKED in order; output j then only needs the rank of its source
+    // (ufill, written at the head of every run and spread by an inclusive max-scan: ranks grow with the position),
+    // and the gather below runs over the ranks: one re-evolved record per survivor, however many copies it has.
+    pt_lds_barrier();  // clast is visible
+    const int f_first = k0 > 0 && k0 < N ? count_le(clast[tid - 1]) : 0;
+    // pass 1: where every own source's run ends (f), how many own sources survive
+    int fk[NREG];
+    int nsurv = 0;
+    {
+      int f_prev = f_first;
+      double run2 = 0.0;
+      if constexpr (PPT > 0) {
 #pragma unroll
-      for (int j = 0; j < NREG; ++j) {
-        const int k = k0 + j;
-        if (k < k1) {
-          run2 += qn[j];
-          const int f = count_le(tid > 0 ? excl + run2 : run2);
-          if (f > f_prev) sidx[f_prev] = (uint16_t)k;
+        for (int j = 0; j < NREG; ++j) {
+          const int k = k0 + j;
+          fk[j] = f_prev;
+          if (k < k1) {
+            run2 += qn[j];
+            int f = count_le(tid > 0 ? excl + run2 : run2);
+            if (k == N - 1 && f < N) {  // positions beyond c[N-1] (searchsorted == N: IndexError in the reference)
+              flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+              f = N;                    // clamp: the last source serves them
+            }
+            nsurv += f > f_prev;
+            f_prev = f;
+            fk[j] = f;
+          }
+        }
+      } else {
+        for (int k = k0; k < k1; ++k) {
+          run2 += c[k] / total;
+          int f = count_le(tid > 0 ? excl + run2 : run2);
+          if (k == N - 1 && f < N) {
+            flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
+            f = N;
+          }
+          nsurv += f > f_prev;
           f_prev = f;
         }
       }
-    } else {
-      for (int k = k0; k < k1; ++k) {
-        run2 += c[k] / total;
-        const int f = count_le(tid > 0 ? excl + run2 : run2);
-        if (f > f_prev) sidx[f_prev] = (uint16_t)k;
-        f_prev = f;
-      }
     }
-    if (k1 == N && k0 < N && f_prev < N) {
-      // positions beyond c[N-1] (searchsorted == N: IndexError in the reference): clamp + flag
-      flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
-      sidx[f_prev] = (uint16_t)(N - 1);
+    // exclusive scan of the survivor counts over the block
+    int incl_s = nsurv;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const int t = __shfl_up(incl_s, off, WAVE);
+      if (lane >= off) incl_s += t;
+    }
+    if (lane == WAVE - 1) scan_tmp[wave] = (uint32_t)incl_s;
+    pt_lds_barrier();  // every thread has read clast by now: the tables may overwrite it and the tree nodes
+    int rank = incl_s - nsurv;
+    for (int w = 0; w < wave; ++w) rank += (int)scan_tmp[w];
+    if (tid == TB - 1) s_U = rank + nsurv;
+    for (int j = tid; j < N; j += TB) ufill[j] = 0;
+    pt_lds_barrier();
+    // pass 2: survivors take their rank
+    {
+      int f_prev = f_first;
+      double run2 = 0.0;
+      if constexpr (PPT > 0) {
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+          const int k = k0 + j;
+          if (k < k1) {
+            const int f = fk[j];
+            if (f > f_prev) {
+              usrc[rank] = (uint16_t)k;
+              ucnt[rank] = (uint16_t)(f - f_prev);
+              ufill[f_prev] = (uint16_t)(rank + 1);
+              ++rank;
+            }
+            f_prev = f;
+          }
+        }
+      } else {
+        for (int k = k0; k < k1; ++k) {
+          run2 += c[k] / total;
+          int f = count_le(tid > 0 ? excl + run2 : run2);
+          if (k == N - 1 && f < N) f = N;
+          if (f > f_prev) {
+            usrc[rank] = (uint16_t)k;
+            ucnt[rank] = (uint16_t)(f - f_prev);
+            ufill[f_prev] = (uint16_t)(rank + 1);
+            ++rank;
+          }
+          f_prev = f;
+        }
+      }
     }
     pt_lds_barrier();
     uint32_t runmax = 0;
     for (int j = k0; j < k1; ++j) {
-      runmax = max(runmax, (uint32_t)sidx[j]);
-      sidx[j] = (uint16_t)runmax;
+      runmax = max(runmax, (uint32_t)ufill[j]);
+      ufill[j] = (uint16_t)runmax;
     }
     uint32_t incl_m = runmax;
 #pragma unroll
@@ -898,31 +973,34 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const uint32_t t = __shfl_up(incl_m, off, WAVE);
       if (lane >= off) incl_m = max(incl_m, t);
     }
+    pt_lds_barrier();  // scan_tmp is reused: the survivor scan has been consumed
     if (lane == WAVE - 1) scan_tmp[wave] = incl_m;
     uint32_t before = __shfl_up(incl_m, 1, WAVE);
     if (lane == 0) before = 0;
     pt_lds_barrier();
     for (int w = 0; w < wave; ++w) before = max(before, scan_tmp[w]);
     if (before > 0)
-      for (int j = k0; j < k1; ++j) sidx[j] = (uint16_t)max((uint32_t)sidx[j], before);
+      for (int j = k0; j < k1; ++j) ufill[j] = (uint16_t)max((uint32_t)ufill[j], before);
   }
   pt_lds_barrier();
 
   PT_STAMP(7);
-  // ---------------- E + F: gather with re-evolve, moments --------------------------------------
+  // ---------------- E + F: one re-evolved record per survivor, moments --------------------------
   double* Pout = a.particles_out + (size_t)pt * N * 6;
   double* Wout = a.weights_out + (size_t)pt * N;
+  const int U = s_U;
   double K[6];
   evolved(0, K);  // pivot of the shifted moments: the point's first evolved particle
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
   constexpr int GU = 2;
-  for (int j0 = tid; j0 < N; j0 += GU * TB) {
-    int lo[GU];
+  for (int h0 = tid; h0 < U; h0 += GU * TB) {
+    int lo[GU], cnt[GU];
     double x[GU][6], w[GU];
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
-      const int j = j0 + g * TB;
-      lo[g] = j < N ? sidx[j] : 0;
+      const int h = h0 + g * TB;
+      lo[g] = h < U ? usrc[h] : 0;
+      cnt[g] = h < U ? ucnt[h] : 0;
     }
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
@@ -931,32 +1009,41 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
-      const int j = j0 + g * TB;
-      if (j < N) {
+      const int h = h0 + g * TB;
+      if (h < U) {
         typedef double pt_d2 __attribute__((ext_vector_type(2)));
-        pt_d2* dst = reinterpret_cast<pt_d2*>(Pout + (size_t)j * 6);
+        pt_d2* dst = reinterpret_cast<pt_d2*>(Pout + (size_t)h * 6);
         // streaming stores: the new state is not read again before the next launch, and should not displace
         // the pre-evolve records that the other workgroups' gathers are about to re-read from L2 / Infinity Cache
         __builtin_nontemporal_store(pt_d2{x[g][0], x[g][1]}, dst);
         __builtin_nontemporal_store(pt_d2{x[g][2], x[g][3]}, dst + 1);
         __builtin_nontemporal_store(pt_d2{x[g][4], x[g][5]}, dst + 2);
-        __builtin_nontemporal_store(w[g], Wout + j);
-        if (a.idx_out) a.idx_out[(size_t)pt * N + j] = lo[g];
-        s0 += w[g];
+        __builtin_nontemporal_store(w[g], Wout + h);
+        const double cw = (double)cnt[g] * w[g];  // the record stands for cnt identical particles
+        s0 += cw;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           double d = x[g][k] - K[k];
-          double wd = w[g] * d;
+          double wd = cw * d;
           s1[k] += wd;
           s2[k] += wd * d;
         }
       }
     }
   }
+  {
+    // which record every output is, and (debug) which source it came from
+    uint16_t* uout = a.uidx_out + (size_t)pt * N;
+    for (int j = tid; j < N; j += TB) {
+      const int h = (int)ufill[j] - 1;
+      uout[j] = (uint16_t)h;
+      if (a.idx_out) a.idx_out[(size_t)pt * N + j] = usrc[h];
+    }
+  }
   PT_STAMP(8);
   {
     // one pass for the 13 sums: wave shuffles -> LDS [wave][13] -> thread k < 6 finishes component k
-    double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (sidx is dead after the gather)
+    double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (the rank tables are dead after the gather)
     pt_lds_barrier();  // LDS only: the gather's stores drain in the background
     const double t0 = pt_wave_sum63(s0);
     if (lane == WAVE - 1) mred[wave * 13] = t0;

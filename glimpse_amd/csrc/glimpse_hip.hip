@@ -123,6 +123,8 @@ struct glh_ctx {
   double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
   float *tmpl_tile32 = nullptr, *search = nullptr;
   unsigned long long* stamps = nullptr;  // phase stamps of the fused kernel (diagnostic)
+  uint16_t* uidx[2] = {nullptr, nullptr};  // [P][N] record of every particle in particles[b] / weights[b] when compact
+  bool compact = false;  // particles[cur] / weights[cur] are run-length compact (left by the fused step)
   int32_t* resid_draws = nullptr;  // [P] uniforms consumed by the last residual resampling
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
@@ -241,7 +243,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->resid_draws); dfree(c->stamps);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
@@ -535,6 +537,7 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   c->th = th;
   c->NB = (N + BLK - 1) / BLK;
   c->cur = 0;
+  c->compact = false;
   c->frame = 0;
   c->have_mask = c->have_active = false;
   c->pt_base = 0;
@@ -583,6 +586,19 @@ extern "C" int glh_set_frame(glh_ctx* c, int frame) {
 static int need_seq(glh_ctx* c) {
   if (!c) return fail(GLH_E_INVALID, "null context");
   if (c->P <= 0) return fail(GLH_E_STATE, "glh_begin_sequence has not been called");
+  return GLH_OK;
+}
+
+// The fused step leaves the state run-length compact; everything else works on one record per particle.
+static int ensure_expanded(glh_ctx* c) {
+  if (!c->compact) return GLH_OK;
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const dim3 grid((c->N + BLK - 1) / BLK, c->P);
+  hipLaunchKernelGGL(k_expand_state, grid, dim3(BLK), 0, c->stream, c->particles[c->cur], c->weights[c->cur],
+                     c->uidx[c->cur], c->particles[c->cur ^ 1], c->weights[c->cur ^ 1], c->N);
+  HIPCHK(hipGetLastError());
+  c->cur ^= 1;
+  c->compact = false;
   return GLH_OK;
 }
 
@@ -689,6 +705,7 @@ extern "C" int glh_set_active(glh_ctx* c, const uint8_t* active) {
 }
 extern "C" int glh_set_particles(glh_ctx* c, const double* p) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   c->moments_frame = -1;
   if (!p) return fail(GLH_E_INVALID, "particles is null");
   UPLOAD(c->particles[c->cur], p, (size_t)c->P * c->N * 6, double);
@@ -696,12 +713,14 @@ extern "C" int glh_set_particles(glh_ctx* c, const double* p) {
 }
 extern "C" int glh_get_particles(glh_ctx* c, double* p) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   if (!p) return fail(GLH_E_INVALID, "particles is null");
   DOWNLOAD(p, c->particles[c->cur], (size_t)c->P * c->N * 6, double);
   return GLH_OK;
 }
 extern "C" int glh_set_weights(glh_ctx* c, const double* w) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   c->moments_frame = -1;
   if (!w) return fail(GLH_E_INVALID, "weights is null");
   UPLOAD(c->weights[c->cur], w, (size_t)c->P * c->N, double);
@@ -709,6 +728,7 @@ extern "C" int glh_set_weights(glh_ctx* c, const double* w) {
 }
 extern "C" int glh_get_weights(glh_ctx* c, double* w) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   if (!w) return fail(GLH_E_INVALID, "weights is null");
   DOWNLOAD(w, c->weights[c->cur], (size_t)c->P * c->N, double);
   return GLH_OK;
@@ -786,6 +806,7 @@ static int stage_normals(glh_ctx* c, const double* host, size_t count) {
 // ------------------------------------------------------------------------------------------
 extern "C" int glh_init_particles(glh_ctx* c, int rng_mode, const double* normals, uint64_t seed) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (rng_mode == GLH_RNG_HOST) {
     if (!normals) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs normals [P][N][6]");
@@ -840,6 +861,7 @@ static int check_images(glh_ctx* c, const int32_t* images) {
 // evolve (optional) + project into the given images + bbox partials
 static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng_mode, uint64_t seed,
                                  uint64_t step, const int32_t* images, bool store = true) {
+  CHK(ensure_expanded(c));
   if (do_evolve) c->moments_frame = -1;
   EvolveArgs a{};
   a.particles = c->particles[c->cur];
@@ -887,6 +909,7 @@ extern "C" int glh_evolve(glh_ctx* c, double tau, int rng_mode, const double* no
 }
 
 static int launch_moments(glh_ctx* c, double* out, int ld, int with_sigma) {
+  CHK(ensure_expanded(c));
   MomentsArgs a{};
   a.particles = c->particles[c->cur];
   a.weights = c->weights[c->cur];
@@ -1017,6 +1040,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
 }
 
 static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected) {
+  CHK(ensure_expanded(c));
   const int O = c->cfg.n_observers;
   // uv + bbox of the (already evolved) particles in the matched images
   if (!projected) CHK(launch_evolve_project(c, false, 0.0, GLH_RNG_PHILOX, 0, 0, images));
@@ -1070,6 +1094,7 @@ extern "C" int glh_resample(glh_ctx* c, int rng_mode, const double* u, uint64_t 
 extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const double* u, uint64_t seed,
                                    uint64_t step) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (method != GLH_RESAMPLE_SYSTEMATIC && method != GLH_RESAMPLE_STRATIFIED && method != GLH_RESAMPLE_CHOICE &&
       method != GLH_RESAMPLE_RESIDUAL)
@@ -1160,7 +1185,8 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   }
   // c[N] and, behind region 2, the pairwise-sum plan
   const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
-  const int plan = pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8 + pt_align16(c->N * 2);  // nodes | clast | sidx
+  // phase D/E: tree nodes | clast, then (over them) three rank tables of N uint16
+  const int plan = std::max(pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8, 3 * pt_align16(c->N * 2));
   // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
   const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX * 8);
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
@@ -1172,7 +1198,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
     r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
   if (getenv("GLH_PT_ONE_BLOCK")) r2 = std::min(PT_LDS_MAX - cN, 100 * 1024);  // experiment: 1 workgroup / CU
   if (c->fused == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
-  if (r2 < r2_min) return false;
+  if (r2 < r2_min || cN + r2 > PT_LDS_MAX) return false;  // (N beyond ~10 900: the staged kernels take the step)
   *r2_bytes = r2;
   return true;
 }
@@ -1212,6 +1238,10 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.inv = c->spl_inv;
   a.poly = c->poly;
   a.idx_out = c->keep_idx ? c->idx : nullptr;
+  for (int b = 0; b < 2; ++b)
+    if (!c->uidx[b]) CHK(dalloc(&c->uidx[b], (size_t)c->cfg.max_points * c->cfg.max_particles));
+  a.uidx_in = c->compact ? c->uidx[c->cur] : nullptr;
+  a.uidx_out = c->uidx[c->cur ^ 1];
   a.stamps = c->stamps;
   a.moments = c->moments + (size_t)frame * c->P * 12;
   a.pt_status = c->pt_status;
@@ -1296,6 +1326,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
+  c->compact = true;
   c->moments_frame = frame;
   return GLH_OK;
 }
@@ -1310,6 +1341,7 @@ extern "C" int glh_get_residual_draws(glh_ctx* c, int32_t* draws) {
 
 extern "C" int glh_record_covariances(glh_ctx* c, int frame) {
   CHK(need_seq(c));
+  CHK(ensure_expanded(c));
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
   if (!c->covariances) {
