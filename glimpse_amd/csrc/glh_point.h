@@ -490,7 +490,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // record of every particle (compact input state): staged in region 2, which is free until phase B
     uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
-    for (int k = tid; k < N; k += TB) s_rec[k] = uin ? uin[k] : (uint16_t)k;
+    if (uin) {
+      for (int base = 0; base < N; base += 4 * TB) {  // four index loads in flight per thread
+        uint16_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = base + q * TB + tid;
+          v[q] = k < N ? uin[k] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = base + q * TB + tid;
+          if (k < N) s_rec[k] = v[q];
+        }
+      }
+    } else {
+      for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
+    }
     pt_lds_barrier();
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
