@@ -943,6 +943,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (tid == TB - 1) s_U = rank + nsurv;
     for (int j = tid; j < N; j += TB) ufill[j] = 0;
     pt_lds_barrier();
+    if (s_U == 0 && tid == 0) {  // no comparison succeeded (NaN weights): every output is a copy of source 0
+      usrc[0] = 0;
+      ucnt[0] = (uint16_t)N;
+      ufill[0] = 1;
+    }
     // pass 2: survivors take their rank
     {
       int f_prev = f_first;
@@ -1004,7 +1009,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // ---------------- E + F: one re-evolved record per survivor, moments --------------------------
   double* Pout = a.particles_out + (size_t)pt * N * 6;
   double* Wout = a.weights_out + (size_t)pt * N;
-  const int U = s_U;
+  const int U = max(s_U, 1);
   double K[6];
   evolved(0, K);  // pivot of the shifted moments: the point's first evolved particle
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // which record every output is, and (debug) which source it came from
     uint16_t* uout = a.uidx_out + (size_t)pt * N;
     for (int j = tid; j < N; j += TB) {
-      const int h = (int)ufill[j] - 1;
+      const int h = max((int)ufill[j], 1) - 1;
       uout[j] = (uint16_t)h;
       if (a.idx_out) a.idx_out[(size_t)pt * N + j] = usrc[h];
     }

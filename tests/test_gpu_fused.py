@@ -198,6 +198,7 @@ def test_fused_step_edge_cases_match_staged(lib):
     params = wl.params.copy()
     params[1, 0:2] = (-30.6, 0.0)   # ~14 px from the left edge: template fits, the evolved cloud does not
     params[2, 0:2] = (-31.6, 5.0)   # template box itself leaves the image
+    params[5, 17] = 0.5             # dem_sigma > 0: CartesianMotion.compute_log_likelihoods contributes
     out = []
     for mode in (1, 0, 2):
         with lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
@@ -210,6 +211,7 @@ def test_fused_step_edge_cases_match_staged(lib):
             ctx.record_moments(0)
             p0 = ctx.get_particles()
             p0[4, 17, 0] = np.nan  # one missing value in point 4
+            p0[5, 3, 2] = np.nan   # and one in point 5, whose DEM term turns it into a NaN weight
             ctx.set_particles(p0)
             for i in range(1, T):
                 ctx.step(i, 1.0, [i], seed=3)
@@ -225,8 +227,11 @@ def test_fused_step_edge_cases_match_staged(lib):
         np.testing.assert_array_equal(o["ef"], ref["ef"])
         np.testing.assert_array_equal(o["p"], ref["p"])
         np.testing.assert_array_equal(o["w"], ref["w"])
-        ok = [0, 1, 2, 3, 5]
+        ok = [0, 1, 2, 3]
         np.testing.assert_allclose(o["m"][:, ok], ref["m"][:, ok], rtol=1e-12, atol=1e-13)
+    # NaN weights (point 5): np.searchsorted returns n for every position -> IndexError in the reference; here the
+    # positions are clamped to the last source and the point is flagged
+    assert ref["st"][5] & lib.PT_NAN and ref["st"][5] & lib.PT_RESAMPLE_CLAMP
 
 
 def test_fused_step_with_gridded_surfaces_equals_staged(lib):
