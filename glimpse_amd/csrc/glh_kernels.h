@@ -1536,8 +1536,8 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Run-length compact state (written by the fused step, glh_point.h) -> one record per particle:
-// out[j] = in[uidx[j]] for the particles and the weights.  grid (ceil(N / BLK), P).
+// Run-length compact state (written by the fused step, glh_point.h: planar, chunk c of record r at c N + r)
+// -> one record per particle: out[j] = in[uidx[j]] for the particles and the weights.  grid (ceil(N / BLK), P).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void k_expand_state(const double* pin, const double* win, const uint16_t* uidx,
                                                       double* pout, double* wout, int N) {
@@ -1545,9 +1545,9 @@ __global__ __launch_bounds__(BLK) void k_expand_state(const double* pin, const d
   if (j >= N) return;
   const size_t base = (size_t)pt * N;
   const int r = uidx[base + j];
-  const double2* src = reinterpret_cast<const double2*>(pin + (base + r) * 6);
+  const double2* src = reinterpret_cast<const double2*>(pin + base * 6) + r;
   double2* dst = reinterpret_cast<double2*>(pout + (base + j) * 6);
-  const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+  const double2 v0 = src[0], v1 = src[N], v2 = src[2 * (size_t)N];
   dst[0] = v0; dst[1] = v1; dst[2] = v2;
   wout[base + j] = win[base + r];
 }

@@ -456,10 +456,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __syncthreads();
 
   const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
+  // A record is three 16-byte chunks.  One record per particle (what every other kernel reads and writes): chunk c
+  // of record r at 3 r + c.  Compact (this kernel's own output): PLANAR, chunk c of record r at c N + r, so that
+  // consecutive lanes store, and mostly load, consecutive 16-byte words.
+  const int rec_stride = uin ? 1 : 3, chunk_stride = uin ? N : 1;
+  const double2* Pin2 = reinterpret_cast<const double2*>(Pin);
   auto evolved = [&](int k, double* x) {
     const int rec = uin ? (int)uin[k] : k;
-    const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)rec * 6);
-    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    const double2* src = Pin2 + (size_t)rec * rec_stride;
+    const double2 v0 = src[0], v1 = src[chunk_stride], v2 = src[2 * chunk_stride];
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
     {
-      const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)s_rec[tid < N ? tid : 0] * 6);
-      nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
+      const double2* src = Pin2 + (size_t)s_rec[tid < N ? tid : 0] * rec_stride;
+      nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
     }
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
@@ -523,8 +528,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
       {
         const int inext = i + TB;
-        const double2* src = reinterpret_cast<const double2*>(Pin + (size_t)s_rec[inext < N ? inext : 0] * 6);
-        nx0 = src[0]; nx1 = src[1]; nx2 = src[2];
+        const double2* src = Pin2 + (size_t)s_rec[inext < N ? inext : 0] * rec_stride;
+        nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
       }
       if (i < N) {
         double n[3];
@@ -1033,12 +1038,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const int h = h0 + g * TB;
       if (h < U) {
         typedef double pt_d2 __attribute__((ext_vector_type(2)));
-        pt_d2* dst = reinterpret_cast<pt_d2*>(Pout + (size_t)h * 6);
+        pt_d2* dst = reinterpret_cast<pt_d2*>(Pout) + h;  // planar: chunk c of record h at c N + h
         // streaming stores: the new state is not read again before the next launch, and should not displace
         // the pre-evolve records that the other workgroups' gathers are about to re-read from L2 / Infinity Cache
         __builtin_nontemporal_store(pt_d2{x[g][0], x[g][1]}, dst);
-        __builtin_nontemporal_store(pt_d2{x[g][2], x[g][3]}, dst + 1);
-        __builtin_nontemporal_store(pt_d2{x[g][4], x[g][5]}, dst + 2);
+        __builtin_nontemporal_store(pt_d2{x[g][2], x[g][3]}, dst + N);
+        __builtin_nontemporal_store(pt_d2{x[g][4], x[g][5]}, dst + 2 * N);
         __builtin_nontemporal_store(w[g], Wout + h);
         const double cw = (double)cnt[g] * w[g];  // the record stands for cnt identical particles
         s0 += cw;
