@@ -9,14 +9,17 @@
 //      tile -> SSD surface -> not-a-knot spline coefficients, all in LDS  (tracker.py:605-614,
 //      observer.py:210); tiles too large for LDS use the HBM workspaces with the same code
 //   C  sample the spline at every particle, w = exp(-ll) + 1e-300         (tracker.py:622-625, :126-149)
-//   D  NumPy-exact w.sum(), float64 scan (weights stay in LDS), inverse searchsorted (tracker.py:168-176)
-//   E  particles[idx]: re-read the PRE-evolve record of each source (L2 / Infinity-Cache hot:
-//      this workgroup streamed it in phase A) and re-apply its evolve step with the same noise
-//      (host normals or counter-based Philox) -- the evolved state is never stored un-resampled
-//                                                                           (tracker.py:222-223)
+//   D  NumPy-exact w.sum(), float64 scan (weights stay in LDS), inverse searchsorted; the sources that
+//      serve at least one position (the survivors) are ranked                 (tracker.py:168-176)
+//   E  particles[idx], run-length compact: for every SURVIVOR re-read its PRE-evolve record (L2 /
+//      Infinity-Cache hot: this workgroup streamed it in phase A), re-apply its evolve step with the same
+//      noise (host normals or counter-based Philox) -- the evolved state is never stored un-resampled --
+//      and store ONE record however many copies it has; every output stores the 2-byte index of its
+//      record                                                                   (tracker.py:222-223)
 //   F  weighted mean / sigma of the resampled set                          (tracker.py:72-104)
 //
-// HBM traffic per particle-frame: 48 B read + 48 B write of state, 8 + 8 B of weights.
+// HBM traffic per particle-frame, U/N ~ 0.57 survivors: ~27 B read (A) + ~20 B re-read (E) + ~32 B of
+// records and weights + 4 B of record indices.
 // The staged kernels of glh_kernels.h remain the general path (active masks, debug capture,
 // the reference's public step methods) and are bit-identical on the same inputs.
 #pragma once

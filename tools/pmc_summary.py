@@ -1,6 +1,7 @@
 """Summarise rocprofv3 runs of bench.py into profiles/ (run here, on files merged back from the GPU box).
 
-    python tools/pmc_summary.py <tag> <workload key, e.g. C3:4096x5000> <kernel_trace.csv> <fetch.csv> <write.csv> [warmup]
+    python tools/pmc_summary.py <tag> <workload key, e.g. C3:4096x5000> <kernel_trace.csv> <fetch.csv> <write.csv>
+                                [untimed launches in the trace run] [untimed launches in the PMC runs]
 
 * kernel trace  -> mean duration per kernel, and the mean over the TIMED launches only (the bench's
   warm-up launches of the dominant kernel are dropped), to set beside bench.py's HIP-event figure;
@@ -29,6 +30,7 @@ def short(name):
 def main():
     tag, key, trace, fetch, write = sys.argv[1:6]
     warmup = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+    pmc_skip = int(sys.argv[7]) if len(sys.argv) > 7 else 2
     dur = defaultdict(list)
     with open(trace) as f:
         for row in csv.DictReader(f):
@@ -50,8 +52,8 @@ def main():
         fs = counters["FETCH_SIZE"].get(k)
         ws = counters["WRITE_SIZE"].get(k)
         if fs and ws:
-            fs_t = fs[2:] if len(fs) > 3 else fs  # PMC passes run with --warmup 2
-            ws_t = ws[2:] if len(ws) > 3 else ws
+            fs_t = fs[pmc_skip:] if len(fs) > pmc_skip + 1 else fs  # the PMC passes' burn-in + warm-up launches
+            ws_t = ws[pmc_skip:] if len(ws) > pmc_skip + 1 else ws
             f_kib, w_kib = sum(fs_t) / len(fs_t), sum(ws_t) / len(ws_t)
             e.update({"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
                       "hbm_read_bytes_per_launch": 2.0 * f_kib * 1024, "hbm_write_bytes_per_launch": w_kib * 1024,
