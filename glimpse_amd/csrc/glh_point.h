@@ -674,18 +674,24 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const double scale = a.inv2s2[o];
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
       if (o == 0) {
+        auto sample_one = [&](int i, double2 q) {
+          if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
+          const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
+        };
+        if constexpr (PPT > 0) {
+          // fully unrolled: u0[r] is a register with a static index (a rolled loop sends the array to scratch:
+          // 80 B per thread written and re-read through memory)
+#pragma unroll
+          for (int r = 0; r < NREG; ++r) {
+            const int i = r * TB + tid;
+            if (i < N) sample_one(i, make_double2(u0[r], c[i]));
+          }
+        } else {
 #pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-          const int i = r * TB + tid;
-          if (i < N) {
-            double2 q;
-            if constexpr (PPT > 0)
-              q = make_double2(pt_pick<NREG>(u0, r), c[i]);
-            else
-              q = make_double2(c[i], V0[i]);
-            if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-            const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
-            c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
+          for (int r = 0; r < rounds; ++r) {
+            const int i = r * TB + tid;
+            if (i < N) sample_one(i, make_double2(c[i], V0[i]));
           }
         }
         c_ready = true;
