@@ -99,10 +99,12 @@ GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z,
   if (f & (CAM_F_ANYK | CAM_F_ANYP)) {
     double r2 = px * px + py * py;
     if (f & CAM_F_ANYK) {
+      // (camera.py:1148-1153 skips a term whose k is zero; adding k * r2^n = +-0.0 instead leaves dr bit for bit
+      // the same for every finite r2, and costs less than the three uniform branches)
       double dr = 1.0;
-      if (f & (CAM_F_K0 << 0)) dr += c.k[0] * r2;
-      if (f & (CAM_F_K0 << 1)) dr += c.k[1] * r2 * r2;
-      if (f & (CAM_F_K0 << 2)) dr += c.k[2] * r2 * r2 * r2;
+      dr += c.k[0] * r2;
+      dr += c.k[1] * r2 * r2;
+      dr += c.k[2] * r2 * r2 * r2;
       if (f & CAM_F_ANYKDEN) {
         double t = 1.0;
         if (f & (CAM_F_K0 << 3)) t += c.k[3] * r2;
