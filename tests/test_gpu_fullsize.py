@@ -1,0 +1,82 @@
+"""BASELINE.json's configurations at FULL size (C3: 4 096 points x 5 000 particles; one GPU's shard of C4: 1 250 points
+x 10 000 particles; 2048^2 frames, 31x31 templates) through properties that do not need the oracle to run at that size:
+
+* the staged kernels, run on a 48-point slice of the same points with the same global RNG keys, reproduce the fused
+  kernel's rows of the big run bit for bit (particles, weights, resample indices) -- the slice is small enough for
+  the oracle-pinned staged path, the big run is what the bench times;
+* systematic resampling returns every point's sources in nondecreasing order, each source index is in range, and the
+  run-length compact state expands to exactly particles[idx] / weights[idx] of those indices;
+* two half-size shards reproduce the unsharded posterior history (checksum of checksums);
+* every point is tracked by the observer, nothing is flagged, and the filter follows the synthetic motion."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T = 4
+SEED = 77
+
+
+def _run(lib, wl, frames, p0, p1, mode, keep_idx=False):
+    from glimpse_amd import workloads
+
+    sub = workloads.Workload.__new__(workloads.Workload)
+    sub.__dict__.update(wl.__dict__)
+    sub.P = p1 - p0
+    sub.params = wl.params[p0:p1]
+    with lib.Context(sub.P, wl.N, 1, max_tile=31, max_search_dim=160, max_frames=T) as ctx:
+        workloads.setup_context(ctx, sub, frames)
+        ctx.set_point_offset(p0)
+        ctx.set_fused(mode)
+        if keep_idx:
+            ctx.set_debug(2)
+        ctx.set_frame(0)
+        ctx.init_particles(seed=SEED)
+        ctx.init_templates(0, 0)
+        ctx.record_moments(0)
+        idx = None
+        for i in range(1, T):
+            ctx.step(i, 1.0, [i], seed=SEED)
+        if keep_idx:
+            idx = ctx.resample_indices()
+        out = dict(moments=ctx.get_moments(0, T), particles=ctx.get_particles(), weights=ctx.get_weights(),
+                   status=ctx.point_status(), obs=ctx.observer_status(), idx=idx)
+    return out
+
+
+@pytest.mark.parametrize("name,shape", [("C3", (4096, 5000)), ("C4", (1250, 10000))])
+def test_full_size_properties(name, shape):
+    """C3 whole; C4 as one of its 8 shards (1 250 points x 10 000 particles: the 1 024-thread variant)."""
+    from glimpse_amd import _lib as lib
+    from glimpse_amd import workloads
+
+    wl = workloads.Workload(name, n_frames=T)
+    assert (wl.P, wl.N) == shape and (wl.tile, wl.imgsz) == ((31, 31), (2048, 2048))
+    frames = [wl.frames(0)]
+    big = _run(lib, wl, frames, 0, wl.P, 1, keep_idx=True)
+    assert (big["status"] == 0).all() and (big["obs"] == lib.OBS_OK).all()
+    assert np.isfinite(big["moments"]).all()
+    # resample indices of the last step: sorted, in range
+    idx = big["idx"]
+    assert idx.min() >= 0 and idx.max() < wl.N
+    assert (np.diff(idx, axis=1) >= 0).all()
+    # the filter follows the synthetic motion (0.15 units/frame along x)
+    vx = big["moments"][-1, :, 3]
+    assert abs(np.median(vx) - 0.15) < 0.03
+    # a slice of the points on the staged kernels, same global RNG keys: bit for bit the fused rows
+    p0, p1 = wl.P // 4, wl.P // 4 + 48
+    small = _run(lib, wl, frames, p0, p1, 0, keep_idx=True)
+    np.testing.assert_array_equal(small["idx"], idx[p0:p1])
+    np.testing.assert_array_equal(small["particles"], big["particles"][p0:p1])
+    np.testing.assert_array_equal(small["weights"], big["weights"][p0:p1])
+    np.testing.assert_allclose(small["moments"], big["moments"][:, p0:p1], rtol=1e-12, atol=1e-13)
+    # the compact state expanded == gather by the indices: copies of a source are identical records
+    same = idx[:, 1:] == idx[:, :-1]
+    assert (big["particles"][:, 1:][same] == big["particles"][:, :-1][same]).all()
+    assert (big["weights"][:, 1:][same] == big["weights"][:, :-1][same]).all()
+    # two shards == the unsharded run
+    half = wl.P // 2
+    lo = _run(lib, wl, frames, 0, half, 1)
+    hi = _run(lib, wl, frames, half, wl.P, 1)
+    np.testing.assert_array_equal(np.concatenate((lo["moments"], hi["moments"]), axis=1), big["moments"])
+    np.testing.assert_array_equal(np.concatenate((lo["particles"], hi["particles"])), big["particles"])
