@@ -186,7 +186,11 @@ struct TileWs {
 template <int TB>
 __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box, int nb, int hist_n, const TileWs& ws,
                                              uint32_t* scan_tmp, unsigned long long* stp = nullptr) {
-#define TP_STAMP(k) do { if (stp && threadIdx.x == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  // diagnostic s_memtime stamps 13 / 14 inside this stage (tools/phase_probe.py), when armed
+#define TP_STAMP(k)                                                                                      \
+  do {                                                                                                   \
+    if (stp && threadIdx.x == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   for (int b = tid; b < nb; b += TB) ws.hist[b] = 0;
@@ -280,6 +284,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(ws.lut[key.y] - ws.lut[med.y]);
   }
   __syncthreads();
+#undef TP_STAMP
 }
 
 // cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614) from ws.S / ws.T into ws.Z (widened
