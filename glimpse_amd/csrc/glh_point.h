@@ -484,7 +484,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // PPT == 0: u parked in c[i] and v in the first N doubles of the observer-0 slot of the uv scratch
   // (L2 / Infinity Cache).
   constexpr int NREG = PPT > 0 ? PPT : 1;
-  const int rounds = PPT > 0 ? PPT : (N + TB - 1) / TB;
+  const int rounds = (N + TB - 1) / TB;  // <= PPT when PPT > 0 (the host picks the variant)
   double* V0 = a.uv + (size_t)pt * N * 2;
   double u0[NREG];
   {
@@ -689,8 +689,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           // 80 B per thread written and re-read through memory)
 #pragma unroll
           for (int r = 0; r < NREG; ++r) {
-            const int i = r * TB + tid;
-            if (i < N) sample_one(i, make_double2(u0[r], c[i]));
+            if (r < rounds) {  // uniform
+              const int i = r * TB + tid;
+              if (i < N) sample_one(i, make_double2(u0[r], c[i]));
+            }
           }
         } else {
 #pragma unroll 1
