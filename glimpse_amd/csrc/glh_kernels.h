@@ -1081,8 +1081,8 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
     for (int idx = tid; idx < wo * ho; idx += BLK) cp[idx] = z[idx];
     __syncthreads();
   }
-  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
-    __shared__ double z1[GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX];
+  if (spline_dense(ho, wo)) {
+    __shared__ double z1[GLH_SPL_DENSE_NINV / 2];  // ho * wo <= (ho^2 + wo^2) / 2
     spline_fit_dense<BLK>(z, z1, wo, ho, a.inv + spline_inverse_off(ho), a.inv + spline_inverse_off(wo));
     return;
   }

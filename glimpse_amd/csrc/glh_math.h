@@ -363,9 +363,13 @@ GLH_HD double knot_local(int i, int n) {
 }
 
 // interval q (0 <= q <= n-4) that holds local coordinate xl in [0, n-1]
-// largest SSE-surface side whose spline fit goes through the explicit inverse of the collocation matrix
-// (glh_host.h: spline_inverse); larger surfaces use the banded LU solves
-constexpr int GLH_SPL_DENSE_MAX = 48;
+// The spline fit of a SMALL surface goes through the explicit inverses of the two collocation matrices
+// (glh_host.h: spline_inverse): small = both inverses fit in 512 doubles, i.e. one entry per thread of the fused
+// kernel and a few KB of LDS (sides up to 16 x 16, or e.g. 4 x 22).  Larger surfaces use the banded LU solves,
+// whose serial chains beat a dense product that has to stream its matrices from memory.
+constexpr int GLH_SPL_DENSE_MAX = 22;    // largest side that can satisfy the rule
+constexpr int GLH_SPL_DENSE_NINV = 512;  // ho^2 + wo^2 <= this
+GLH_HD bool spline_dense(int ho, int wo) { return ho * ho + wo * wo <= GLH_SPL_DENSE_NINV; }
 GLH_HD int64_t spline_inverse_off(int n) {  // offset of the n x n inverse in the packed table (sizes 4 .. MAX)
   // sum_{m=4}^{n-1} m^2
   const int64_t k = n - 1;

@@ -369,7 +369,7 @@ __device__ __forceinline__ void pt_solve_line(double* x, int stride, int n, cons
 template <int TB>
 __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) {
   const int tid = threadIdx.x;
-  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
+  if (spline_dense(ho, wo)) {
     spline_fit_dense<TB>(ws.Z, ws.Z1, wo, ho, ws.ih, ws.iw);
     return;
   }
@@ -656,12 +656,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int s_bytes = pt_align16(hs * ld_lds * 4);
     const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
     const int l1 = hcl + pt_align16(hs * ws_ * 2);
-    const bool dense = ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX;  // spline fit by explicit inverses
+    const bool dense = spline_dense(ho, wo);  // spline fit by explicit inverses
     const int zb = pt_align16(ho * wo * 8);
     // small inverses (one entry per thread) are fetched before the SSD and parked in LDS after it, like the LU
     // factors of the larger surfaces: no memory latency inside the fit
     const int ninv = ho * ho + wo * wo;
-    const bool inv_lds = dense && ninv <= TB;
+    const bool inv_lds = dense;  // (ninv <= 512 <= TB)
     const int l2 = dense ? 2 * zb + (inv_lds ? pt_align16(ninv * 8) : 0) : zb + pt_align16(5 * (ho + wo) * 8);
     const bool fits = off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
@@ -786,9 +786,44 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       PT_STAMP(2);
       pt_ssd<TB>(ws, tw, th, wo, ho);
       PT_STAMP(3);
-      pt_spline_fit<TB>(ws, wo, ho);
-      PT_STAMP(4);
-      sample_all(ws.Z);
+      const int lub = pt_align16(5 * (ho + wo) * 8);
+      if (zb + (dense ? zb : lub) <= a.r2_bytes) {
+        // The template tile and the histogram tables are dead: the SSD surface moves from the HBM workspace into
+        // region 2 (four loads in flight per thread), with the LU factors of a larger surface behind it, so that
+        // the fit and the sampling of every particle read LDS.
+        double* Zl = reinterpret_cast<double*>(r2);
+        double* fl = Zl + zb / 8;
+        const double* Zg = ws.Z;
+        for (int base = 0; base < ho * wo; base += 4 * TB) {
+          double v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * TB + tid;
+            v[q] = idx < ho * wo ? Zg[idx] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * TB + tid;
+            if (idx < ho * wo) Zl[idx] = v[q];
+          }
+        }
+        if (!dense) {
+          for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
+          for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
+          ws.fh = fl;
+          ws.fw = fl + 5 * ho;
+        }
+        __syncthreads();
+        ws.Z = Zl;
+        ws.Z1 = fl;
+        pt_spline_fit<TB>(ws, wo, ho);
+        PT_STAMP(4);
+        sample_all(Zl);
+      } else {
+        pt_spline_fit<TB>(ws, wo, ho);
+        PT_STAMP(4);
+        sample_all(ws.Z);
+      }
     }
     __syncthreads();  // region 2 is free for the next observer
   }

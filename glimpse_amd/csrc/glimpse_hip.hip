@@ -1188,7 +1188,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   // phase D/E: tree nodes | clast, then (over them) three rank tables of N uint16
   const int plan = std::max(pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8, 3 * pt_align16(c->N * 2));
   // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
-  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX * 8);
+  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_NINV / 2 * 8);
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + 48 * 48 * 2 + 4096;
   int r2;

@@ -67,7 +67,7 @@ void hc_spline_sample(const double* z, int ho, int wo, const double* box, const 
       x[(size_t)i * stride] = acc * u0i[i];
     }
   };
-  if (ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX) {
+  if (spline_dense(ho, wo)) {
     // small surfaces: C = Ih . Z . Iw^T with the explicit inverses (spline_fit_dense of glh_kernels.h)
     std::vector<double> ih((size_t)ho * ho), iw((size_t)wo * wo), z1((size_t)ho * wo);
     spline_inverse(ho, ih.data());
