@@ -784,7 +784,32 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.fw = fw_g;
       pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
       PT_STAMP(2);
-      pt_ssd<TB>(ws, tw, th, wo, ho);
+      if (offT + pt_align16(hs * ws.ld * 4) <= a.r2_bytes) {
+        // the histogram tables are dead and the search tile alone does fit behind the template: bring it in from
+        // the workspace (four loads in flight per thread), so that the SSD reads LDS
+        float* Sl = reinterpret_cast<float*>(r2 + offT);
+        const float4* Sg = reinterpret_cast<const float4*>(ws.S);
+        float4* Sl4 = reinterpret_cast<float4*>(Sl);
+        const int n4 = hs * ws.ld / 4;  // ld is a multiple of 4
+        for (int base = 0; base < n4; base += 4 * TB) {
+          float4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * TB + tid;
+            v[q] = idx < n4 ? Sg[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = base + q * TB + tid;
+            if (idx < n4) Sl4[idx] = v[q];
+          }
+        }
+        __syncthreads();
+        ws.S = Sl;
+        pt_ssd<TB>(ws, tw, th, wo, ho);
+      } else {
+        pt_ssd<TB>(ws, tw, th, wo, ho);
+      }
       PT_STAMP(3);
       const int lub = pt_align16(5 * (ho + wo) * 8);
       if (zb + (dense ? zb : lub) <= a.r2_bytes) {
