@@ -383,6 +383,26 @@ __device__ __forceinline__ void pt_spline_fit(const TileWs& ws, int wo, int ho) 
 // global loads / stores (which __syncthreads() would)
 __device__ __forceinline__ void pt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Whole block: n items from memory into LDS with four loads in flight per thread (a plain copy loop waits for
+// every load before it issues the next).  No barrier.
+template <int TB, typename T>
+__device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base < n; base += 4 * TB) {
+    T v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      v[q] = src[idx < n ? idx : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      if (idx < n) dst[idx] = v[q];
+    }
+  }
+}
+
 #define PT_STAMP(k)                                                                      \
   do {                                                                                   \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
@@ -504,19 +524,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // record of every particle (compact input state): staged in region 2, which is free until phase B
     uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
     if (uin) {
-      for (int base = 0; base < N; base += 4 * TB) {  // four index loads in flight per thread
-        uint16_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k = base + q * TB + tid;
-          v[q] = k < N ? uin[k] : (uint16_t)0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k = base + q * TB + tid;
-          if (k < N) s_rec[k] = v[q];
-        }
-      }
+      pt_stage<TB>(s_rec, uin, N);
     } else {
       for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
     }
@@ -786,24 +794,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       PT_STAMP(2);
       if (offT + pt_align16(hs * ws.ld * 4) <= a.r2_bytes) {
         // the histogram tables are dead and the search tile alone does fit behind the template: bring it in from
-        // the workspace (four loads in flight per thread), so that the SSD reads LDS
+        // the workspace, so that the SSD reads LDS
         float* Sl = reinterpret_cast<float*>(r2 + offT);
-        const float4* Sg = reinterpret_cast<const float4*>(ws.S);
-        float4* Sl4 = reinterpret_cast<float4*>(Sl);
-        const int n4 = hs * ws.ld / 4;  // ld is a multiple of 4
-        for (int base = 0; base < n4; base += 4 * TB) {
-          float4 v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int idx = base + q * TB + tid;
-            v[q] = idx < n4 ? Sg[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int idx = base + q * TB + tid;
-            if (idx < n4) Sl4[idx] = v[q];
-          }
-        }
+        pt_stage<TB>(reinterpret_cast<float4*>(Sl), reinterpret_cast<const float4*>(ws.S),
+                     hs * ws.ld / 4);  // ld is a multiple of 4
         __syncthreads();
         ws.S = Sl;
         pt_ssd<TB>(ws, tw, th, wo, ho);
@@ -814,24 +808,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const int lub = pt_align16(5 * (ho + wo) * 8);
       if (zb + (dense ? zb : lub) <= a.r2_bytes) {
         // The template tile and the histogram tables are dead: the SSD surface moves from the HBM workspace into
-        // region 2 (four loads in flight per thread), with the LU factors of a larger surface behind it, so that
+        // region 2, with the LU factors of a larger surface behind it, so that
         // the fit and the sampling of every particle read LDS.
         double* Zl = reinterpret_cast<double*>(r2);
         double* fl = Zl + zb / 8;
-        const double* Zg = ws.Z;
-        for (int base = 0; base < ho * wo; base += 4 * TB) {
-          double v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int idx = base + q * TB + tid;
-            v[q] = idx < ho * wo ? Zg[idx] : 0.0;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int idx = base + q * TB + tid;
-            if (idx < ho * wo) Zl[idx] = v[q];
-          }
-        }
+        pt_stage<TB>(Zl, static_cast<const double*>(ws.Z), ho * wo);
         if (!dense) {
           for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
           for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
