@@ -420,6 +420,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ uint32_t scan_tmp[PT_WAVES];
   __shared__ int s_box[NOBS][4];
   __shared__ int s_status[NOBS];
+  __shared__ double s_K[6];  // the point's first evolved particle: pivot of the shifted moments (phase A -> F)
   __shared__ CamDev s_cam[NOBS];           // cameras: LDS broadcast reads instead of ~60 live SGPRs each
   __shared__ double s_m[GLH_MOTION_FULL_LEN];  // this point's motion parameters: the loops below store to global
                                           // memory, so reading them through a global pointer would reload
@@ -551,6 +552,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         double n[3];
         evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
         evolve_cartesian(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
+        if (i == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s_K[k] = x[k];
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
         if (a.has_dem) {
@@ -1072,8 +1077,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   double* Pout = a.particles_out + (size_t)pt * N * 6;
   double* Wout = a.weights_out + (size_t)pt * N;
   const int U = max(s_U, 1);
-  double K[6];
-  evolved(0, K);  // pivot of the shifted moments: the point's first evolved particle
+  double K[6];  // pivot of the shifted moments: the point's first evolved particle (parked by phase A)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) K[k] = s_K[k];
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
   constexpr int GU = 2;
   for (int h0 = tid; h0 < U; h0 += GU * TB) {
