@@ -420,6 +420,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ uint32_t scan_tmp[PT_WAVES];
   __shared__ int s_box[NOBS][4];
   __shared__ int s_status[NOBS];
+  __shared__ double s_u;     // np.random.random() of this point's systematic resampling (tracker.py:173)
   __shared__ double s_K[6];  // the point's first evolved particle: pivot of the shifted moments (phase A -> F)
   __shared__ CamDev s_cam[NOBS];           // cameras: LDS broadcast reads instead of ~60 live SGPRs each
   __shared__ double s_m[GLH_MOTION_FULL_LEN];  // this point's motion parameters: the loops below store to global
@@ -436,6 +437,16 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const double tau = a.tau, tau2 = a.tau * a.tau;
 
   PT_STAMP(0);
+  if (tid == 0) {
+    if (a.rng_mode == GLH_RNG_HOST) {
+      s_u = a.u[pt];
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+                    (uint32_t)(a.seed >> 32), r);
+      s_u = u01_halfopen(r[0], r[1]);
+    }
+  }
   for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
   if (tid < GLH_MOTION_FULL_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_FULL_LEN + tid];
   {
@@ -920,15 +931,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   double* clast = node + a.nnodes;  // [TB] last cumulative weight of every segment
   clast[tid] = tid > 0 ? excl + run : run;
   PT_STAMP(12);
-  double u;
-  if (a.rng_mode == GLH_RNG_HOST) {
-    u = a.u[pt];
-  } else {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
-                  (uint32_t)(a.seed >> 32), r);
-    u = u01_halfopen(r[0], r[1]);
-  }
+  const double u = s_u;  // the point's resample offset (drawn once, in the prologue)
   const double inv_n = 1.0 / (double)N;
   // Region 2 once the tree nodes and clast are dead: three tables of N uint16 each.
   const int n16 = pt_align16(N * 2) / 2;
