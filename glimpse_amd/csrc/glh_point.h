@@ -547,8 +547,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const double2* src = Pin2 + (size_t)s_rec[tid < N ? tid : 0] * rec_stride;
       nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
     }
-#pragma unroll 1
-    for (int r = 0; r < rounds; ++r) {
+    auto a_iter = [&](int r) {
       // compiler barrier: camera / motion constants are re-read from LDS (broadcast) every iteration
       // instead of being hoisted into ~100 registers that would spill
       asm volatile("" ::: "memory");
@@ -604,6 +603,16 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           }
         }
       }
+    };
+    if constexpr (PPT > 0 && NOBS == 1 && !SURF) {
+      // unrolled over the per-thread particles (u0[r] = u with a static index instead of a compare-select chain
+      // over the array); only where one observer keeps the body small
+#pragma unroll
+      for (int r = 0; r < NREG; ++r)
+        if (r < rounds) a_iter(r);
+    } else {
+#pragma unroll 1
+      for (int r = 0; r < rounds; ++r) a_iter(r);
     }
     if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
     if (raster_oob) view_bits |= GLH_PT_RASTER_OOB;
