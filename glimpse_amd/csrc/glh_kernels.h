@@ -29,6 +29,21 @@ struct ObsFrame {
   int32_t width, height, channels;
 };
 
+// Division of small non-negative integers by a divisor that is the same for the whole workgroup: n / d as
+// umulhi(n, ceil(2^32 / d)), exact whenever n * d < 2^32 (here n < 2^17 pixels or outputs, d < 2^9).  The
+// compiler's general 32-bit division is ~40 instructions per use; this is one, after one float64 division per
+// divisor.
+struct UDiv {
+  uint32_t m, d;
+};
+__device__ __forceinline__ UDiv udiv_make(int d) {
+  UDiv r;
+  r.d = (uint32_t)d;
+  r.m = d > 1 ? (uint32_t)(4294967296.0 / (double)d) + 1u : 0u;
+  return r;
+}
+__device__ __forceinline__ int udiv(const UDiv& u, int n) { return u.d > 1 ? (int)__umulhi((uint32_t)n, u.m) : n; }
+
 // ------------------------------------------------------------------------------------------
 // wave / block reductions (deterministic order)
 // ------------------------------------------------------------------------------------------
@@ -1026,8 +1041,9 @@ template <int NT>
 __device__ __forceinline__ void spline_fit_dense(double* Z, double* Z1, int wo, int ho, const double* Ih,
                                                  const double* Iw) {
   const int tid = threadIdx.x;
+  const UDiv by_wo = udiv_make(wo);
   for (int idx = tid; idx < ho * wo; idx += NT) {
-    const int r = idx / wo, c = idx - r * wo;
+    const int r = udiv(by_wo, idx), c = idx - r * wo;
     const double* row = Ih + (size_t)r * ho;
     double acc = 0.0;
 #pragma unroll 4
@@ -1036,7 +1052,7 @@ __device__ __forceinline__ void spline_fit_dense(double* Z, double* Z1, int wo, 
   }
   __syncthreads();
   for (int idx = tid; idx < ho * wo; idx += NT) {
-    const int r = idx / wo, c = idx - r * wo;
+    const int r = udiv(by_wo, idx), c = idx - r * wo;
     const double* row = Iw + (size_t)c * wo;
     const double* zr = Z1 + (size_t)r * wo;
     double acc = 0.0;

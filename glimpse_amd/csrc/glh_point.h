@@ -196,12 +196,13 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   for (int b = tid; b < nb; b += TB) ws.hist[b] = 0;
   __syncthreads();
   // four pixel loads in flight per thread (each is a scattered byte fetch with a full memory latency)
+  const UDiv by_w = udiv_make(w);
   for (int base = 0; base < n; base += 4 * TB) {
     int key[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = base + q * TB + tid;
-      const int r = idx / w, c = idx - r * w;
+      const int r = udiv(by_w, idx), c = idx - r * w;
       key[q] = idx < n ? pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
     }
 #pragma unroll
@@ -254,8 +255,9 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   // so a window leaves the tile by at most 3 and ONE edge reflection is exact
   // (scipy.ndimage 'reflect': d c b a | a b c d | d c b a).
   const int npc = (w + 1) >> 1;
+  const UDiv by_npc = udiv_make(npc);
   for (int idx = tid; idx < h * npc; idx += TB) {
-    const int r = idx / npc, c0 = 2 * (idx - r * npc);
+    const int r = udiv(by_npc, idx), c0 = 2 * (idx - r * npc);
     int rows[5], cols[6];
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
@@ -298,10 +300,12 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   const int nstrips = spr * ho;
   const int G = ssd_row_split(wo, ho);
   const double inv_area = 1.0 / (double)(tw * th);
-  for (int s0 = 0; s0 < nstrips; s0 += TB / G) {
-    const int strip = s0 + tid / G, g = tid % G;
+  const int lgG = __ffs(G) - 1;  // G is a power of two
+  const UDiv by_spr = udiv_make(spr);
+  for (int s0 = 0; s0 < nstrips; s0 += TB >> lgG) {
+    const int strip = s0 + (tid >> lgG), g = tid & (G - 1);
     const bool live = strip < nstrips;
-    const int rr = live ? strip / spr : 0;
+    const int rr = live ? udiv(by_spr, strip) : 0;
     const int cc = live ? (strip - rr * spr) * SSD_W : 0;
     double acc64[SSD_W];
 #pragma unroll
@@ -480,8 +484,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int hist_n = a.tmpl_hist_n[slot];
     float* T = reinterpret_cast<float*>(r2);
     const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
+    const UDiv by_twp = udiv_make(twp);
     for (int idx = tid; idx < th * twp; idx += TB) {
-      const int i = idx / twp, j = idx - i * twp;
+      const int i = udiv(by_twp, idx), j = idx - i * twp;
       T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
     }
     double* cq = reinterpret_cast<double*>(r2 + pt_align16(th * twp * 4));
