@@ -158,6 +158,12 @@ __host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
   return pt_align16(th * ssd_twp(tw) * 4) + pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
 }
 
+// The raw-key tile of a w x h crop is stored with its 'reflect' border already in place (2 rows above and below,
+// 2 columns left, 3 right), row stride even: every 5x5 window of a PAIR of pixels is then three aligned 32-bit
+// words per row, without index arithmetic.
+__host__ __device__ __forceinline__ int pt_keys_stride(int w) { return (w + 6 + 1) & ~1; }
+__host__ __device__ __forceinline__ int pt_keys_count(int w, int h) { return (h + 4) * pt_keys_stride(w); }
+
 // ints of the NumPy pairwise-sum plan staged in LDS: leaf_off | leaf_len | ops | level_off | roots
 __host__ __device__ __forceinline__ int pt_plan_ints(int nleaves, int nnodes, int nlevels, int nroots) {
   return 2 * nleaves + 3 * (nnodes - nleaves) + (nlevels + 1) + nroots;
@@ -170,7 +176,7 @@ struct TileWs {
   uint32_t* cum;    // [nb]
   double* lut;      // [nb]
   float* S;         // [hs][ld] search tile
-  uint16_t* keys;   // [hs * ws] raw pixel keys
+  uint16_t* keys;   // [pt_keys_count(ws, hs)] raw pixel keys with their reflected border
   double* Z;        // [ho * wo] SSD surface -> spline coefficients
   double* Z1;       // [ho * wo] scratch of the dense spline fit (sides <= GLH_SPL_DENSE_MAX), always LDS
   const double* ih;  // explicit inverses of the ho / wo collocation matrices (LDS copy or the global table)
@@ -193,28 +199,39 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   } while (0)
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  const int wp = pt_keys_stride(w);
+  uint16_t* keys = ws.keys + 2 * wp + 2;  // element (r, c) of the crop at keys[r * wp + c], r in [-2, h + 2), c in [-2, w + 3)
   for (int b = tid; b < nb; b += TB) ws.hist[b] = 0;
   __syncthreads();
   // four pixel loads in flight per thread (each is a scattered byte fetch with a full memory latency)
   const UDiv by_w = udiv_make(w);
   for (int base = 0; base < n; base += 4 * TB) {
-    int key[4];
+    int key[4], at[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = base + q * TB + tid;
       const int r = udiv(by_w, idx), c = idx - r * w;
+      at[q] = r * wp + c;
       key[q] = idx < n ? pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (key[q] >= 0) {
-        ws.keys[base + q * TB + tid] = (uint16_t)key[q];
+        keys[at[q]] = (uint16_t)key[q];
         atomicAdd(&ws.hist[key[q]], 1u);
       }
     }
   }
   __syncthreads();
   TP_STAMP(13);
+  // scipy.ndimage 'reflect' (d c b a | a b c d | d c b a), columns first: 2 left, 3 right of every crop row
+  // (tiles are >= 8 pixels on a side, so one reflection is exact) ...
+  for (int idx = tid; idx < 5 * h; idx += TB) {
+    const int r = idx / 5, k = idx - 5 * r;
+    const int c = k < 2 ? -1 - k : w + (k - 2);         // -1, -2, w, w + 1, w + 2
+    const int src = k < 2 ? k : w - 1 - (k - 2);        //  0,  1, w - 1, w - 2, w - 3
+    keys[r * wp + c] = keys[r * wp + src];
+  }
   {
     // inclusive scan of the nb <= 2 * TB bins: two bins per thread + block scan
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
@@ -236,6 +253,13 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     if (b1 < nb) ws.cum[b1] = excl + local;
   }
   __syncthreads();
+  // ... then whole padded rows: -1 <- 0, -2 <- 1, h <- h - 1, h + 1 <- h - 2 (the column borders are in place)
+  for (int idx = tid; idx < 4 * wp; idx += TB) {
+    const int k = idx / wp, c = idx - k * wp - 2;
+    const int r = k < 2 ? -1 - k : h + (k - 2);
+    const int src = k < 2 ? k : h - 1 - (k - 2);
+    keys[r * wp + c] = keys[src * wp + c];
+  }
   for (int b = tid; b < nb; b += TB) {
     if (ws.hist[b]) {
       const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
@@ -251,34 +275,25 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     ws.S[r * ld + c] = 0.0f;
   }
   // 5x5 median of the raw keys around every pixel, TWO horizontally adjacent pixels per thread on
-  // packed 16-bit lanes (same selection network, v_pk_min/max_u16).  Tiles are >= 8 pixels on a side,
-  // so a window leaves the tile by at most 3 and ONE edge reflection is exact
-  // (scipy.ndimage 'reflect': d c b a | a b c d | d c b a).
+  // packed 16-bit lanes (same selection network, v_pk_min/max_u16).  The window of the pair (r, c0), (r, c0 + 1)
+  // is columns c0 - 2 .. c0 + 3 of rows r - 2 .. r + 2 of the bordered tile: three aligned 32-bit words per row
+  // (c0 and the row stride are even), i.e. the pairs (k0 k1) (k2 k3) (k4 k5) directly and (k1 k2) (k3 k4) by a
+  // funnel shift.
   const int npc = (w + 1) >> 1;
   const UDiv by_npc = udiv_make(npc);
   for (int idx = tid; idx < h * npc; idx += TB) {
     const int r = udiv(by_npc, idx), c0 = 2 * (idx - r * npc);
-    int rows[5], cols[6];
-#pragma unroll
-    for (int d = 0; d < 5; ++d) {
-      int rr = r + d - 2;
-      rr = rr < 0 ? -rr - 1 : (rr >= h ? 2 * h - 1 - rr : rr);
-      rows[d] = rr * w;
-    }
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      int cc = c0 + d - 2;
-      cc = cc < 0 ? -cc - 1 : (cc >= w ? 2 * w - 1 - cc : cc);
-      cols[d] = cc;
-    }
+    const uint32_t* win = reinterpret_cast<const uint32_t*>(keys + (r - 2) * wp + (c0 - 2));
     glh_us2 v[25];
 #pragma unroll
     for (int dr = 0; dr < 5; ++dr) {
-      unsigned short k6[6];
-#pragma unroll
-      for (int d = 0; d < 6; ++d) k6[d] = ws.keys[rows[dr] + cols[d]];
-#pragma unroll
-      for (int dc = 0; dc < 5; ++dc) v[dr * 5 + dc] = glh_us2{k6[dc], k6[dc + 1]};  // pixel c0 | pixel c0 + 1
+      const uint32_t d0 = win[dr * (wp / 2)], d1 = win[dr * (wp / 2) + 1], d2 = win[dr * (wp / 2) + 2];
+      const uint32_t m01 = (d0 >> 16) | (d1 << 16), m12 = (d1 >> 16) | (d2 << 16);
+      v[dr * 5 + 0] = __builtin_bit_cast(glh_us2, d0);   // pixel c0 | pixel c0 + 1 in the low | high half
+      v[dr * 5 + 1] = __builtin_bit_cast(glh_us2, m01);
+      v[dr * 5 + 2] = __builtin_bit_cast(glh_us2, d1);
+      v[dr * 5 + 3] = __builtin_bit_cast(glh_us2, m12);
+      v[dr * 5 + 4] = __builtin_bit_cast(glh_us2, d2);
     }
     const glh_us2 key = v[12];
     const glh_us2 med = median25_pk(v);
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           st = GLH_OBS_OUT_OF_BOUNDS;
         else {
           const int w = s_box[o][2] - s_box[o][0], h = s_box[o][3] - s_box[o][1];
-          if (w > a.max_dim || h > a.max_dim || (long long)w * h > a.keys_cap ||
+          if (w > a.max_dim || h > a.max_dim || (long long)pt_keys_count(w, h) > a.keys_cap ||
               (long long)h * ((w + 14) & ~3) > a.search_cap)
             st = GLH_OBS_TILE_TOO_LARGE;
         }
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int ld_lds = pt_search_ld(ws_);
     const int s_bytes = pt_align16(hs * ld_lds * 4);
     const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
-    const int l1 = hcl + pt_align16(hs * ws_ * 2);
+    const int l1 = hcl + pt_align16(pt_keys_count(ws_, hs) * 2);
     const bool dense = spline_dense(ho, wo);  // spline fit by explicit inverses
     const int zb = pt_align16(ho * wo * 8);
     // small inverses (one entry per thread) are fetched before the SSD and parked in LDS after it, like the LU

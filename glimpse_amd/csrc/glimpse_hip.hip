@@ -285,7 +285,7 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   const size_t P = k.max_points, N = k.max_particles, O = k.n_observers;
   c->tile_cap = k.max_tile * k.max_tile;
   c->search_cap = k.max_search_dim * (k.max_search_dim + 16);  // rows padded for the fused kernel
-  c->keys_cap = k.max_search_dim * k.max_search_dim;
+  c->keys_cap = pt_keys_count(k.max_search_dim, k.max_search_dim);  // with the reflected border
   c->sse_cap = c->search_cap;
   const size_t NBmax = (N + BLK - 1) / BLK;
   int rc = GLH_OK;
@@ -1190,7 +1190,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
   const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_NINV / 2 * 8);
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
-  const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + 48 * 48 * 2 + 4096;
+  const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2 + 4096;
   int r2;
   if (cN + std::max(r2_min, typical) <= PT_LDS_HALF)
     r2 = PT_LDS_HALF - cN;
