@@ -835,7 +835,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.cdf_v = hv_g;
       ws.fh = fh_g;
       ws.fw = fw_g;
-      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
+      if (offT + hcl + pt_align16(pt_keys_count(ws_, hs) * 2) <= a.r2_bytes) {
+        // only the float32 search tile is too large: the key tile stays in LDS (its own call, so that the
+        // median's window loads keep their address space)
+        ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
+        pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
+      } else {
+        pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
+      }
       PT_STAMP(2);
       if (offT + pt_align16(hs * ws.ld * 4) <= a.r2_bytes) {
         // the histogram tables are dead and the search tile alone does fit behind the template: bring it in from
