@@ -688,6 +688,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(1);
   // ---------------- B + C per observer, in the reference's order (tracker.py:139-146) ----------
   bool outside = false;
+  const bool w_here = NOBS == 1 && !a.has_dem;  // uniform: phase C of observer 0 writes weights, not log likelihoods
+  bool w_done = false;
   bool c_ready = false;  // uniform: c[] holds log likelihoods (not observer 0's parked coordinates)
   for (int o = 0; o < NOBS; ++o) {
     if (s_status[o] != GLH_OBS_OK) continue;  // uniform
@@ -735,7 +737,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         auto sample_one = [&](int i, double2 q) {
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
-          c[i] = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
+          const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
+          // a single observer and no motion-model term: this IS the log likelihood, the weight follows at once
+          c[i] = w_here ? exp(-ll) + 1e-300 : ll;
         };
         if constexpr (PPT > 0) {
           // fully unrolled: u0[r] is a register with a static index (a rolled loop sends the array to scratch:
@@ -755,6 +759,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           }
         }
         c_ready = true;
+        w_done = w_here;
       } else {
         if (!c_ready) {  // observer 0 was skipped: c[] still holds its parked coordinates
           for (int i = tid; i < N; i += TB) c[i] = 0.0;
@@ -889,12 +894,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int i = tid; i < N; i += TB) c[i] = 0.0;  // every observer skipped (same-thread indices)
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
-  for (int i = tid; i < N; i += TB) {
-    double ll = c[i];
-    if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
-    c[i] = exp(-ll) + 1e-300;  // the weights stay in LDS until the gather of phase E
+  if (!w_done) {
+    for (int i = tid; i < N; i += TB) {
+      double ll = c[i];
+      if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
+      c[i] = exp(-ll) + 1e-300;  // the weights stay in LDS until the gather of phase E
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   PT_STAMP(6);
   // ---------------- D: w.sum() as NumPy's pairwise tree, cumsum(w / total), searchsorted ------
