@@ -6,14 +6,27 @@
 One "step" = one frame update (evolve -> project -> search tile -> SSD -> spline -> weights ->
 resample -> moments, track/tracker.py:331-357) for ALL tracked points of this GPU, on synthetic
 frames that are already resident in HBM.  Metric (BASELINE.json): particle-frames/s
-= points x particles x steps / wall, summed over GPUs (weak scaling: every GPU tracks its own
-shard of points, no data-path collective; one RCCL gather of the posterior moments at the end).
+= points x particles x steps / wall, summed over GPUs.
 
-Prints ONE JSON line on rank 0 (see the keys in DESIGN.md "Measurement").
+Default workload = BASELINE config 3 as it is worded: 4096 points x 5000 particles tracked through a
+100-frame sequence FROM THE PRIOR (frame 0 initialises particles and templates, the 99 frame updates are the
+timed steps; the first of them work on the wide prior cloud and run longer than the steady state, which is
+reported beside the headline as `steady_ms_per_step`).  The W warm-up steps run the first W updates of the
+same sequence, untimed; the state is then re-initialised (untimed) and the K timed steps start from the prior.
+
+N > 1: one process per GPU, each tracking its own block of points (weak scaling; `--split strong` divides the
+workload's points instead), no data-path collective, ONE RCCL gather of the posterior moments at the end of
+the timed region (glh_gather_moments inside the library; no torch anywhere).  `--gpus N` without a launcher
+starts the N ranks itself (children are started before anything touches a GPU); under torchrun
+(RANK / WORLD_SIZE set) every process is one rank.
+
+Prints ONE JSON line on rank 0 (keys: DESIGN.md "Measurement") and exits non-zero when the run is unhealthy.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,46 +35,95 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP32_PEAK_TFLOPS = 157.3    # vector FP32 peak (= FP32-input MFMA rate on gfx950)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0  # float4 copy kernel, same guide ("6.29 TB/s measured")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed frame updates (default: the whole sequence)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override points per GPU")
     ap.add_argument("--particles", type=int, default=None)
-    ap.add_argument("--burn-in", type=int, default=6,
-                    help="untimed frames after initialisation, before the warm-up: the particle cloud starts "
-                         "from its wide prior and reaches the tracking regime after a few updates")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo gathers host copies and "
-                         "exists to exercise the multi-rank path where ranks share one GPU)")
+    ap.add_argument("--burn-in", type=int, default=0,
+                    help="untimed frame updates between initialisation and the timed steps (0 = time the sequence "
+                         "from the prior, as BASELINE words it; 6 = steady-state only)")
+    ap.add_argument("--split", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU tracks the configuration's per-GPU share; strong: the configuration's "
+                         "points are divided over the GPUs (C4: 10 000 points / N)")
+    ap.add_argument("--transport", default=None, choices=["rccl", "host"],
+                    help="collective transport for N > 1 (default: RCCL when every rank can make the communicator, "
+                         "else host copies through the rendezvous directory -- reported in the JSON line)")
     ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frame updates per library call: 0 = all the timed steps in one glh_track call (the frame loop "
                          "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the glimpse_amd.Tracker.track() leg (api_ms_per_step)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
-    ap.add_argument("--cpu-workers", type=int, default=min(16, os.cpu_count() or 1),
-                    help="processes of the parallel CPU baseline (the reference's parallel=True); 1 disables it")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="processes of the parallel CPU baseline (the reference's parallel=True = os.cpu_count(), "
+                         "helpers.py:2008-2011); 0 = every core this process may use, 1 disables it")
     ap.add_argument("--seed", type=int, default=1234)
-    return ap.parse_args()
+    ap.add_argument("--dump-moments", default=None, help="rank 0 saves the (gathered) posterior history (T, P, 12) here (.npy)")
+    return ap.parse_args(argv)
 
 
-class DevArray:
-    """Zero-copy view of a library-owned device buffer for torch (RCCL gather)."""
+# ------------------------------------------------------------------------------------------------
+# launcher: `--gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    def __init__(self, ptr, shape, typestr="<f8"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2}
+
+def launch(args):
+    """Start N fresh rank processes (this parent never touches a GPU), relay rank 0's JSON line, fail if any
+    child fails."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
+# ------------------------------------------------------------------------------------------------
+# host-side helpers
+# ------------------------------------------------------------------------------------------------
 KERNEL_OF_STAGE = {"point_step": "k_point_step", "evolve_project": "k_evolve_project", "resample": "k_resample",
                    "weights": "k_weights", "ssd": "k_ssd", "tileprep": "k_tileprep", "spline_fit": "k_spline_fit"}
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, whichever is smaller."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def pmc_traffic(wl, kernel):
@@ -103,90 +165,25 @@ def ssd_flops_per_step(O, tile, boxes, status):
     return total
 
 
-def cpu_baseline(wl, frames, steps, target_seconds):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
-    from oracle import motion as omotion
-    from oracle import tracker as otracker
-
-    observers = [otracker.Observer(frames[o], np.tile(wl.cams[o], (len(frames[o]), 1)), wl.sigmas[o])
-                 for o in range(wl.O)]
-    nfr = 1 + steps
-    matching = np.tile(np.arange(nfr)[:, None], (1, wl.O))
-    taus = np.ones(nfr - 1)
-
-    def model(p):
-        q = wl.params[p]
-        return omotion.CartesianMotion(xy=q[0:2], xy_sigma=q[2:4], vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13],
-                                       axyz_sigma=q[13:16], dem=q[16], dem_sigma=q[17], n=wl.N)
-
-    np.random.seed(7)
-    t0 = time.perf_counter()
-    otracker.track([model(0)], observers, matching, taus, tile_size=wl.tile)
-    per_point = time.perf_counter() - t0
-    n_pts = int(max(1, min(wl.P - 1, round(target_seconds / max(per_point, 1e-3)))))
-    first = 1 if wl.P > 1 else 0  # (a one-point workload, C1, times its only point again)
-    t0 = time.perf_counter()
-    otracker.track([model(first + p) for p in range(n_pts)], observers, matching, taus, tile_size=wl.tile)
-    dt = time.perf_counter() - t0
-    cpu_baseline.per_point_seconds = dt / n_pts
-    return {
-        "value": n_pts * wl.N * steps / dt,
-        "unit": "particle-frames/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{n_pts} of {wl.P} points x {wl.N} particles x {steps} steps of the same workload, "
-                  f"oracle/ (NumPy {np.__version__} + SciPy + C SSD), {dt:.1f} s on 1 of {os.cpu_count()} host cores "
-                  f"({cpu_model()})",
-    }
+def _render_one(job):
+    wl, o, t = job
+    return wl.frame(o, t)
 
 
-def _cpu_worker(job):
-    """One host process of the parallel CPU baseline (spawned: it never touches the GPU).  Rebuilds its
-    inputs from the workload recipe, then tracks its block of points with the oracle."""
-    name, n_points, n_particles, n_frames, lo, hi = job
-    from glimpse_amd import workloads
-    from oracle import motion as omotion
-    from oracle import tracker as otracker
+def render_frames(wl, workers):
+    """All frames of the workload, [O] arrays (T, H, W) uint8.  The ground map of every camera is computed once
+    here; the frames are then rendered by forked workers (this runs before the process touches the GPU)."""
+    for o in range(wl.O):
+        wl.scene.ground_map(wl.cams[o])
+    jobs = [(wl, o, t) for o in range(wl.O) for t in range(wl.T)]
+    if workers > 1 and len(jobs) > 4:
+        import multiprocessing as mp
 
-    wl = workloads.Workload(name, n_frames=n_frames, n_points=n_points, n_particles=n_particles, shard=0, seed=0)
-    frames = [[wl.frame(o, t) for t in range(n_frames)] for o in range(wl.O)]
-    observers = [otracker.Observer(frames[o], np.tile(wl.cams[o], (n_frames, 1)), wl.sigmas[o]) for o in range(wl.O)]
-    matching = np.tile(np.arange(n_frames)[:, None], (1, wl.O))
-    models = []
-    for p in range(lo, hi):
-        q = wl.params[p]
-        models.append(omotion.CartesianMotion(xy=q[0:2], xy_sigma=q[2:4], vxyz=q[4:7], vxyz_sigma=q[7:10],
-                                              axyz=q[10:13], axyz_sigma=q[13:16], dem=q[16], dem_sigma=q[17], n=wl.N))
-    np.random.seed(100 + lo)
-    t0 = time.perf_counter()
-    otracker.track(models, observers, matching, np.ones(n_frames - 1), tile_size=wl.tile)
-    return time.perf_counter() - t0
-
-
-def cpu_baseline_parallel(wl, steps, per_point_seconds, target_seconds, workers):
-    """The reference's `parallel=True` (one process per block of tracks, tracker.py:381-387, helpers.py:2008-2017)
-    restated with the oracle: `workers` spawned processes, each tracking its own block of points."""
-    import multiprocessing as mp
-
-    per_worker = int(max(1, round(target_seconds / max(per_point_seconds, 1e-3))))
-    per_worker = min(per_worker, max(1, wl.P // workers))
-    jobs = [(wl.name, wl.P, wl.N, 1 + steps, w * per_worker, (w + 1) * per_worker) for w in range(workers)]
-    ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
-    with ctx.Pool(workers) as pool:
-        times = pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
-    busy = max(times)  # the tracking itself; `wall` also holds interpreter start-up and frame rendering
-    n_pts = workers * per_worker
-    return {
-        "value": n_pts * wl.N * steps / busy,
-        "unit": "particle-frames/s",
-        "cores": workers,
-        "kind": "port",
-        "sample": f"{workers} processes x {per_worker} points x {wl.N} particles x {steps} steps (oracle/, one block of "
-                  f"points per process like the reference's parallel=True); slowest process {busy:.1f} s, {wall:.1f} s "
-                  f"with start-up, of {os.cpu_count()} host cores",
-    }
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            flat = pool.map(_render_one, jobs, chunksize=1)
+    else:
+        flat = [_render_one(j) for j in jobs]
+    return [np.stack(flat[o * wl.T:(o + 1) * wl.T]) for o in range(wl.O)]
 
 
 def cpu_model():
@@ -200,45 +197,205 @@ def cpu_model():
     return "unknown CPU"
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = int(os.environ.get("GLH_BENCH_DEVICE", local_rank))  # test hook: several ranks on one GPU
-    use_nccl = args.dist_backend == "nccl"
-    dist = None
-    if world > 1 or os.environ.get("GLH_BENCH_FORCE_DIST") == "1":  # (test hook: the collective path with one rank)
-        import torch
-        import torch.distributed as dist
+def _oracle_models(wl, lo, hi):
+    from oracle import motion as omotion
 
-        if use_nccl:
-            torch.cuda.set_device(device)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    out = []
+    for p in range(lo, hi):
+        q = wl.params[p]
+        out.append(omotion.CartesianMotion(xy=q[0:2], xy_sigma=q[2:4], vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13],
+                                           axyz_sigma=q[13:16], dem=q[16], dem_sigma=q[17], n=wl.N))
+    return out
+
+
+def _oracle_track(wl, frames, lo, hi, n_frames, seed):
+    """The oracle (CPU restatement of the reference path) on points [lo, hi) over frames 0 .. n_frames-1 from the
+    prior: the same frame window as the GPU's timed region.  Returns seconds."""
+    from oracle import tracker as otracker
+
+    observers = [otracker.Observer(list(frames[o][:n_frames]), np.tile(wl.cams[o], (n_frames, 1)), wl.sigmas[o])
+                 for o in range(wl.O)]
+    matching = np.tile(np.arange(n_frames)[:, None], (1, wl.O))
+    np.random.seed(seed)
+    t0 = time.perf_counter()
+    otracker.track(_oracle_models(wl, lo, hi), observers, matching, np.ones(n_frames - 1), tile_size=wl.tile)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(wl, frames, n_frames, target_seconds):
+    """One host core, a bounded sample of the same workload: whole tracks (all `n_frames` frames from the prior)
+    of as many points as fit in the time budget."""
+    steps = n_frames - 1
+    per_point = _oracle_track(wl, frames, 0, 1, n_frames, 7)
+    n_pts = int(max(1, min(wl.P - 1, round(target_seconds / max(per_point, 1e-3)))))
+    first = 1 if wl.P > 1 else 0  # (a one-point workload, C1, times its only point again)
+    dt = _oracle_track(wl, frames, first, first + n_pts, n_frames, 8)
+    cpu_baseline.per_point_seconds = dt / n_pts
+    return {
+        "value": n_pts * wl.N * steps / dt,
+        "unit": "particle-frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_pts} of {wl.P} points x {wl.N} particles x {steps} steps from the prior (the GPU's frame window), "
+                  f"oracle/ (NumPy {np.__version__} + SciPy + C SSD), {dt:.1f} s on 1 of {os.cpu_count()} host cores "
+                  f"({cpu_model()})",
+    }
+
+
+def _cpu_worker(job):
+    """One host process of the parallel CPU baseline (spawned: it never touches the GPU)."""
+    name, n_points, n_particles, n_total_frames, n_frames, lo, hi, frame_files = job
+    from glimpse_amd import workloads
+
+    wl = workloads.Workload(name, n_frames=n_total_frames, n_points=n_points, n_particles=n_particles, shard=0, seed=0)
+    frames = [np.load(f, mmap_mode="r") for f in frame_files]
+    return _oracle_track(wl, frames, lo, hi, n_frames, 100 + lo)
+
+
+def cpu_baseline_parallel(wl, frames, n_frames, per_point_seconds, target_seconds, workers):
+    """The reference's `parallel=True` (one process per block of tracks, tracker.py:381-387, helpers.py:2008-2017)
+    restated with the oracle: `workers` spawned processes, each tracking its own block of points through the whole
+    frame window; the rendered frames reach them as memory-mapped files."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+
+    steps = n_frames - 1
+    per_worker = int(max(1, round(target_seconds / max(per_point_seconds, 1e-3))))
+    per_worker = min(per_worker, max(1, wl.P // workers))
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="glh_bench_frames_", dir=base)
+    try:
+        files = []
+        for o in range(wl.O):
+            files.append(os.path.join(tmp, f"frames_{o}.npy"))
+            np.save(files[-1], np.ascontiguousarray(frames[o][:n_frames]))
+        jobs = [(wl.name, wl.P, wl.N, wl.T, n_frames, w * per_worker, (w + 1) * per_worker, files) for w in range(workers)]
+        ctx = mp.get_context("spawn")
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            times = pool.map(_cpu_worker, jobs)
+        wall = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    busy = max(times)  # the tracking itself; `wall` also holds interpreter start-up
+    n_pts = workers * per_worker
+    return {
+        "value": n_pts * wl.N * steps / busy,
+        "unit": "particle-frames/s",
+        "cores": workers,
+        "kind": "port",
+        "sample": f"{workers} processes x {per_worker} points x {wl.N} particles x {steps} steps from the prior (oracle/, one "
+                  f"block of points per process like the reference's parallel=True); slowest process {busy:.1f} s, "
+                  f"{wall:.1f} s with start-up; os.cpu_count() = {os.cpu_count()}, usable = {usable_cores()}",
+    }
+
+
+def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
+    """The same sequence through the drop-in Python API, glimpse_amd.Tracker.track(rng="philox"): wall time of the
+    whole call (frame upload, the frame loop, per-frame status reads, result download) per frame update."""
+    import datetime
+
+    import glimpse_amd as g
+
+    t00 = time.perf_counter()
+    t_start = datetime.datetime(2020, 1, 1)
+    unit = datetime.timedelta(days=1)
+    observers = []
+    for o in range(wl.O):
+        v = wl.cams[o]
+        images = []
+        for t in range(n_frames):
+            cam = g.Camera(imgsz=v[6:8], f=v[8:10], c=v[10:12], k=v[12:18], p=v[18:20], xyz=v[0:3], viewdir=v[3:6])
+            images.append(g.Image(cam=cam, datetime=t_start + t * unit, array=np.asarray(frames[o][t])))
+        observers.append(g.Observer(images, sigma=wl.sigmas[o]))
+    models = []
+    for p in range(wl.P):
+        q = wl.params[p]
+        models.append(g.CartesianMotion(xy=q[0:2], time_unit=unit, dem=q[16], dem_sigma=q[17], n=wl.N, xy_sigma=q[2:4],
+                                        vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13], axyz_sigma=q[13:16]))
+    tracker = g.Tracker(observers, device=device, max_search_dim=max_search_dim)
+    t_setup = time.perf_counter() - t00
+    t0 = time.perf_counter()
+    tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
+    wall = time.perf_counter() - t0
+    ok = sum(e is None for e in tracks.errors)
+    finite = bool(np.isfinite(tracks.means[:, -1]).all())
+    if tracker._ctx is not None:
+        tracker._ctx.close()
+    return {"api_ms_per_step": 1e3 * wall / (n_frames - 1), "api_track_seconds": wall, "api_object_setup_seconds": t_setup,
+            "api_tracks_ok": ok, "api_last_means_finite": finite}
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def worker(args):
+    from glimpse_amd import _lib, sharding, workloads
+
+    group = sharding.Group.from_env()
+    rank, world = group.rank, group.world
+    if "WORLD_SIZE" in os.environ and args.gpus != world and args.gpus != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank))  # test hook: several ranks on one GPU
+
+    cfg = workloads.CONFIGS[args.workload]
+    W, B = max(0, args.warmup), max(0, args.burn_in)
+    if args.steps is None:
+        T = cfg["frames"]
+        K = T - 1 - B
+    else:
+        K = args.steps
+        T = 1 + B + K
+    if K < 1:
+        raise SystemExit("need at least one timed step")
+    W = min(W, T - 1)
+    strong = args.split == "strong"
+    if strong:
+        # the configuration's points (or --points of them) divided over the ranks: every rank builds the same
+        # point set and keeps its contiguous block
+        total = args.points if args.points is not None else cfg["points"]
+        lo, hi = sharding.shard_range(total, world, rank)
+        wl = workloads.Workload(args.workload, n_frames=T, n_points=total, n_particles=args.particles, shard=0, seed=0)
+        wl = wl.slice(lo, hi)
+        point_offset = lo
+        sizes = sharding.shard_sizes(total, world)
+    else:
+        wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
+                                seed=0)
+        point_offset = rank * wl.P
+        sizes = [wl.P] * world
+
+    # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files
+    cores = usable_cores()
+    if world == 1:
+        frames = render_frames(wl, cores)
+    else:
+        if rank == 0:
+            frames = render_frames(wl, cores)
+            for o in range(wl.O):
+                group.store.put_array(f"frames_{o}", frames[o])
         else:
-            dist.init_process_group("gloo")
-    from glimpse_amd import _lib, workloads
+            frames = [group.store.get_array(f"frames_{o}", mmap=True) for o in range(wl.O)]
 
-    K, W, B = args.steps, args.warmup, max(0, args.burn_in)
-    T = 1 + B + W + K
-    wl = workloads.Workload(args.workload, n_frames=T, n_points=args.points, n_particles=args.particles, shard=rank,
-                            seed=0)
-    frames = [wl.frames(o) for o in range(wl.O)]
     ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
                        max_frames=T)
     workloads.setup_context(ctx, wl, frames)
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
-    ctx.set_point_offset(rank * wl.P)
+    ctx.set_point_offset(point_offset)
+    transport = group.attach(ctx, args.transport)
     seed = args.seed
     images = lambda i: [i] * wl.O  # noqa: E731
 
-    # frame 0: initialise particles + templates (tracker.py:327-342), untimed
-    ctx.set_frame(0)
-    ctx.init_particles(seed=seed)
-    for o in range(wl.O):
-        ctx.init_templates(o, 0)
-    ctx.record_moments(0)
+    def initialise():
+        """frame 0: particles + templates (tracker.py:327-342), untimed"""
+        ctx.set_frame(0)
+        ctx.init_particles(seed=seed)
+        for o in range(wl.O):
+            ctx.init_templates(o, 0)
+        ctx.record_moments(0)
+
     F = K if args.frames_per_call <= 0 else min(args.frames_per_call, K)
 
     def run(first, count):
@@ -253,59 +410,34 @@ def main():
                 ctx.track(list(range(i, i + n)), [1.0] * n, [images(j) for j in range(i, i + n)], seed=seed)
             i += n
 
-    run(1, B)  # burn-in, untimed
-    run(1 + B, W)  # warm-up, untimed
+    def gather():
+        return group.gather_moments(ctx, 0, T, sizes)
+
+    initialise()
+    run(1, W)  # warm-up: the first W updates of the same sequence, untimed
+    if world > 1:
+        gather()  # warm the communicator up outside the timed region
     ctx.sync()
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            import torch
-
-            dist.barrier()
-            if use_nccl:
-                torch.cuda.synchronize()
-
-    gather_list = None
-    mom = None
-
-    def gather_moments():
-        """The one collective of a sequence: every rank's posterior moments [T][P][12] to rank 0."""
-        import torch
-
-        nonlocal gather_list, mom
-        if use_nccl:
-            if mom is None:  # zero-copy view of the library-owned history buffer
-                ptr, nbytes = ctx.moments_device()
-                mom = torch.as_tensor(DevArray(ptr, (T, wl.P, 12)), device=f"cuda:{device}")
-            send = mom
-        else:
-            send = torch.from_numpy(ctx.get_moments(0, T))
-        if rank == 0 and gather_list is None:
-            gather_list = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list, dst=0)
-
-    if dist is not None:
-        gather_moments()  # warm the communicator up outside the timed region
+    initialise()  # back to the prior (untimed)
+    run(1, B)  # burn-in, untimed
+    ctx.sync()
 
     # HIP events around every kernel launch on the context's stream, over the timed region itself
     ctx.profile_enable(True)
     ctx.profile_reset()
-    barrier()
+    group.barrier()
     t0 = time.perf_counter()
-    run(1 + B + W, K)
-    if dist is not None:
+    run(1 + B, K)
+    gathered = None
+    if world > 1:
         ctx.sync()
-        gather_moments()
-    barrier()
+        gathered = gather()
+    group.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], device=f"cuda:{device}" if use_nccl else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max(elapsed)
     stage_ms = ctx.profile_get()
+    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+    launch_ms = ctx.profile_launches(dom)
     ctx.profile_enable(False)
 
     # health of the run: every point must still be tracked by every observer
@@ -313,20 +445,25 @@ def main():
     pt_status = ctx.point_status()
     frac_ok = float((status == 0).mean())
     n_err = int((pt_status != 0).sum())
-    # algorithmic bytes / SSD flops of one step, from the search boxes of the last timed step
+    # algorithmic bytes / SSD flops of one step, from the search boxes of the last timed step (the smallest tiles
+    # of the sequence: the tile term, ~4 % of the bytes, is if anything understated for the first frames)
     boxes = ctx.search_boxes()
     abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
     flops = ssd_flops_per_step(wl.O, wl.tile, boxes, status)
+    moments_local = ctx.get_moments(0, T)
 
     gathered_ok = None
-    if dist is not None and rank == 0:
-        # every shard's moments arrived and are finite for the timed frames
-        import torch
-
-        allm = torch.stack([g.cpu() for g in gather_list])  # (world, T, P, 12)
-        gathered_ok = bool(torch.isfinite(allm[:, 1 + B + W:1 + B + W + K]).all())
+    if world > 1 and rank == 0:
+        allm, allst = gathered
+        gathered_ok = bool(allm.shape == (T, sum(sizes), 12) and np.isfinite(allm[1 + B:1 + B + K]).all()
+                           and np.array_equal(allm[:, :wl.P], moments_local))
+        n_err = int((allst != 0).sum())
+    rc = 0
+    if rank == 0 and args.dump_moments:
+        np.save(args.dump_moments, gathered[0] if world > 1 else moments_local)
     if rank == 0:
-        value = world * wl.P * wl.N * K / elapsed
+        total_points = sum(sizes)
+        value = total_points * wl.N * K / elapsed
         out = {
             "metric": "particle-frames/s",
             "value": value,
@@ -336,43 +473,79 @@ def main():
             "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
-                           frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F),
+                           total_points=total_points, frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F,
+                           timed_from="the prior (frame 0 initialises, every later frame is a timed step)" if B == 0
+                           else f"after {B} untimed updates"),
+            "rccl_ranks": world if transport == "rccl" else 0,
+            "collective": {"none": "none (1 rank)", "rccl": "RCCL ncclSend/ncclRecv gather inside libglimpse_hip.so",
+                           "host": "host copies through the rendezvous directory (RCCL unavailable: "
+                                   + getattr(group, "why_host", "") + ")"}[transport],
             "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err,
-                       "gathered_moments_finite": gathered_ok},
+                       "gathered_moments_finite": gathered_ok,
+                       "final_means_finite": bool(np.isfinite(moments_local[B + K]).all())},
         }
         tot = sum(ms for ms, _ in stage_ms.values())
-        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
         dom_ms, dom_n = stage_ms[dom]
         per_launch_ms = dom_ms / max(dom_n, 1)
         launches_per_step = dom_n / K
         # one launch of the dominant kernel processes P*N particle-frames (SURVEY 8(d) per-unit bytes)
         ach = abytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9
-        roof = {"kernel": KERNEL_OF_STAGE.get(dom, dom), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, KERNEL_OF_STAGE.get(dom, dom)),
+        kern = KERNEL_OF_STAGE.get(dom, dom)
+        roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern),
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": abytes / launches_per_step,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
                 "ssd_fp32_tflops": flops / (tot / K * 1e-3) / 1e12,
-                # the measured device-copy ceiling of this GPU beside the 8 TB/s spec
+                # what a float4 copy kernel reaches on this chip (MI355X_MICROARCH.md), and this GPU's own
+                # hipMemcpyDtoD rate ("a measured device-copy ceiling")
+                "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
-        roof["frac_of_measured_copy"] = ach / roof["measured_copy_GBps"]
         out["roofline"] = roof
         out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, frames, min(K, 4), args.cpu_seconds)
-            if args.cpu_workers > 1:
+        if len(launch_ms) == dom_n and launches_per_step == 1:
+            tail = launch_ms[-min(20, K):]
+            out["steady_ms_per_step"] = float(tail.mean())
+            out["steady_value"] = wl.P * wl.N / (float(tail.mean()) * 1e-3) * world
+            out["steady_roofline_frac"] = abytes / (float(tail.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:8]]
+    group_ok = True
+    ctx_closed = False
+    if rank == 0 and world == 1:
+        if not args.no_api:
+            ctx.close()
+            ctx_closed = True
+            out.update(api_leg(wl, frames, T, seed, device, args.max_search_dim))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, frames, T, args.cpu_seconds)
+            workers = args.cpu_workers if args.cpu_workers > 0 else usable_cores()
+            if workers > 1 and wl.P >= 2 * workers:
                 out["cpu_baseline_parallel"] = cpu_baseline_parallel(
-                    wl, min(K, 4), cpu_baseline.per_point_seconds, args.cpu_seconds, args.cpu_workers)
+                    wl, frames, T, cpu_baseline.per_point_seconds, args.cpu_seconds, workers)
+    if rank == 0:
+        h = out["health"]
+        if h["points_with_error_bits"] or h["observer_ok_fraction"] < 0.99 or not h["final_means_finite"] \
+                or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False:
+            rc = 3
+            out["health"]["verdict"] = "UNHEALTHY"
         print(json.dumps(out), flush=True)
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
+    if not ctx_closed:
+        ctx.close()
+    return rc if group_ok else 4
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -23,6 +23,7 @@ PT_RASTER_OOB, PT_NOT_VISIBLE = 32, 64
 RASTER_DEM, RASTER_DEM_SIGMA, RASTER_VIEWSHED = 0, 1, 2
 OBS_OK, OBS_SKIPPED, OBS_OUT_OF_BOUNDS, OBS_TILE_TOO_LARGE, OBS_NO_TEMPLATE = 0, 1, 2, 3, 4
 NO_ERROR_FRAME = 0x7F7F7F7F
+COMM_ID_BYTES = 128
 
 
 class GlhError(RuntimeError):
@@ -105,6 +106,13 @@ SIGNATURES = {
     "glh_stage_count": (_I, []),
     "glh_stage_name": (C.c_char_p, [_I]),
     "glh_profile_get": (_I, [_P, _P, _P]),
+    "glh_profile_get_launches": (_I, [_P, _I, _P, _I, _P]),
+    "glh_comm_unique_id": (_I, [_P]),
+    "glh_comm_init": (_I, [_P, _P, _I, _I]),
+    "glh_comm_destroy": (_I, [_P]),
+    "glh_comm_barrier": (_I, [_P]),
+    "glh_comm_max_f64": (_I, [_P, _P]),
+    "glh_gather_moments": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "glh_measure_copy_bandwidth": (_I, [_P, _U64, _I, _P]),
     "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
     "glh_stage_project_directions": (_I, [_I, _P, _P, _I, _P]),
@@ -163,6 +171,13 @@ def device_count():
     return n.value
 
 
+def comm_unique_id():
+    """128-byte RCCL communicator id (ncclGetUniqueId): made by one rank, handed to the others."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(load().glh_comm_unique_id(buf))
+    return buf.raw
+
+
 def stage_names():
     lib = load()
     return [lib.glh_stage_name(i).decode() for i in range(lib.glh_stage_count())]
@@ -181,7 +196,9 @@ class Context:
         self.O = n_observers
         self.P = self.N = 0
         self.tile = (0, 0)
+        self.rank, self.world = 0, 1
         self._keep = []  # device-borrowed frame owners
+        self._frame_shape = {}  # observer -> (height, width, channels) the library copies per frame
 
     def close(self):
         if getattr(self, "handle", None):
@@ -199,6 +216,18 @@ class Context:
     # ---- observers
     def observer_init(self, obs, n_images, width, height, channels, sigma):
         check(self.lib.glh_observer_init(self.handle, obs, n_images, width, height, channels, float(sigma)))
+        self._frame_shape[obs] = (int(height), int(width), int(channels))
+
+    def _frame(self, obs, pixels):
+        """The C side copies width * height * channels bytes: refuse anything that is not exactly that."""
+        a = np.asarray(pixels)
+        if a.dtype != np.uint8:
+            raise TypeError(f"frames are uint8 (got {a.dtype}); the library never casts pixel data")
+        h, w, ch = self._frame_shape[obs]
+        want = (h, w) if ch == 1 else (h, w, ch)
+        if a.shape != want and not (ch == 1 and a.shape == (h, w, 1)):
+            raise ValueError(f"observer {obs}: frame shape {a.shape} != {want} declared by observer_init")
+        return np.ascontiguousarray(a)
 
     def observer_set_cameras(self, obs, cams, first=0):
         cams = _arr(cams, np.float64)
@@ -206,12 +235,12 @@ class Context:
         check(self.lib.glh_observer_set_cameras(self.handle, obs, first, len(cams), _ptr(cams)))
 
     def observer_upload_frame(self, obs, image, pixels):
-        pixels = _arr(pixels, np.uint8)
+        pixels = self._frame(obs, pixels)
         check(self.lib.glh_observer_upload_frame(self.handle, obs, image, _ptr(pixels)))
 
     def observer_upload_frame_async(self, obs, image, pixels):
         """Upload without waiting for the device; `pixels` may be reused as soon as the call returns."""
-        pixels = _arr(pixels, np.uint8)
+        pixels = self._frame(obs, pixels)
         check(self.lib.glh_observer_upload_frame_async(self.handle, obs, image, _ptr(pixels)))
 
     def observer_set_frame_device(self, obs, image, dev_ptr, owner=None):
@@ -453,6 +482,55 @@ class Context:
         launches = np.zeros(n, dtype=np.int64)
         check(self.lib.glh_profile_get(self.handle, _ptr(ms), _ptr(launches)))
         return {name: (float(ms[i]), int(launches[i])) for i, name in enumerate(stage_names())}
+
+    def profile_launches(self, stage):
+        """Duration (ms) of every timed launch of `stage` (a name of stage_names()) since the last reset."""
+        k = stage_names().index(stage)
+        n = C.c_int(0)
+        check(self.lib.glh_profile_get_launches(self.handle, k, None, 0, C.byref(n)))
+        out = np.zeros(n.value)
+        if n.value:
+            check(self.lib.glh_profile_get_launches(self.handle, k, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    # ---- multi-GPU (RCCL behind the C ABI; glimpse_amd/sharding.py drives it)
+    def comm_init(self, comm_id, rank, world):
+        """Join the communicator made by `comm_unique_id()` on one rank (collective)."""
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError(f"comm_id must be {COMM_ID_BYTES} bytes")
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        check(self.lib.glh_comm_init(self.handle, buf, int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        check(self.lib.glh_comm_destroy(self.handle))
+
+    def comm_barrier(self):
+        check(self.lib.glh_comm_barrier(self.handle))
+
+    def comm_max(self, value):
+        v = C.c_double(float(value))
+        check(self.lib.glh_comm_max_f64(self.handle, C.byref(v)))
+        return v.value
+
+    def gather_moments(self, frame0, n_frames, points_per_rank, root=0):
+        """One RCCL exchange: on `root` returns (moments (n_frames, sum P, 12) in rank order, status (sum P,));
+        None elsewhere."""
+        ppr = np.ascontiguousarray(points_per_rank, dtype=np.int32)
+        if ppr.shape != (self.world,):
+            raise ValueError("points_per_rank must have one entry per rank")
+        if self.rank != root:
+            check(self.lib.glh_gather_moments(self.handle, root, frame0, n_frames, _ptr(ppr), None, None))
+            return None
+        total = int(ppr.sum())
+        flat = np.empty(total * n_frames * 12)
+        status = np.empty(total, dtype=np.uint32)
+        check(self.lib.glh_gather_moments(self.handle, root, frame0, n_frames, _ptr(ppr), _ptr(flat), _ptr(status)))
+        blocks, at = [], 0
+        for pr in ppr:
+            blocks.append(flat[at: at + pr * n_frames * 12].reshape(n_frames, pr, 12))
+            at += pr * n_frames * 12
+        return np.concatenate(blocks, axis=1), status
 
 
 # ---- stateless stage hooks (parity tests) -----------------------------------------------

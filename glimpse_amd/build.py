@@ -22,6 +22,7 @@ DEPS = [
     os.path.join(HERE, "csrc", "glh_math.h"),
     os.path.join(HERE, "csrc", "glh_median.h"),
     os.path.join(HERE, "csrc", "glh_host.h"),
+    os.path.join(HERE, "csrc", "glh_comm.h"),
     os.path.join(os.path.dirname(HERE), "include", "glimpse_hip.h"),
 ]
 FLAGS = [

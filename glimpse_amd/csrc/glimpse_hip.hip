@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/glimpse_hip.h"
+#include "glh_comm.h"
 #include "glh_host.h"
 #include "glh_kernels.h"
 #include "glh_point.h"
@@ -147,6 +148,9 @@ struct glh_ctx {
   std::vector<hipEvent_t> pool;
   double ms[ST_COUNT] = {0};
   int64_t launches[ST_COUNT] = {0};
+  std::vector<float> launch_ms[ST_COUNT];  // duration of every timed launch since the last reset (bounded)
+  // multi-GPU (glh_comm.h)
+  Comm* comm = nullptr;
 };
 
 template <typename T>
@@ -197,7 +201,10 @@ static int drain_profile(glh_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto& e : c->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) c->ms[e.stage] += ms;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->ms[e.stage] += ms;
+      if (c->launch_ms[e.stage].size() < (1u << 16)) c->launch_ms[e.stage].push_back(ms);
+    }
     c->pool.push_back(e.a);
     c->pool.push_back(e.b);
   }
@@ -223,6 +230,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   if (!c) return GLH_OK;
   (void)hipSetDevice(c->cfg.device_id);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)glh_comm_destroy(c);
   for (auto& e : c->pending) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -269,6 +277,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   if (k.max_frames <= 0) k.max_frames = 128;
   if (k.max_points <= 0 || k.max_particles <= 0 || k.n_observers <= 0 || k.n_observers > MAX_OBS)
     return fail(GLH_E_INVALID, "max_points/max_particles must be > 0 and 1 <= n_observers <= %d", MAX_OBS);
+  if (k.max_points > 65535)  // the staged kernels put the point index in gridDim.y
+    return fail(GLH_E_UNSUPPORTED, "max_points %d exceeds 65535 points per context: shard the points", k.max_points);
   if (k.max_tile < 5 || k.max_tile > 127) return fail(GLH_E_INVALID, "max_tile must be in [5, 127]");
   if (k.max_search_dim < k.max_tile + 3 || k.max_search_dim > 2000)
     return fail(GLH_E_INVALID, "max_search_dim must be in [max_tile + 3, 2000]");
@@ -554,6 +564,11 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   size_t nm = (size_t)c->cfg.max_frames * P * 12;
   hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->moments, nm, (double)NAN);
   HIPCHK(hipGetLastError());
+  if (c->covariances) {  // a reused context must not return the previous sequence's covariances
+    hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->covariances,
+                       (size_t)c->cfg.max_frames * c->cfg.max_points * 36, (double)NAN);
+    HIPCHK(hipGetLastError());
+  }
   // NumPy pairwise-sum plan for this N
   PairwisePlan pl;
   pairwise_plan(N, pl);
@@ -970,7 +985,12 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
 static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
   const int O = c->cfg.n_observers;
   for (int o = 0; o < O; ++o) {
-    if (images[o] < 0) continue;
+    if (images[o] < 0) {
+      // no image for this observer at this frame (tracker.py:577): the status must not keep the previous frame's
+      HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->obs_status + (size_t)o * c->P), GLH_OBS_SKIPPED, (size_t)c->P,
+                               c->stream));
+      continue;
+    }
     TilePrepArgs tp{};
     tp.active = c->have_active ? c->active : nullptr;
     tp.obs_mask = c->have_mask ? c->obs_mask : nullptr;
@@ -1542,6 +1562,7 @@ extern "C" int glh_profile_reset(glh_ctx* c) {
   for (int i = 0; i < ST_COUNT; ++i) {
     c->ms[i] = 0;
     c->launches[i] = 0;
+    c->launch_ms[i].clear();
   }
   return GLH_OK;
 }
@@ -1552,6 +1573,176 @@ extern "C" int glh_profile_get(glh_ctx* c, double* ms, int64_t* launches) {
     if (ms) ms[i] = c->ms[i];
     if (launches) launches[i] = c->launches[i];
   }
+  return GLH_OK;
+}
+
+extern "C" int glh_profile_get_launches(glh_ctx* c, int stage, double* ms, int cap, int* n) {
+  if (!c || !n || stage < 0 || stage >= ST_COUNT || cap < 0 || (cap > 0 && !ms))
+    return fail(GLH_E_INVALID, "bad argument");
+  CHK(drain_profile(c));
+  const auto& v = c->launch_ms[stage];
+  *n = (int)v.size();
+  for (int i = 0; i < cap && i < (int)v.size(); ++i) ms[i] = (double)v[i];
+  return GLH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU: one process per GPU, one gather at the end of a sequence (glh_comm.h)
+// ------------------------------------------------------------------------------------------
+#define NCCLCHK(api, expr)                                                                         \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return fail(GLH_E_COMM, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int glh_comm_unique_id(char* id) {
+  if (!id) return fail(GLH_E_INVALID, "id is null");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(GLH_E_COMM, "%s", rccl_load_error());
+  static_assert(GLH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id is RCCL's ncclUniqueId");
+  ncclUniqueId u;
+  NCCLCHK(api, api->GetUniqueId(&u));
+  memcpy(id, u.internal, GLH_COMM_ID_BYTES);
+  return GLH_OK;
+}
+
+static int comm_free(glh_ctx* c) {
+  if (!c->comm) return GLH_OK;
+  Comm* k = c->comm;
+  c->comm = nullptr;
+  (void)hipSetDevice(c->cfg.device_id);
+  (void)hipStreamSynchronize(c->stream);
+  RcclApi* api = rccl_api();
+  if (k->comm && api) (void)api->CommDestroy(k->comm);
+  dfree(k->stage);
+  dfree(k->scalar);
+  delete k;
+  return GLH_OK;
+}
+
+extern "C" int glh_comm_destroy(glh_ctx* c) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  return comm_free(c);
+}
+
+extern "C" int glh_comm_init(glh_ctx* c, const char* id, int rank, int world) {
+  if (!c || !id) return fail(GLH_E_INVALID, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(GLH_E_INVALID, "need 0 <= rank < world (got %d, %d)", rank, world);
+  RcclApi* api = rccl_api();
+  if (!api) return fail(GLH_E_COMM, "%s", rccl_load_error());
+  CHK(comm_free(c));
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  Comm* k = new (std::nothrow) Comm();
+  if (!k) return fail(GLH_E_NOMEM, "out of host memory");
+  k->rank = rank;
+  k->world = world;
+  ncclUniqueId u;
+  memcpy(u.internal, id, GLH_COMM_ID_BYTES);
+  ncclResult_t r = api->CommInitRank(&k->comm, world, u, rank);
+  if (r != ncclSuccess) {
+    delete k;
+    return fail(GLH_E_COMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, c->cfg.device_id,
+                api->GetErrorString(r));
+  }
+  if (dalloc(&k->scalar, 2) != GLH_OK) {
+    (void)api->CommDestroy(k->comm);
+    delete k;
+    return GLH_E_NOMEM;
+  }
+  c->comm = k;
+  return GLH_OK;
+}
+
+static int need_comm(glh_ctx* c) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (!c->comm) return fail(GLH_E_STATE, "glh_comm_init has not been called");
+  return GLH_OK;
+}
+
+// max over the ranks of one host double (the bench's max-over-ranks wall time); doubles as a barrier: it
+// returns once every rank's stream has reached the reduction
+extern "C" int glh_comm_max_f64(glh_ctx* c, double* value) {
+  CHK(need_comm(c));
+  if (!value) return fail(GLH_E_INVALID, "value is null");
+  RcclApi* api = rccl_api();
+  Comm* k = c->comm;
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  HIPCHK(hipMemcpyAsync(k->scalar, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(api, api->AllReduce(k->scalar, k->scalar + 1, 1, ncclDouble, ncclMax, k->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(value, k->scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return GLH_OK;
+}
+
+extern "C" int glh_comm_barrier(glh_ctx* c) {
+  double v = 0.0;
+  CHK(join_uploads(c));
+  return glh_comm_max_f64(c, &v);
+}
+
+// Gather of the posterior moments (and the per-point status words) to rank `root`:
+//   every rank sends frames [frame0, frame0 + n_frames) of its moments history, a contiguous block of
+//   n_frames * P_rank * 12 doubles, and its P_rank status words; the root receives the blocks rank after rank,
+//   out = | rank 0: [n_frames][P_0][12] | rank 1: [n_frames][P_1][12] | ... (doubles), status = | P_0 | P_1 | ...
+// One ncclGroup of sends / receives on the context's stream (the root's own block goes through the same
+// send / receive pair); the root then downloads to the host buffers.  points_per_rank [world].
+extern "C" int glh_gather_moments(glh_ctx* c, int root, int frame0, int n_frames, const int32_t* points_per_rank,
+                                  double* out, uint32_t* status) {
+  CHK(need_comm(c));
+  CHK(need_seq(c));
+  Comm* k = c->comm;
+  RcclApi* api = rccl_api();
+  if (root < 0 || root >= k->world || !points_per_rank) return fail(GLH_E_INVALID, "bad root / points_per_rank");
+  if (frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames) return fail(GLH_E_INVALID, "bad frame range");
+  if (points_per_rank[k->rank] != c->P)
+    return fail(GLH_E_INVALID, "points_per_rank[%d] = %d, but this context tracks %d points", k->rank,
+                points_per_rank[k->rank], c->P);
+  const bool is_root = k->rank == root;
+  if (is_root && !out) return fail(GLH_E_INVALID, "the root needs an output buffer");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  size_t total_pts = 0;
+  for (int r = 0; r < k->world; ++r) {
+    if (points_per_rank[r] < 0) return fail(GLH_E_INVALID, "points_per_rank[%d] < 0", r);
+    total_pts += (size_t)points_per_rank[r];
+  }
+  const size_t mom_doubles = total_pts * (size_t)n_frames * 12;
+  const size_t st_off = (mom_doubles * 8 + 15) & ~(size_t)15;  // bytes
+  if (is_root) {
+    const size_t need = st_off + total_pts * 4;
+    if (k->stage_bytes < need) {
+      dfree(k->stage);
+      k->stage_bytes = 0;
+      CHK(dalloc((uint8_t**)&k->stage, need));
+      k->stage_bytes = need;
+    }
+  }
+  const double* mine = c->moments + (size_t)frame0 * c->P * 12;
+  NCCLCHK(api, api->GroupStart());
+  ncclResult_t r1 = api->Send(mine, (size_t)n_frames * c->P * 12, ncclDouble, root, k->comm, c->stream);
+  ncclResult_t r2 = api->Send(c->pt_status, (size_t)c->P, ncclUint32, root, k->comm, c->stream);
+  ncclResult_t r3 = ncclSuccess;
+  if (is_root) {
+    double* dst = k->stage;
+    uint32_t* sdst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(k->stage) + st_off);
+    for (int r = 0; r < k->world && r3 == ncclSuccess; ++r) {
+      const size_t pr = (size_t)points_per_rank[r];
+      r3 = api->Recv(dst, pr * n_frames * 12, ncclDouble, r, k->comm, c->stream);
+      if (r3 == ncclSuccess) r3 = api->Recv(sdst, pr, ncclUint32, r, k->comm, c->stream);
+      dst += pr * n_frames * 12;
+      sdst += pr;
+    }
+  }
+  ncclResult_t r4 = api->GroupEnd();
+  for (ncclResult_t r : {r1, r2, r3, r4})
+    if (r != ncclSuccess) return fail(GLH_E_COMM, "moments gather failed: %s", api->GetErrorString(r));
+  if (is_root) {
+    HIPCHK(hipMemcpyAsync(out, k->stage, mom_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+    if (status)
+      HIPCHK(hipMemcpyAsync(status, reinterpret_cast<uint8_t*>(k->stage) + st_off, total_pts * 4, hipMemcpyDeviceToHost,
+                            c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
   return GLH_OK;
 }
 

@@ -73,6 +73,9 @@ class Workload:
         foot = self.cams[-1] if self.O == 2 else cam0
         self.scene = synth.default_scene(foot, seed=seed, velocity=VELOCITY, n_frames=self.T, margin=30.0)
         border = 0.5 * max(self.tile) + 110.0 if min(self.imgsz) >= 1024 else 0.5 * max(self.tile) + 60.0
+        # the scene drifts 1.5 px per frame: long sequences keep their points further from the image border, so that
+        # the last frame's search boxes are still inside the image
+        border += 10.0 * max(abs(VELOCITY[0]), abs(VELOCITY[1])) * max(0, self.T - 32)
         if self.O == 2:
             border += 200.0  # keep the points inside the oblique view too
         # different shards track different points of the same scene
@@ -97,6 +100,15 @@ class Workload:
                 raise ValueError(f"only {ok.sum()} of {want} points are visible in both cameras")
             self.xy = cand[ok][:want]
         self.params = motion_params(self.xy, dem_sigma=self.dem_sigma)
+
+    def slice(self, lo, hi):
+        """The same workload restricted to points [lo, hi) (a shard of a strong split)."""
+        sub = Workload.__new__(Workload)
+        sub.__dict__.update(self.__dict__)
+        sub.P = hi - lo
+        sub.xy = self.xy[lo:hi]
+        sub.params = self.params[lo:hi]
+        return sub
 
     def frame(self, obs, t):
         return self.scene.render(self.cams[obs], float(t))

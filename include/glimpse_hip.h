@@ -39,6 +39,7 @@ extern "C" {
 #define GLH_E_NOMEM (-3)     /* host or device allocation failed                          */
 #define GLH_E_STATE (-4)     /* call sequence error (e.g. step before templates)          */
 #define GLH_E_UNSUPPORTED (-5)
+#define GLH_E_COMM (-6)      /* librccl missing, or an RCCL call failed                   */
 
 /* ---- camera vector ------------------------------------------------------------------ */
 /* [0:3] xyz  [3:6] viewdir(deg)  [6:8] imgsz  [8:10] f  [10:12] c  [12:18] k1..k6
@@ -278,9 +279,38 @@ int glh_profile_reset(glh_ctx* ctx);
 int glh_stage_count(void);
 const char* glh_stage_name(int stage);
 int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /* [stages] */);
+/* Duration (ms) of every timed launch of `stage` since the last reset, in launch order: up to `cap` values
+ * into ms, *n = how many there are (the first frames after the wide prior run longer than the steady state). */
+int glh_profile_get_launches(glh_ctx* ctx, int stage, double* ms, int cap, int* n);
 /* Measured device-copy ceiling of this GPU: `iters` device-to-device copies of `bytes`
  * bytes on the context's stream between two HIP events; *gbps = bytes read + bytes written per second / 1e9. */
 int glh_measure_copy_bandwidth(glh_ctx* ctx, uint64_t bytes, int iters, double* gbps);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
+ * The reference's one parallel seam is a map over tracks (track/tracker.py:381-387,
+ * `config.backend(np=parallel)`, helpers.py:2008-2017): tracks are independent, so here every process owns
+ * one GPU, one context and a contiguous block of the tracked points (glh_set_point_offset), nothing is
+ * exchanged while a sequence runs, and at its end the per-point posterior moments are collected on one rank.
+ * librccl is loaded on the first of these calls (dlopen), never by a single-GPU user.                  */
+#define GLH_COMM_ID_BYTES 128
+/* One rank (the root) makes the communicator id (ncclGetUniqueId) and hands its 128 bytes to the others by
+ * whatever the launcher offers (glimpse_amd/sharding.py: a file store under MASTER_PORT).               */
+int glh_comm_unique_id(char* id /* [GLH_COMM_ID_BYTES] */);
+/* Join the communicator as `rank` of `world` on the context's device and stream (ncclCommInitRank:
+ * collective, every rank calls it).                                                                    */
+int glh_comm_init(glh_ctx* ctx, const char* id, int rank, int world);
+int glh_comm_destroy(glh_ctx* ctx);
+/* Every rank's stream has reached this point (an all-reduce of one word, then a stream sync).            */
+int glh_comm_barrier(glh_ctx* ctx);
+/* *value = max over the ranks of *value (host double; wall-clock maxima of a timed region).              */
+int glh_comm_max_f64(glh_ctx* ctx, double* value);
+/* The one collective of a sequence: frames [frame0, frame0 + n_frames) of every rank's moments history
+ * ([n_frames][P_rank][12], what `process` returns per track, tracker.py:370-373) and its per-point status
+ * words to rank `root`, as ONE group of ncclSend / ncclRecv on the context's stream.  points_per_rank
+ * [world]; on the root `out` receives | rank 0: [n_frames][P_0][12] | rank 1: ... | and `status` (or NULL)
+ * | P_0 | P_1 | ... |; other ranks pass NULL.  Blocks until the exchange is over.                        */
+int glh_gather_moments(glh_ctx* ctx, int root, int frame0, int n_frames, const int32_t* points_per_rank,
+                       double* out, uint32_t* status);
 
 /* ---- stage-level test hooks (stateless; each runs one kernel on explicit inputs) -------- */
 /* Camera.xyz_to_uv (camera.py:591-628): xyz [n][3] -> uv [n][2].                            */

@@ -1,7 +1,7 @@
-"""Zero-copy hand-off of the library-owned moments history to torch (what bench.py gives RCCL).
+"""Zero-copy hand-off of the library-owned moments history to torch (for callers that issue their own collective).
 
 Runs in a fresh interpreter: torch bundles its own HIP runtime and must be imported BEFORE
-libglimpse_hip.so is loaded (bench.py does exactly that for N > 1); inside the shared pytest process
+libglimpse_hip.so is loaded (a torch job would have done exactly that); inside the shared pytest process
 other tests have already loaded the library."""
 import os
 import subprocess
@@ -18,8 +18,7 @@ import sys
 sys.path.insert(0, {root!r})
 import torch                      # first: see the module docstring
 import numpy as np
-import bench
-from glimpse_amd import _lib, workloads
+from glimpse_amd import _lib, sharding, workloads
 
 T, P, N = 3, 4, 600
 wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
@@ -35,7 +34,7 @@ with _lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
     ctx.sync()
     ptr, nbytes = ctx.moments_device()
     assert nbytes == T * P * 12 * 8
-    view = torch.as_tensor(bench.DevArray(ptr, (T, P, 12)), device="cuda:0")
+    view = torch.as_tensor(sharding.DeviceArray(ptr, (T, P, 12)), device="cuda:0")
     assert view.dtype == torch.float64 and view.data_ptr() == ptr and view.is_contiguous()
     want = ctx.get_moments(0, T)
     np.testing.assert_array_equal(view.cpu().numpy(), want)

@@ -1,0 +1,86 @@
+"""The multi-GPU path on one GPU: the RCCL communicator behind the C ABI (one rank: its send / receive pair goes
+through the same grouped exchange), and `bench.py --gpus 2` with both ranks on device 0 (the launcher, the frame
+hand-over, point offsets, the end-of-sequence gather).  RCCL refuses two ranks on one device, so the two-rank run
+uses the host transport -- the RCCL exchange itself is what the one-rank test runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small_context(lib, workloads, P=6, N=512, T=4, offset=0):
+    wl = workloads.Workload("C1", n_frames=T, n_points=P, n_particles=N, imgsz=(256, 256), shard=0)
+    frames = [wl.frames(0)]
+    ctx = lib.Context(P, N, 1, max_search_dim=128, max_frames=T)
+    workloads.setup_context(ctx, wl, frames)
+    ctx.set_point_offset(offset)
+    ctx.set_frame(0)
+    ctx.init_particles(seed=5)
+    ctx.init_templates(0, 0)
+    ctx.record_moments(0)
+    ctx.track(list(range(1, T)), [1.0] * (T - 1), [[i] for i in range(1, T)], seed=5)
+    return ctx, T
+
+
+def test_rccl_communicator_one_rank():
+    """glh_comm_unique_id / glh_comm_init / barrier / max / glh_gather_moments on a world of one."""
+    from glimpse_amd import _lib as lib
+    from glimpse_amd import sharding, workloads
+
+    ctx, T = _small_context(lib, workloads)
+    try:
+        group = sharding.Group(0, 1, 0, None)
+        assert group.attach(ctx, "rccl") == "rccl"
+        group.barrier()
+        assert group.max(3.25) == 3.25
+        mom, status = group.gather_moments(ctx, 0, T, [ctx.P])
+        np.testing.assert_array_equal(mom, ctx.get_moments(0, T))
+        np.testing.assert_array_equal(status, ctx.point_status())
+        # a sub-range of the frames
+        mom2, _ = group.gather_moments(ctx, 1, 2, [ctx.P])
+        np.testing.assert_array_equal(mom2, ctx.get_moments(1, 2))
+        with pytest.raises(lib.GlhError):
+            ctx.gather_moments(0, T, [ctx.P + 1])
+        group.close()
+    finally:
+        ctx.close()
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ, GLH_BENCH_DEVICE="0", **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+    """`--gpus 2` starts two ranks; with `--split strong` they track the two halves of the points that one rank
+    tracks alone, so the gathered posterior history must be the single-rank one (the device RNG is keyed on the
+    global point index)."""
+    common = ["--workload", "C2", "--points", "16", "--particles", "600", "--steps", "3", "--warmup", "1",
+              "--no-cpu-baseline", "--no-api", "--split", "strong"]
+    two = _bench(["--gpus", "2", "--transport", "host", "--dump-moments", str(tmp_path / "two.npy")] + common)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["health"]["gathered_moments_finite"] is True
+    assert two["health"]["points_with_error_bits"] == 0
+    assert two["config"]["total_points"] == 16 and two["config"]["points_per_gpu"] == 8
+    assert "host copies" in two["collective"]
+    one = _bench(["--gpus", "1", "--dump-moments", str(tmp_path / "one.npy")] + common)
+    assert one["n_gpus"] == 1 and one["config"]["total_points"] == 16
+    assert one["roofline"]["kernel"] == "k_point_step" and one["steps"] == 3
+    assert one["health"]["final_means_finite"]
+    m1, m2 = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert m1.shape == (4, 16, 12)
+    np.testing.assert_array_equal(m1, m2)

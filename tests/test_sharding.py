@@ -80,3 +80,99 @@ def test_gather_points_world2_gloo(tmp_path):
     for rc, out, err in outs:
         assert rc == 0, err[-2000:]
     assert "GATHER_OK" in outs[0][1]
+
+
+GROUP_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from glimpse_amd import sharding
+group = sharding.Group.from_env()
+assert group.world == 2 and group.store is not None
+P, T = 7, 5                                  # ragged: 4 + 3 points
+sizes = sharding.shard_sizes(P, group.world)
+lo, hi = sharding.shard_range(P, group.world, group.rank)
+full = np.arange(P * T * 12, dtype=float).reshape(P, T, 12)
+status = (np.arange(P) % 3).astype(np.uint32)
+
+
+class FakeCtx:                               # the host transport only needs these three calls
+    def get_moments(self, f0, n):
+        return np.ascontiguousarray(np.transpose(full[lo:hi, f0:f0 + n], (1, 0, 2)))
+    def point_status(self):
+        return status[lo:hi]
+    def sync(self):
+        pass
+
+
+ctx = FakeCtx()
+assert group.attach(ctx, "host") == "host"
+group.barrier()
+assert group.max(10.0 + group.rank) == 11.0
+got = group.gather_moments(ctx, 0, T, sizes)
+arrs = group.gather_arrays([full[lo:hi], status[lo:hi]])
+if group.rank == 0:
+    mom, st = got
+    assert mom.shape == (T, P, 12) and np.array_equal(mom, np.transpose(full, (1, 0, 2)))
+    assert np.array_equal(st, status)
+    assert np.array_equal(arrs[0], full) and np.array_equal(arrs[1], status)
+    print("GROUP_OK")
+else:
+    assert got is None and arrs is None
+path = group.store.path
+group.close()
+if group.rank == 0:
+    assert not os.path.exists(path)
+"""
+
+
+def test_group_host_transport_world2(tmp_path):
+    """The torch-free multi-rank path (FileStore rendezvous + host transport): what `bench.py --gpus 2` and
+    `Tracker.track(parallel=2)` run when RCCL cannot make a communicator."""
+    script = tmp_path / "group_worker.py"
+    script.write_text(GROUP_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLH_RENDEZVOUS_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for rc, out, err in outs:
+        assert rc == 0, err[-2000:]
+    assert "GROUP_OK" in outs[0][1]
+
+
+def test_bench_launcher_starts_n_ranks(tmp_path, monkeypatch):
+    """`bench.py --gpus N` without a launcher starts N rank processes with the torchrun environment before anything
+    touches a GPU, relays rank 0's line and fails if a rank fails (the ranks are stubbed: no GPU here)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os, sys, json\n"
+                    "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                    "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                    "assert os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+                    "open(os.path.join(os.path.dirname(__file__), f'seen.{r}'), 'w').write(str(w))\n"
+                    "if r == 0: print(json.dumps({'n_gpus': w}))\n"
+                    "sys.exit(int(os.environ.get('STUB_FAIL_RANK', '-1')) == r)\n")
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: p)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+    args = bench.parse_args(["--gpus", "3"])
+    assert bench.launch(args) == 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("seen.")) == ["seen.0", "seen.1", "seen.2"]
+    monkeypatch.setenv("STUB_FAIL_RANK", "2")
+    assert bench.launch(args) == 1
