@@ -67,6 +67,9 @@ def parse_args(argv=None):
                     help="processes of the parallel CPU baseline (the reference's parallel=True = os.cpu_count(), "
                          "helpers.py:2008-2011); 0 = every core this process may use, 1 disables it")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--math", default="fast", choices=["fast", "exact"],
+                    help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
+                         "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
     ap.add_argument("--dump-moments", default=None, help="rank 0 saves the (gathered) posterior history (T, P, 12) here (.npy)")
     return ap.parse_args(argv)
 
@@ -173,17 +176,34 @@ def _render_one(job):
 def render_frames(wl, workers):
     """All frames of the workload, [O] arrays (T, H, W) uint8.  The ground map of every camera is computed once
     here; the frames are then rendered by forked workers (this runs before the process touches the GPU)."""
+    cache = os.environ.get("GLH_FRAME_CACHE")  # (A/B tooling: repeated runs of one workload on one box)
+    key = None
+    if cache:
+        key = os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}")
+        if all(os.path.exists(f"{key}_{o}.npy") for o in range(wl.O)):
+            return [np.load(f"{key}_{o}.npy", mmap_mode="r") for o in range(wl.O)]
     for o in range(wl.O):
         wl.scene.ground_map(wl.cams[o])
     jobs = [(wl, o, t) for o in range(wl.O) for t in range(wl.T)]
-    if workers > 1 and len(jobs) > 4:
+    # forked helpers are only safe while this process has not initialised the GPU runtime; a profiler's preloaded
+    # library has done that before main() (rocprofv3 --pmc): render serially there
+    from glimpse_amd import _lib as _l
+
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if workers > 1 and len(jobs) > 4 and not profiled and _l._lib is None:
         import multiprocessing as mp
 
         with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
             flat = pool.map(_render_one, jobs, chunksize=1)
     else:
         flat = [_render_one(j) for j in jobs]
-    return [np.stack(flat[o * wl.T:(o + 1) * wl.T]) for o in range(wl.O)]
+    frames = [np.stack(flat[o * wl.T:(o + 1) * wl.T]) for o in range(wl.O)]
+    if key:
+        os.makedirs(cache, exist_ok=True)
+        for o in range(wl.O):
+            np.save(f"{key}_{o}.npy", frames[o])
+    return frames
 
 
 def cpu_model():
@@ -384,6 +404,7 @@ def worker(args):
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
     ctx.set_point_offset(point_offset)
+    ctx.set_math(args.math)
     transport = group.attach(ctx, args.transport)
     seed = args.seed
     images = lambda i: [i] * wl.O  # noqa: E731
@@ -477,7 +498,7 @@ def worker(args):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": dict(wl.describe(), rng="device Philox4x32-10", parallelism=f"points sharded x{world}",
+            "config": dict(wl.describe(), rng="device Philox4x32-7", math=args.math, parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F,
                            timed_from="the prior (frame 0 initialises, every later frame is a timed step)" if B == 0
                            else f"after {B} untimed updates"),

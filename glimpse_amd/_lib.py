@@ -16,6 +16,7 @@ MOTION_LEN = 18
 MOTION_FULL_LEN = 24
 MOTION_KINDS = {"cartesian": 0, "cylindrical": 1, "tangent_cartesian": 2, "tangent_cylindrical": 3}
 RNG_HOST, RNG_PHILOX = 0, 1
+MATH_EXACT, MATH_FAST = 0, 1
 RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2, "residual": 3}
 OK = 0
 PT_NAN, PT_TEMPLATE_OOB, PT_SAMPLE_OUTSIDE, PT_RESAMPLE_CLAMP, PT_CONST_TILE = 1, 2, 4, 8, 16
@@ -93,6 +94,7 @@ SIGNATURES = {
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
     "glh_track": (_I, [_P, _I, _P, _P, _P, _U64]),
     "glh_set_fused": (_I, [_P, _I]),
+    "glh_set_math": (_I, [_P, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
@@ -395,6 +397,10 @@ class Context:
     def set_fused(self, mode=1):
         """0 staged kernels, 1 fused per-point kernel (default), 2 fused with tiles forced to HBM (test)."""
         check(self.lib.glh_set_fused(self.handle, int(mode)))
+
+    def set_math(self, mode="exact"):
+        """"exact" (NumPy rounding; default) or "fast" (FMA / reciprocal arithmetic for device-RNG runs)."""
+        check(self.lib.glh_set_math(self.handle, {"exact": MATH_EXACT, "fast": MATH_FAST}[mode]))
 
     def set_point_offset(self, offset):
         check(self.lib.glh_set_point_offset(self.handle, int(offset)))

@@ -84,7 +84,7 @@ __device__ __forceinline__ void flag_point(uint32_t* pt_status, int32_t* pt_err_
 // ------------------------------------------------------------------------------------------
 // normals: host-fed (parity with np.random) or Philox + Box-Muller
 // ------------------------------------------------------------------------------------------
-// Standard normals from one Philox4x32-10 block.  Bench-mode process noise does not need
+// Standard normals from one Philox4x32 block (glh_math.h: 7 rounds).  Bench-mode process noise does not need
 // float64 transcendentals: the Box-Muller radius/angle run on the float32 hardware units
 // (v_log_f32, v_sqrt_f32, v_sin/cos_f32 in revolutions), |z| <= 6.6, then widen to float64.
 __device__ __forceinline__ void box_muller_f32(uint32_t ra, uint32_t rb, double& z0, double& z1) {
@@ -98,14 +98,14 @@ __device__ __forceinline__ void box_muller_f32(uint32_t ra, uint32_t rb, double&
 __device__ __forceinline__ void philox_normals2(uint64_t seed, uint32_t c0, uint32_t c1,
                                                 uint32_t c2, uint32_t c3, double& z0, double& z1) {
   uint32_t r[4];
-  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  philox4x32(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
   box_muller_f32(r[0], r[1], z0, z1);
 }
 // three normals from ONE block (all four output words are used)
 __device__ __forceinline__ void philox_normals3(uint64_t seed, uint32_t c0, uint32_t c1,
                                                 uint32_t c2, uint32_t c3, double* z) {
   uint32_t r[4];
-  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  philox4x32(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
   double dump;
   box_muller_f32(r[0], r[1], z[0], z[1]);
   box_muller_f32(r[2], r[3], z[2], dump);
@@ -195,11 +195,31 @@ __device__ __forceinline__ void evolve_cartesian(double* p, const double* m, con
     p[3 + k] += tau * acc;
   }
 }
+// the same step in fast arithmetic (glh_math.h): 4 fused multiply-adds per axis instead of 8 operations
+__device__ __forceinline__ void evolve_cartesian_fast(double* p, const double* m, const double* n, double tau,
+                                                      double tau2) {
+  const double h = 0.5 * tau2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double acc = glh_fma(m[13 + k], n[k], m[10 + k]);
+    p[k] = glh_fma(h, acc, glh_fma(tau, p[3 + k], p[k]));
+    p[3 + k] = glh_fma(tau, acc, p[3 + k]);
+  }
+}
+template <bool FAST>
+__device__ __forceinline__ void evolve_cartesian_m(double* p, const double* m, const double* n, double tau,
+                                                   double tau2) {
+  if (FAST)
+    evolve_cartesian_fast(p, m, n, tau, tau2);
+  else
+    evolve_cartesian(p, m, n, tau, tau2);
+}
+template <bool FAST = false>
 __device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
                                                 double tau2, const Surfaces& surf, bool* oob) {
   const int kind = (int)m[18];
   if (kind == GLH_MOTION_CARTESIAN) {
-    evolve_cartesian(p, m, n, tau, tau2);
+    evolve_cartesian_m<FAST>(p, m, n, tau, tau2);
     return;
   }
   const bool cyl = kind == GLH_MOTION_CYLINDRICAL || kind == GLH_MOTION_TANGENT_CYLINDRICAL;
@@ -299,6 +319,7 @@ struct EvolveArgs {
   uint64_t seed, step;
   double tau;
   int32_t do_evolve, store, rng_mode, N, P, O, NB, frame, pt_base;
+  int32_t fast;  // GLH_MATH_FAST: fast arithmetic (glh_math.h), like the fused kernel's FAST instantiation
   Surfaces surf;
   ObsFrame obs[MAX_OBS];
 };
@@ -321,7 +342,10 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
       double n[3];
       evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, a.N, n);
       bool oob = false;
-      evolve_particle(p, m, n, a.tau, a.tau * a.tau, a.surf, &oob);
+      if (a.fast)
+        evolve_particle<true>(p, m, n, a.tau, a.tau * a.tau, a.surf, &oob);
+      else
+        evolve_particle<false>(p, m, n, a.tau, a.tau * a.tau, a.surf, &oob);
       uint32_t bits = viewshed_bits(a.surf, p[0], p[1]);
       if (oob) bits |= GLH_PT_RASTER_OOB;
       if (bits) flag_point(a.pt_status, a.pt_err_frame, pt, bits, a.frame);
@@ -343,7 +367,10 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
     double u = 0.0, v = 0.0;
     double mnu = INFINITY, mnv = INFINITY, mxu = -INFINITY, mxv = -INFINITY, nanf = 0.0;
     if (valid) {
-      project(*a.obs[o].cam, p[0], p[1], p[2], u, v);
+      if (a.fast)
+        project_fast(*a.obs[o].cam, cam_flags(*a.obs[o].cam), p[0], p[1], p[2], u, v);
+      else
+        project(*a.obs[o].cam, p[0], p[1], p[2], u, v);
       reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * a.N + i] = make_double2(u, v);
       if (isnan(u) || isnan(v)) {
         nanf = 1.0;
@@ -1131,6 +1158,7 @@ struct WeightArgs {
   double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
   int32_t on[MAX_OBS];
   int32_t N, P, O, tw, th, sse_cap, frame;
+  int32_t fast;  // GLH_MATH_FAST
   Surfaces surf;
 };
 
@@ -1146,11 +1174,18 @@ __device__ __forceinline__ void sse_box_of(const int* box, const double* duv, in
 
 constexpr int WEIGHTS_PER_THREAD = 4;
 
+// 2^(j / 32), j < 32: the table of exp_fast (glh_math.h), made by the first 32 threads of a block
+__device__ __forceinline__ void exp_table_fill(double* tab32) {
+  if (threadIdx.x < GLH_EXP_TAB) tab32[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / GLH_EXP_TAB));
+}
+
 __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   __shared__ double tab[16 * GLH_NPOLY];
+  __shared__ double tab32[GLH_EXP_TAB];
   const int pt = blockIdx.y;
   if (a.active && !a.active[pt]) return;
   for (int k = threadIdx.x; k < 16 * GLH_NPOLY; k += BLK) tab[k] = a.poly[k];
+  exp_table_fill(tab32);
   __syncthreads();
   const double* m = a.motion + (size_t)pt * GLH_MOTION_FULL_LEN;
   const bool has_motion_term = (int)m[18] <= GLH_MOTION_CYLINDRICAL;  // tangent models return None
@@ -1179,7 +1214,9 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3]))
         flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
       double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
-      double val = spline_eval_poly(tab, a.coef + slot * (size_t)a.sse_cap, wo, ho, wo, cv0, cu0, q.x, q.y);
+      const double* coef = a.coef + slot * (size_t)a.sse_cap;
+      double val = a.fast ? spline_eval_poly_fast(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+                          : spline_eval_poly(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y);
       if (a.ll_out) a.ll_out[slot * a.N + i] = val * a.inv2s2[o];
       ll += val * a.inv2s2[o];
     }
@@ -1191,7 +1228,8 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       double d = m[16] - z;
       ll += dem_scale * (d * d);
     }
-    if (has_motion_term || any_obs) a.weights[(size_t)pt * a.N + i] = exp(-ll) + 1e-300;
+    if (has_motion_term || any_obs)
+      a.weights[(size_t)pt * a.N + i] = a.fast ? weight_of<true>(ll, tab32) : weight_of<false>(ll, tab32);
   }
   if (oob) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RASTER_OOB, a.frame);
 }
@@ -1225,6 +1263,14 @@ __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
 //       accumulated in one pass around a pivot particle K (shifted moments: no cancellation
 //       at UTM-scale coordinates).
 // ------------------------------------------------------------------------------------------
+// #{j in [0, n): j + u <= ck * scale}, scale = n / total: the number of systematic positions (j + u) / n at or
+// below the cumulative weight ck / total, in fast arithmetic (no verification against the reference's rounding of
+// the positions, which only the host-RNG parity mode needs).  NaN -> 0.
+__device__ __forceinline__ int count_le_fast(double ck, double scale, double u, int n) {
+  const double g = floor(glh_fma(ck, scale, -u)) + 1.0;
+  return g >= 0.0 ? (g > (double)n ? n : (int)g) : 0;
+}
+
 struct ResampleArgs {
   const double* particles_in;
   const double* weights_in;
@@ -1245,6 +1291,7 @@ struct ResampleArgs {
   uint64_t seed, step;
   int32_t N, nleaves, nnodes, nlevels, nroots, rng_mode, frame, pt_base;
   int32_t method;  // GLH_RESAMPLE_*
+  int32_t fast;    // GLH_MATH_FAST (systematic resampling only): see the fast branch in k_resample
 };
 
 __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
@@ -1299,7 +1346,10 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     __syncthreads();  // node[] may be rewritten by the next call
     return t;
   };
-  const double total = pairwise_total();
+  // fast arithmetic, systematic resampling: no normalisation pass at all -- the raw weights are scanned and the
+  // positions are scaled instead, pos_j <= c_k / total  <=>  j <= c_k * (N / total) - u (glh_point.h does the same)
+  const bool fast_sys = a.fast && a.method == GLH_RESAMPLE_SYSTEMATIC;
+  const double total = fast_sys ? 1.0 : pairwise_total();
   const int seg = (N + BLK - 1) / BLK;
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   const int lane = tid & (WAVE - 1);
@@ -1386,7 +1436,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
           key = a.u[(size_t)pt * N + j];
         } else {
           uint32_t r[4];
-          philox4x32_10((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x52455344u, (uint32_t)a.seed,
+          philox4x32((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x52455344u, (uint32_t)a.seed,
                         (uint32_t)(a.seed >> 32), r);
           key = u01_halfopen(r[0], r[1]);
         }
@@ -1412,7 +1462,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       if (clamp) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
     }
   } else {
-  cumsum_inplace(true, total);
+  cumsum_inplace(!fast_sys, total);
   const double inv_n = 1.0 / (double)N;
   if (a.method == GLH_RESAMPLE_SYSTEMATIC) {
     // --- positions (tracker.py:173): pos_j = (j + u) * (1 / n)
@@ -1421,7 +1471,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       u = a.u[pt];
     } else {
       uint32_t r[4];
-      philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+      philox4x32((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
                     (uint32_t)(a.seed >> 32), r);
       u = u01_halfopen(r[0], r[1]);
     }
@@ -1429,7 +1479,9 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     //     c[k-1] < pos_j <= c[k], i.e. j in [f(k-1), f(k)) with f(k) = #{j : pos_j <= c[k]}.
     //     f is guessed arithmetically and fixed up with the exact float comparison, so the
     //     indices are exactly searchsorted's; each thread scatters the runs of its own k range.
+    const double scale = fast_sys ? (double)N / c[N - 1] : 0.0;
     auto count_le = [&](double ck) -> int {
+      if (fast_sys) return count_le_fast(ck, scale, u, N);
       double g = floor(ck * (double)N - u) + 1.0;
       int f = g < 0.0 ? 0 : (g > (double)N ? N : (int)g);
       while (f < N && ((double)f + u) * inv_n <= ck) ++f;
@@ -1464,7 +1516,7 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
         uj = a.u[(size_t)pt * N + j];
       } else {
         uint32_t r[4];
-        philox4x32_10((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x53545241u, (uint32_t)a.seed,
+        philox4x32((uint32_t)j, (uint32_t)(pt + a.pt_base), (uint32_t)a.step, 0x53545241u, (uint32_t)a.seed,
                       (uint32_t)(a.seed >> 32), r);
         uj = u01_halfopen(r[0], r[1]);
       }

@@ -126,6 +126,103 @@ GLH_HD void project_f(const CamDev& c, uint32_t f, double x, double y, double z,
   u = qx * c.f[0] + c.off[0];
   v = qy * c.f[1] + c.off[1];
 }
+// ---- "fast" arithmetic (GLH_MATH_FAST; device-RNG runs): the same formulas with fused multiply-adds and
+// Newton-refined reciprocals instead of IEEE divisions.  Every operation stays within ~1 ulp of the exact path
+// (relative differences of the posteriors ~1e-13), but results are no longer NumPy's bit for bit -- which only the
+// host-fed RNG mode (parity with np.random) needs.  The fused and the staged kernels share these functions, so
+// they remain bit-identical to each other.
+GLH_HD double glh_fma(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fma(a, b, c);
+#else
+  return fma(a, b, c);
+#endif
+}
+GLH_HD double rcp_nr(double x) {  // 1 / x: v_rcp_f64 + two Newton steps (<= 1 ulp for normal x)
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+#else
+  return 1.0 / x;
+#endif
+}
+// min / max of two non-NaN doubles as ONE instruction (HIP's fmin / fmax canonicalise both operands first: three)
+GLH_HD double min_nn(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
+GLH_HD double max_nn(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a > b ? a : b;
+#endif
+}
+
+// project_f in fast arithmetic (perspective cameras and raster grids alike).
+GLH_HD void project_fast(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
+  if (f & CAM_F_GRID) {
+    double gx = x - c.xyz[0], gy = y - c.xyz[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(gx), "+v"(gy));
+#endif
+    u = gx * rcp_nr(c.f[0]);
+    v = gy * rcp_nr(c.f[1]);
+    return;
+  }
+  double dx = x, dy = y, dz = z;
+  if (!(f & CAM_F_DIRECTIONS)) {
+    dx = x - c.xyz[0];
+    dy = y - c.xyz[1];
+    dz = z - c.xyz[2];
+  }
+  if ((f & CAM_F_CORR) && !(f & CAM_F_DIRECTIONS))
+    dz = glh_fma((c.refraction - 1.0) * rcp_nr(2.0 * c.radius), glh_fma(dx, dx, dy * dy), dz);
+  const double cx = glh_fma(c.R[0], dx, glh_fma(c.R[1], dy, c.R[2] * dz));
+  const double cy = glh_fma(c.R[3], dx, glh_fma(c.R[4], dy, c.R[5] * dz));
+  const double cz = glh_fma(c.R[6], dx, glh_fma(c.R[7], dy, c.R[8] * dz));
+  if (!(cz > 0.0)) {
+    u = v = NAN;
+    return;
+  }
+  const double inv = rcp_nr(cz);
+  const double px = cx * inv, py = cy * inv;
+  double qx = px, qy = py;
+  if (f & (CAM_F_ANYK | CAM_F_ANYP)) {
+    const double r2 = glh_fma(px, px, py * py);
+    if (f & CAM_F_ANYK) {
+      double dr = glh_fma(r2, glh_fma(r2, glh_fma(r2, c.k[2], c.k[1]), c.k[0]), 1.0);
+      if (f & CAM_F_ANYKDEN) dr *= rcp_nr(glh_fma(r2, glh_fma(r2, glh_fma(r2, c.k[5], c.k[4]), c.k[3]), 1.0));
+      qx = px * dr;
+      qy = py * dr;
+    }
+    if (f & CAM_F_ANYP) {
+      const double xty2 = 2.0 * (px * py);
+      qx += glh_fma(xty2, c.p[0], c.p[1] * glh_fma(2.0 * px, px, r2));
+      qy += glh_fma(c.p[0], glh_fma(2.0 * py, py, r2), xty2 * c.p[1]);
+    }
+  }
+  u = glh_fma(qx, c.f[0], c.off[0]);
+  v = glh_fma(qy, c.f[1], c.off[1]);
+}
+template <bool FAST>
+GLH_HD void project_m(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
+  if (FAST)
+    project_fast(c, f, x, y, z, u, v);
+  else
+    project_f(c, f, x, y, z, u, v);
+}
+
 GLH_HD void project(const CamDev& c, double x, double y, double z, double& u, double& v) {
   project_f(c, cam_flags(c), x, y, z, u, v);
 }
@@ -473,6 +570,75 @@ GLH_HD double spline_eval_poly(const double* tab, const double* coef, int ld, in
   return sp;
 }
 
+// spline_eval_poly in fast arithmetic: Horner steps and the tensor sum as fused multiply-adds, the tensor summed
+// row by row (20 operations instead of 48), clamps as min / max (the arguments are never NaN here: a NaN
+// projection skips the observer before anything is sampled).
+GLH_HD double spline_eval_poly_fast(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,
+                                    double cu0, double u, double v) {
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
+  const int qv = spline_interval(vl, ho);
+  const int qu = spline_interval(ul, wo);
+  double hv[4], hu[4];
+  {
+    const double* c = tab + 16 * spline_poly_index(ho, qv);
+    const double s = vl - spline_interval_start(qv);
+    for (int m2 = 0; m2 < 4; ++m2)
+      hv[m2] = glh_fma(glh_fma(glh_fma(c[4 * m2 + 3], s, c[4 * m2 + 2]), s, c[4 * m2 + 1]), s, c[4 * m2]);
+  }
+  {
+    const double* c = tab + 16 * spline_poly_index(wo, qu);
+    const double s = ul - spline_interval_start(qu);
+    for (int m2 = 0; m2 < 4; ++m2)
+      hu[m2] = glh_fma(glh_fma(glh_fma(c[4 * m2 + 3], s, c[4 * m2 + 2]), s, c[4 * m2 + 1]), s, c[4 * m2]);
+  }
+  double sp = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double* row = coef + (size_t)(qv + i) * ld + qu;
+    const double si = glh_fma(row[3], hu[3], glh_fma(row[2], hu[2], glh_fma(row[1], hu[1], row[0] * hu[0])));
+    sp = glh_fma(hv[i], si, sp);
+  }
+  return sp;
+}
+template <bool FAST>
+GLH_HD double spline_eval_poly_m(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,
+                                 double cu0, double u, double v) {
+  return FAST ? spline_eval_poly_fast(tab, coef, ld, ho, wo, cv0, cu0, u, v)
+              : spline_eval_poly(tab, coef, ld, ho, wo, cv0, cu0, u, v);
+}
+
+// w = exp(-ll) + 1e-300 (tracker.py:149).  Exact: the library exp.  Fast: exp(x) = 2^m * T[j] * P(r) with
+// x = (32 m + j) ln2 / 32 + r, |r| <= ln2 / 64, T[j] = 2^(j/32) (a 32-entry table the caller provides: LDS) and
+// P the degree-5 Taylor polynomial (|r|^6 / 720 < 2.3e-15): ~1e-15 relative, half the instructions.
+constexpr int GLH_EXP_TAB = 32;
+GLH_HD double exp_fast(double x, const double* tab32) {
+  const double t = x * 0x1.71547652b82fep+5;  // 32 / ln 2
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double kf = __builtin_rint(t);
+#else
+  const double kf = rint(t);
+#endif
+  double r = glh_fma(kf, -0x1.62e42fefa39efp-6, x);  // ln 2 / 32 = hi + lo
+  r = glh_fma(kf, -0x1.abc9e3b39803fp-61, r);
+  const int ki = (int)kf;
+  const double T = tab32[ki & (GLH_EXP_TAB - 1)];
+  double p = glh_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = glh_fma(p, r, 1.0 / 6.0);
+  p = glh_fma(p, r, 0.5);
+  p = glh_fma(p, r, 1.0);
+  p = glh_fma(p, r, 1.0);
+  return ldexp(T * p, ki >> 5);
+}
+template <bool FAST>
+GLH_HD double weight_of(double ll, const double* tab32) {
+  if (FAST) {
+    // exp underflows to 0 below -745.2, like the library's (ki stays a small int: ll < 2^24)
+    const double x = -ll;
+    return (x < -746.0 ? 0.0 : exp_fast(x, tab32)) + 1e-300;
+  }
+  return exp(-ll) + 1e-300;
+}
+
 // Evaluate the tensor spline with coefficients coef[ho][wo] (row stride ld) at (u, v);
 // arguments are clamped to the outermost cell centres (FITPACK fpbisp).
 GLH_HD double spline_eval(const double* coef, int ld, int ho, int wo, double cv0, double cu0,
@@ -494,16 +660,24 @@ GLH_HD double spline_eval(const double* coef, int ld, int ho, int wo, double cv0
   return sp;
 }
 
-// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: no state in HBM -------------------
+// ---- Philox4x32 (Salmon et al. 2011), counter-based: no state in HBM ----------------------
+// The device streams use 7 rounds: the smallest round count of Philox4x32 that passes BigCrush ("Crush-resistant",
+// Salmon et al. 2011, table 2; the paper's own safety margin is 10).  philox4x32_r<10> is Random123's
+// philox4x32_10 (known-answer vectors in tests/test_hostcheck.py); the statistical tests of the 7-round streams
+// are tests/test_gpu_rng_statistics.py.
+#ifndef GLH_PHILOX_ROUNDS
+#define GLH_PHILOX_ROUNDS 7
+#endif
 GLH_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-GLH_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                          uint32_t k1, uint32_t* out) {
+template <int ROUNDS>
+GLH_HD void philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                         uint32_t k1, uint32_t* out) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#ifndef GLH_PHILOX_ROUNDS
-#define GLH_PHILOX_ROUNDS 10
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
 #endif
-  for (int r = 0; r < GLH_PHILOX_ROUNDS; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     // one 32 x 32 -> 64 product per multiplier (a single v_mad_u64_u32 on gfx950) gives hi and lo
     const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -514,6 +688,11 @@ GLH_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     k1 += W1;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// the generator of every device stream (evolve / init noise, resampling offsets)
+GLH_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                       uint32_t* out) {
+  philox4x32_r<GLH_PHILOX_ROUNDS>(c0, c1, c2, c3, k0, k1, out);
 }
 
 // two uint32 -> uniform double in (0, 1): 53 random bits, never 0 (safe for log)

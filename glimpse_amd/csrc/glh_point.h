@@ -429,7 +429,9 @@ __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
 
 // SURF: the context holds gridded surfaces (dem / dem_sigma / viewshed rasters); compiled out otherwise so
 // that the common constant-surface kernel carries none of their registers.
-template <int TB, int PPT, int MINW, int NOBS, bool SURF>
+// FAST: fast arithmetic (GLH_MATH_FAST, glh_math.h): fused multiply-adds, Newton reciprocals, table exp, and a
+// resampling that scans the raw weights and scales the positions instead of normalising (no NumPy-exact sum tree).
+template <int TB, int PPT, int MINW, int NOBS, bool SURF, bool FAST>
 __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   constexpr int PT_WAVES = TB / WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -445,6 +447,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ double s_m[GLH_MOTION_FULL_LEN];  // this point's motion parameters: the loops below store to global
                                           // memory, so reading them through a global pointer would reload
                                           // (and wait for) them on every iteration
+  __shared__ double tab32[GLH_EXP_TAB];   // 2^(j/32) for exp_fast
+  __shared__ double s_scale;              // FAST: N / sum of the weights (phase D)
   const int pt = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int N = a.N;
@@ -461,12 +465,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       s_u = a.u[pt];
     } else {
       uint32_t r[4];
-      philox4x32_10((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
-                    (uint32_t)(a.seed >> 32), r);
+      philox4x32((uint32_t)(pt + a.pt_base), 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed,
+                 (uint32_t)(a.seed >> 32), r);
       s_u = u01_halfopen(r[0], r[1]);
     }
   }
   for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
+  if (FAST) exp_table_fill(tab32);
   if (tid < GLH_MOTION_FULL_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_FULL_LEN + tid];
   {
     static_assert(sizeof(CamDev) % 8 == 0, "CamDev is copied as doubles");
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
-    evolve_cartesian(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
+    evolve_cartesian_m<FAST>(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
   };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       if (i < N) {
         double n[3];
         evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
-        evolve_cartesian(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
+        evolve_cartesian_m<FAST>(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
         if (i == 0) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) s_K[k] = x[k];
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
           double u, v;
-          project_f(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
+          project_m<FAST>(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
           if (o == 0) {
             if constexpr (PPT > 0) {
               pt_put<NREG>(u0, r, u);
@@ -618,8 +623,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           if (isnan(u) || isnan(v)) {
             nanf[o] = 1.0;
           } else {
-            mn[o][0] = fmin(mn[o][0], u); mx[o][0] = fmax(mx[o][0], u);
-            mn[o][1] = fmin(mn[o][1], v); mx[o][1] = fmax(mx[o][1], v);
+            mn[o][0] = min_nn(mn[o][0], u); mx[o][0] = max_nn(mx[o][0], u);  // (u, v are not NaN here)
+            mn[o][1] = min_nn(mn[o][1], v); mx[o][1] = max_nn(mx[o][1], v);
           }
         }
       }
@@ -736,10 +741,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       if (o == 0) {
         auto sample_one = [&](int i, double2 q) {
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-          const double term = spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          const double term = spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           // a single observer and no motion-model term: this IS the log likelihood, the weight follows at once
-          c[i] = w_here ? exp(-ll) + 1e-300 : ll;
+          c[i] = w_here ? weight_of<FAST>(ll, tab32) : ll;
         };
         if constexpr (PPT > 0) {
           // fully unrolled: u0[r] is a register with a static index (a rolled loop sends the array to scratch:
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int i = tid; i < N; i += TB) {
           const double2 q = uvp[i];
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
-          c[i] += spline_eval_poly(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          c[i] += spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
         }
       }
     };
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int i = tid; i < N; i += TB) {
       double ll = c[i];
       if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
-      c[i] = exp(-ll) + 1e-300;  // the weights stay in LDS until the gather of phase E
+      c[i] = weight_of<FAST>(ll, tab32);  // the weights stay in LDS until the gather of phase E
     }
     __syncthreads();
   }
@@ -906,40 +911,43 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(6);
   // ---------------- D: w.sum() as NumPy's pairwise tree, cumsum(w / total), searchsorted ------
   double* node = reinterpret_cast<double*>(r2);
-  {
-    const int sub = tid & 7;
-    for (int L = tid >> 3; L < a.nleaves; L += TB / 8) {
-      const int off = p_leaf_off[L], len = p_leaf_len[L];
-      double res;
-      if (len < 8) {
-        res = 0.0;
-        if (sub == 0)
-          for (int i = 0; i < len; ++i) res += c[off + i];
-      } else {
-        double r = c[off + sub];
-        const int body = len - (len & 7);
-        for (int i = 8; i < body; i += 8) r += c[off + i + sub];
-        r += __shfl_xor(r, 1, WAVE);
-        r += __shfl_xor(r, 2, WAVE);
-        r += __shfl_xor(r, 4, WAVE);
-        res = r;
-        if (sub == 0)
-          for (int i = body; i < len; ++i) res += c[off + i];
+  double total = 1.0;
+  if constexpr (!FAST) {
+    {
+      const int sub = tid & 7;
+      for (int L = tid >> 3; L < a.nleaves; L += TB / 8) {
+        const int off = p_leaf_off[L], len = p_leaf_len[L];
+        double res;
+        if (len < 8) {
+          res = 0.0;
+          if (sub == 0)
+            for (int i = 0; i < len; ++i) res += c[off + i];
+        } else {
+          double r = c[off + sub];
+          const int body = len - (len & 7);
+          for (int i = 8; i < body; i += 8) r += c[off + i + sub];
+          r += __shfl_xor(r, 1, WAVE);
+          r += __shfl_xor(r, 2, WAVE);
+          r += __shfl_xor(r, 4, WAVE);
+          res = r;
+          if (sub == 0)
+            for (int i = body; i < len; ++i) res += c[off + i];
+        }
+        if (sub == 0) node[L] = res;
       }
-      if (sub == 0) node[L] = res;
-    }
-  }
-  __syncthreads();
-  for (int l = 0; l < a.nlevels; ++l) {
-    for (int k = p_level_off[l] + tid; k < p_level_off[l + 1]; k += TB) {
-      const int32_t* op = p_ops + 3 * k;
-      node[op[0]] = node[op[1]] + node[op[2]];
     }
     __syncthreads();
+    for (int l = 0; l < a.nlevels; ++l) {
+      for (int k = p_level_off[l] + tid; k < p_level_off[l + 1]; k += TB) {
+        const int32_t* op = p_ops + 3 * k;
+        node[op[0]] = node[op[1]] + node[op[2]];
+      }
+      __syncthreads();
+    }
+    total = node[p_roots[0]];
+    for (int r = 1; r < a.nroots; ++r) total += node[p_roots[r]];
   }
   PT_STAMP(10);
-  double total = node[p_roots[0]];
-  for (int r = 1; r < a.nroots; ++r) total += node[p_roots[r]];
   // cumsum(w / total) over contiguous segments, one per thread, WITHOUT storing it: c[] keeps the weights.
   // PPT > 0 (seg <= PPT): the quotients wait in registers for the second pass; otherwise they are recomputed.
   const int seg = (N + TB - 1) / TB;
@@ -949,11 +957,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   if constexpr (PPT > 0) {
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
-      qn[j] = k0 + j < k1 ? c[k0 + j] / total : 0.0;
+      // (FAST: the raw weights are scanned; the positions are scaled by N / total instead)
+      qn[j] = k0 + j < k1 ? (FAST ? c[k0 + j] : c[k0 + j] / total) : 0.0;
       if (k0 + j < k1) run += qn[j];
     }
   } else {
-    for (int k = k0; k < k1; ++k) run += c[k] / total;
+    for (int k = k0; k < k1; ++k) run += FAST ? c[k] : c[k] / total;
   }
   double incl = run;
 #pragma unroll
@@ -973,6 +982,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // (thread 0's running sums are used as they are)
   double* clast = node + a.nnodes;  // [TB] last cumulative weight of every segment
   clast[tid] = tid > 0 ? excl + run : run;
+  if (FAST && tid == TB - 1) s_scale = (double)N / (excl + run);  // N / sum of the weights
   PT_STAMP(12);
   const double u = s_u;  // the point's resample offset (drawn once, in the prologue)
   const double inv_n = 1.0 / (double)N;
@@ -988,7 +998,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // VERIFIED with the two exact comparisons around it; only if one fails (an ulp-level boundary) does
     // the general walk run.
     const double dN = (double)N;
+    pt_lds_barrier();  // clast (and, FAST, the position scale) are visible
+    const double pos_scale = FAST ? s_scale : 0.0;
     auto count_le = [&](double ck) -> int {
+      if constexpr (FAST) return count_le_fast(ck, pos_scale, u, N);
       double g = floor(ck * dN - u) + 1.0;
       g = g < 0.0 ? 0.0 : (g > dN ? dN : g);
       const bool below_ok = !(g > 0.0) || ((g - 1.0) + u) * inv_n <= ck;  // position g-1 is counted
@@ -1004,7 +1017,6 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // least one position (the survivors) are RANKED in order; output j then only needs the rank of its source
     // (ufill, written at the head of every run and spread by an inclusive max-scan: ranks grow with the position),
     // and the gather below runs over the ranks: one re-evolved record per survivor, however many copies it has.
-    pt_lds_barrier();  // clast is visible
     const int f_first = k0 > 0 && k0 < N ? count_le(clast[tid - 1]) : 0;
     // pass 1: where every own source's run ends (f), how many own sources survive
     int fk[NREG];
@@ -1031,7 +1043,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       } else {
         for (int k = k0; k < k1; ++k) {
-          run2 += c[k] / total;
+          run2 += FAST ? c[k] : c[k] / total;
           int f = count_le(tid > 0 ? excl + run2 : run2);
           if (k == N - 1 && f < N) {
             flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RESAMPLE_CLAMP, a.frame);
@@ -1082,7 +1094,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       } else {
         for (int k = k0; k < k1; ++k) {
-          run2 += c[k] / total;
+          run2 += FAST ? c[k] : c[k] / total;
           int f = count_le(tid > 0 ? excl + run2 : run2);
           if (k == N - 1 && f < N) f = N;
           if (f > f_prev) {
@@ -1160,8 +1172,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int k = 0; k < 6; ++k) {
           double d = x[g][k] - K[k];
           double wd = cw * d;
-          s1[k] += wd;
-          s2[k] += wd * d;
+          if constexpr (FAST) {
+            s1[k] = glh_fma(cw, d, s1[k]);
+            s2[k] = glh_fma(wd, d, s2[k]);
+          } else {
+            s1[k] += wd;
+            s2[k] += wd * d;
+          }
         }
       }
     }

@@ -105,6 +105,7 @@ struct glh_ctx {
   int fused = 1;    // glh_step: 0 staged kernels, 1 fused per-point kernel, 2 fused with tiles forced to HBM (test)
   int pt_base = 0;  // global index of this context's point 0
   bool all_cartesian = true;  // every point is CartesianMotion (what the fused kernel evolves)
+  bool fast_math = false;     // GLH_MATH_FAST (glh_set_math)
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
@@ -373,13 +374,13 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-#define GLH_PT_VARIANTS(SURF_)                                                                          \
-  (const void*)k_point_step<512, 0, 4, 1, SURF_>, (const void*)k_point_step<512, 0, 4, 2, SURF_>,          \
-  (const void*)k_point_step<512, 4, 4, 1, SURF_>, (const void*)k_point_step<512, 10, 4, 1, SURF_>,         \
-  (const void*)k_point_step<512, 4, 4, 2, SURF_>, (const void*)k_point_step<512, 10, 4, 2, SURF_>,         \
-  (const void*)k_point_step<1024, 0, 4, 1, SURF_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_>,        \
-  (const void*)k_point_step<1024, 10, 4, 1, SURF_>, (const void*)k_point_step<1024, 10, 4, 2, SURF_>
-    for (const void* f : {GLH_PT_VARIANTS(false), GLH_PT_VARIANTS(true)}) {
+#define GLH_PT_VARIANTS(SURF_, FAST_)                                                                             \
+  (const void*)k_point_step<512, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 0, 4, 2, SURF_, FAST_>,     \
+  (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_>,    \
+  (const void*)k_point_step<512, 4, 4, 2, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 2, SURF_, FAST_>,    \
+  (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_>,   \
+  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 10, 4, 2, SURF_, FAST_>
+    for (const void* f : {GLH_PT_VARIANTS(false, false), GLH_PT_VARIANTS(true, false), GLH_PT_VARIANTS(false, true)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
@@ -629,6 +630,11 @@ static int ensure_expanded(glh_ctx* c) {
     HIPCHK(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(type), hipMemcpyDeviceToHost, c->stream)); \
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
+
+// Fast arithmetic is in force for constant-surface contexts (the gridded-surface kernels are exact only).
+static bool use_fast(const glh_ctx* c) {
+  return c->fast_math && !(c->rasters[0].z || c->rasters[1].z || c->rasters[2].z);
+}
 
 static Surfaces surfaces(const glh_ctx* c) {
   Surfaces s{};
@@ -901,6 +907,7 @@ static int launch_evolve_project(glh_ctx* c, bool do_evolve, double tau, int rng
   a.NB = c->NB;
   a.frame = c->frame;
   a.pt_base = c->pt_base;
+  a.fast = use_fast(c);
   for (int o = 0; o < a.O; ++o) fill_obs(c, o, images ? images[o] : -1, &a.obs[o]);
   {
     StageTimer t(c, ST_EVOLVE_PROJECT);
@@ -1091,6 +1098,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.th = c->th;
   wa.sse_cap = c->sse_cap;
   wa.frame = c->frame;
+  wa.fast = use_fast(c);
   wa.surf = surfaces(c);
   {
     StageTimer t(c, ST_WEIGHTS);
@@ -1161,6 +1169,7 @@ extern "C" int glh_resample_method(glh_ctx* c, int method, int rng_mode, const d
   a.rng_mode = rng_mode;
   a.frame = c->frame;
   a.pt_base = c->pt_base;
+  a.fast = use_fast(c);
   if (c->have_active) {
     // inactive points keep their state: copy their rows across before swapping buffers
     HIPCHK(hipMemcpyAsync(c->particles[c->cur ^ 1], c->particles[c->cur], (size_t)c->P * c->N * 6 * sizeof(double),
@@ -1316,12 +1325,15 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     if (big && ppt == 4) ppt = 10;
     if (getenv("GLH_PT_UVLDS")) ppt = 0;
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z;
-#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                              \
-  do {                                                                                                  \
-    if (surf)                                                                                           \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true>), grid, block, lds, c->stream, a);    \
-    else                                                                                                \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false>), grid, block, lds, c->stream, a);   \
+    const bool fast = use_fast(c);
+#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
+  do {                                                                                                         \
+    if (surf)                                                                                                  \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, false>), grid, block, lds, c->stream, a);    \
+    else if (fast)                                                                                             \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, true>), grid, block, lds, c->stream, a);    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, false>), grid, block, lds, c->stream, a);   \
   } while (0)
     if (!big) {
       if (O == 1) {
@@ -1476,6 +1488,13 @@ extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
     return GLH_OK;
   }
   DOWNLOAD(stamps, c->stamps, n, unsigned long long);
+  return GLH_OK;
+}
+
+extern "C" int glh_set_math(glh_ctx* c, int mode) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (mode != GLH_MATH_EXACT && mode != GLH_MATH_FAST) return fail(GLH_E_INVALID, "mode must be GLH_MATH_EXACT or GLH_MATH_FAST");
+  c->fast_math = mode == GLH_MATH_FAST;
   return GLH_OK;
 }
 

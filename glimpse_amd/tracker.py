@@ -11,7 +11,7 @@ Random numbers.  The reference draws from the legacy global `np.random` stream, 
 track after another.  `rng="numpy"` (default) reproduces exactly that
 stream on the host and feeds it to the device, so `np.random.seed(s); tracker.track(...)`
 gives the reference's particles, indices and posteriors.  `rng="philox"` draws on the device
-(counter-based Philox4x32-10) and is what large runs use.
+(counter-based Philox4x32, fast arithmetic: `glh_set_math`) and is what large runs use.
 """
 import datetime
 import os
@@ -261,6 +261,8 @@ class Tracker:
             ctx.set_motion(np.stack([m.params_full() for m in motion_models]))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
             ctx.set_point_offset(point_offset)
+            # device-RNG runs have no reference stream to be bit-exact with: fast arithmetic (GLH_MATH_FAST)
+            ctx.set_math("fast" if draws is None else "exact")
             for w in warn_log:
                 w.clear()
             out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None

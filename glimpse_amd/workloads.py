@@ -84,6 +84,7 @@ class Workload:
         else:
             # keep only seeds that every camera sees with a full template + search margin
             margin = 0.5 * max(self.tile) + (110.0 if min(self.imgsz) >= 1024 else 40.0)
+            margin += 20.0 * max(abs(VELOCITY[0]), abs(VELOCITY[1])) * max(0, self.T - 32)  # (f = 1200, oblique: <= 2 px/frame)
             want, factor = self.P, 2
             while True:
                 cand = synth.grid_points(cam0, want * factor, border_px=border - 200.0 + margin, seed=1000 + shard)

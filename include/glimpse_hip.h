@@ -95,7 +95,15 @@ extern "C" {
 
 /* ---- random-number modes ------------------------------------------------------------- */
 #define GLH_RNG_HOST 0   /* caller supplies the normals / uniforms (parity with np.random)  */
-#define GLH_RNG_PHILOX 1 /* counter-based Philox4x32-10 on the device                       */
+#define GLH_RNG_PHILOX 1 /* counter-based Philox4x32 (7 rounds) on the device               */
+
+/* ---- arithmetic modes (glh_set_math) --------------------------------------------------- */
+#define GLH_MATH_EXACT 0 /* every float64 expression rounds like NumPy's (default): with host-fed draws the resample
+                          * indices are the reference's bit for bit                                           */
+#define GLH_MATH_FAST 1  /* same formulas with fused multiply-adds, Newton reciprocals instead of IEEE divisions, a
+                          * table exp and no normalisation pass in the systematic resampling: ~1e-13 relative on the
+                          * posteriors, ~10 % faster; meant for device-RNG runs, where no reference stream exists to be
+                          * bit-exact with.  Applies to contexts without gridded surfaces.                        */
 
 typedef struct glh_ctx glh_ctx;
 
@@ -241,6 +249,9 @@ int glh_track(glh_ctx* ctx, int n_frames, const int32_t* frames, const double* t
  * forced into the HBM workspaces (test hook for the large-tile path).  All give the same
  * particles bit for bit.                                                                      */
 int glh_set_fused(glh_ctx* ctx, int on);
+/* GLH_MATH_EXACT (default) or GLH_MATH_FAST for every kernel of this context (the staged and the fused kernels use
+ * the same arithmetic in either mode, so they stay bit-identical to each other).                                */
+int glh_set_math(glh_ctx* ctx, int mode);
 
 /* Diagnostic: s_memtime stamps [P][16] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */

@@ -147,6 +147,30 @@ double hc_poly_basis_error(int nmax, int nsamp) {
 }
 
 void hc_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned* out) {
-  philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+  philox4x32_r<10>(c0, c1, c2, c3, k0, k1, out);  // Random123's philox4x32_10 (known-answer vectors)
+}
+// the round count the device streams use (GLH_PHILOX_ROUNDS), and any other
+void hc_philox_rounds(int rounds, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                      unsigned* out) {
+  if (rounds == 7) philox4x32_r<7>(c0, c1, c2, c3, k0, k1, out);
+  else if (rounds == 10) philox4x32_r<10>(c0, c1, c2, c3, k0, k1, out);
+  else philox4x32(c0, c1, c2, c3, k0, k1, out);
+}
+int hc_philox_device_rounds() { return GLH_PHILOX_ROUNDS; }
+// fast-arithmetic restatements against the exact ones (host build: rcp_nr is 1 / x here)
+double hc_exp_fast(double x) {
+  static double tab[GLH_EXP_TAB];
+  static bool init = false;
+  if (!init) {
+    for (int j = 0; j < GLH_EXP_TAB; ++j) tab[j] = exp2((double)j / GLH_EXP_TAB);
+    init = true;
+  }
+  return weight_of<true>(-x, tab) - 1e-300;
+}
+void hc_project_fast(const double* cam24, const double* xyz, int n, double* uv) {
+  CamDev c;
+  expand_camera(cam24, &c);
+  const unsigned f = cam_flags(c);
+  for (int i = 0; i < n; ++i) project_fast(c, f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
 }
 }

@@ -148,3 +148,54 @@ def test_philox_known_answers(hc):
         out = (C.c_uint * 4)()
         hc.hc_philox(*ctr, *key, out)
         assert tuple(out) == want
+
+
+def _philox_python(rounds, ctr, key):
+    """Independent restatement of Philox4x32-R (Salmon et al. 2011, fig. 2) in Python integers."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(rounds):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, \
+            p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return [c0, c1, c2, c3]
+
+
+def test_philox_device_round_count_matches_python_restatement(hc):
+    """The device streams use Philox4x32-7 (the Crush-resistant minimum); the 10-round form is pinned by Random123's
+    known-answer vectors above, every other round count by the same round function restated in Python."""
+    hc.hc_philox_device_rounds.restype = C.c_int
+    assert hc.hc_philox_device_rounds() == 7
+    rng = np.random.default_rng(3)
+    for rounds in (7, 10):
+        for _ in range(50):
+            ctr = [int(v) for v in rng.integers(0, 2 ** 32, 4)]
+            key = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+            out = (C.c_uint * 4)()
+            hc.hc_philox_rounds(rounds, *[C.c_uint(v) for v in ctr + key], out)
+            assert list(out) == _philox_python(rounds, ctr, key)
+    # and the Python restatement reproduces a Random123 vector at 10 rounds
+    assert _philox_python(10, [0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+def test_fast_arithmetic_restatements_stay_within_a_few_ulp(hc, golden):
+    """GLH_MATH_FAST helpers against the exact path (host build of the same code): the table exp over the whole
+    range of log likelihoods, and the FMA projection on the reference's projection goldens."""
+    hc.hc_exp_fast.restype = C.c_double
+    x = -np.concatenate((np.linspace(0, 50, 20001), np.geomspace(1e-12, 745.0, 5000), [0.0, 1e-300, 744.9, 746.5, 1e6]))
+    got = np.array([hc.hc_exp_fast(C.c_double(v)) for v in x])
+    want = np.exp(x)
+    ok = want > 1e-290
+    assert np.abs(got[ok] / want[ok] - 1).max() < 4e-15
+    assert (got[~ok] >= 0).all() and (got[~ok] < 2e-290).all()
+    pos = np.array([hc.hc_exp_fast(C.c_double(v)) for v in (1e-9, 0.5, 3.0)])
+    np.testing.assert_allclose(pos, np.exp([1e-9, 0.5, 3.0]), rtol=4e-15)
+    g = golden("g1_projection.npz")
+    for cam, xyz, uv in zip(g["cams"], g["xyz"], g["uv"]):
+        got = np.empty_like(uv)
+        hc.hc_project_fast(p(np.ascontiguousarray(cam)), p(np.ascontiguousarray(xyz)), len(xyz), p(got))
+        assert np.array_equal(np.isnan(got), np.isnan(uv))
+        ok = ~np.isnan(uv[:, 0])
+        np.testing.assert_allclose(got[ok], uv[ok], rtol=1e-12, atol=1e-8)

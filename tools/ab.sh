@@ -14,7 +14,7 @@ for i in 1 2 3; do
         --*) extra=$v ;;
         *) export $v ;;
       esac
-      python bench.py --no-cpu-baseline "$@" $extra 2>/dev/null | python -c "
+      python bench.py --no-cpu-baseline --no-api "$@" $extra 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms']*d['roofline']['launches_per_step'],4))"
     )
