@@ -505,17 +505,33 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     float* T = reinterpret_cast<float*>(r2);
     const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
     const UDiv by_twp = udiv_make(twp);
-    for (int idx = tid; idx < th * twp; idx += TB) {
-      const int i = udiv(by_twp, idx), j = idx - i * twp;
-      T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
-    }
     double* cq = reinterpret_cast<double*>(r2 + pt_align16(th * twp * 4));
     double* cv = cq + pt_align16(hist_n * 8) / 8;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
-    for (int k = tid; k < hist_n; k += TB) {
-      cq[k] = hq_g[k];
-      cv[k] = hv_g[k];
+    if (th * twp <= 2 * TB && hist_n <= 2 * TB) {
+      // the usual sizes: every load of this thread is in flight before the first LDS store (one memory latency
+      // instead of four)
+      const int i0 = tid, i1 = tid + TB;
+      const int r0 = udiv(by_twp, i0), j0 = i0 - r0 * twp, r1 = udiv(by_twp, i1), j1 = i1 - r1 * twp;
+      const bool t0 = i0 < th * twp && j0 < tw, t1 = i1 < th * twp && j1 < tw;
+      const float f0 = t0 ? tg[r0 * tw + j0] : 0.0f, f1 = t1 ? tg[r1 * tw + j1] : 0.0f;
+      const bool h0 = i0 < hist_n, h1 = i1 < hist_n;
+      const double q0 = h0 ? hq_g[i0] : 0.0, v0 = h0 ? hv_g[i0] : 0.0;
+      const double q1 = h1 ? hq_g[i1] : 0.0, v1 = h1 ? hv_g[i1] : 0.0;
+      if (i0 < th * twp) T[i0] = f0;
+      if (i1 < th * twp) T[i1] = f1;
+      if (h0) { cq[i0] = q0; cv[i0] = v0; }
+      if (h1) { cq[i1] = q1; cv[i1] = v1; }
+    } else {
+      for (int idx = tid; idx < th * twp; idx += TB) {
+        const int i = udiv(by_twp, idx), j = idx - i * twp;
+        T[idx] = j < tw ? tg[i * tw + j] : 0.0f;
+      }
+      for (int k = tid; k < hist_n; k += TB) {
+        cq[k] = hq_g[k];
+        cv[k] = hv_g[k];
+      }
     }
   };
   __syncthreads();
@@ -739,28 +755,37 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const double scale = a.inv2s2[o];
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
       if (o == 0) {
-        auto sample_one = [&](int i, double2 q) {
+        auto sample_one = [&](double2 q) -> double {
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           const double term = spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           // a single observer and no motion-model term: this IS the log likelihood, the weight follows at once
-          c[i] = w_here ? weight_of<FAST>(ll, tab32) : ll;
+          return w_here ? weight_of<FAST>(ll, tab32) : ll;
         };
         if constexpr (PPT > 0) {
           // fully unrolled: u0[r] is a register with a static index (a rolled loop sends the array to scratch:
-          // 80 B per thread written and re-read through memory)
+          // 80 B per thread written and re-read through memory).  The results replace the u's in their registers
+          // and are stored after the loop: with no LDS store between them, the table / coefficient loads of one
+          // particle can be issued while the previous one is still being summed.
 #pragma unroll
           for (int r = 0; r < NREG; ++r) {
             if (r < rounds) {  // uniform
               const int i = r * TB + tid;
-              if (i < N) sample_one(i, make_double2(u0[r], c[i]));
+              if (i < N) u0[r] = sample_one(make_double2(u0[r], c[i]));
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < NREG; ++r) {
+            if (r < rounds) {
+              const int i = r * TB + tid;
+              if (i < N) c[i] = u0[r];
             }
           }
         } else {
 #pragma unroll 1
           for (int r = 0; r < rounds; ++r) {
             const int i = r * TB + tid;
-            if (i < N) sample_one(i, make_double2(c[i], V0[i]));
+            if (i < N) c[i] = sample_one(make_double2(c[i], V0[i]));
           }
         }
         c_ready = true;

@@ -20,6 +20,7 @@ NAMES = ["", "A evolve+project", "B tile_prep", "B ssd", "B spline_fit", "C samp
          "E gather", "F moments"]
 with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     workloads.setup_context(ctx, wl, frames)
+    ctx.set_math(os.environ.get("GLH_MATH", "fast"))
     ctx.set_frame(0)
     ctx.init_particles(seed=3)
     for o in range(wl.O):
