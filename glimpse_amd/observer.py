@@ -26,14 +26,15 @@ class Observer:
         self.cache = cache
 
     def index(self, value, maxdt=datetime.timedelta(0)):
-        """observer.py:71-100."""
-        if isinstance(value, datetime.datetime):
-            dts = np.abs(value - self.datetimes)
-            index = np.argmin(dts)
-            if maxdt is not None and dts[index] > abs(maxdt):
-                raise ValueError("Nearest image out of range by " + str(dts[index] - abs(maxdt)))
-            return index
-        return self.images.index(value)
+        """observer.py:71-100: position of an image object, or of the image nearest to a datetime (ValueError when
+        that image is further than |maxdt| away; maxdt=None accepts any distance)."""
+        if not isinstance(value, datetime.datetime):
+            return self.images.index(value)
+        gaps = [abs(value - dt) for dt in self.datetimes]
+        nearest = min(range(len(gaps)), key=gaps.__getitem__)  # first of equally near images
+        if maxdt is not None and gaps[nearest] > abs(maxdt):
+            raise ValueError("Nearest image out of range by " + str(gaps[nearest] - abs(maxdt)))
+        return nearest
 
     def xyz_to_uv(self, xyz, img):
         """observer.py:102-113 (GPU projection)."""

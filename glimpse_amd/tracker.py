@@ -42,13 +42,25 @@ def _vector24(img):
     return img.cam.vector24 if hasattr(img, "cam") else img.vector24
 
 
-def _timestamps(dts):
-    return np.array([d.timestamp() for d in dts], dtype=float)
+_US = datetime.timedelta(microseconds=1)
 
 
-def pairwise_distance_datetimes(x, y):
-    """helpers.py:1831-1854: |x_i - y_j| in seconds."""
-    return np.abs(_timestamps(x)[:, None] - _timestamps(y)[None, :])
+def _offsets_us(dts, ref):
+    """Datetimes as exact integer microseconds from `ref` (timedelta arithmetic, no float timestamps)."""
+    return np.fromiter(((d - ref) // _US for d in dts), dtype=np.int64, count=len(dts))
+
+
+def nearest_in_sorted(times_us, queries_us):
+    """For every query the index of the nearest entry of the ascending `times_us` and its distance (microseconds).
+    One binary search per query (np.searchsorted) instead of the reference's len(queries) x len(times) distance
+    matrix (helpers.py:1831-1854); a tie goes to the earlier entry, like np.argmin over that matrix."""
+    times_us = np.asarray(times_us, dtype=np.int64)
+    queries_us = np.asarray(queries_us, dtype=np.int64)
+    right = np.clip(np.searchsorted(times_us, queries_us, side="left"), 0, len(times_us) - 1)
+    left = np.maximum(right - 1, 0)
+    d_left, d_right = np.abs(queries_us - times_us[left]), np.abs(times_us[right] - queries_us)
+    take_left = d_left <= d_right
+    return np.where(take_left, left, right), np.where(take_left, d_left, d_right)
 
 
 class Tracker:
@@ -89,34 +101,45 @@ class Tracker:
         self.templates = None
 
     def parse_datetimes(self, datetimes, maxdt=datetime.timedelta(0)):
-        """tracker.py:425-464."""
+        """Behaviour of tracker.py:425-464: the sequence must be monotone (either direction: backward tracking
+        passes decreasing datetimes), repeated datetimes and datetimes further than |maxdt| from every Observer
+        image are dropped with the reference's warnings, at least two must remain."""
         datetimes = np.asarray(datetimes)
-        monotonic = (datetimes[1:] >= datetimes[:-1]).all() or (datetimes[1:] <= datetimes[:-1]).all()
-        if not monotonic:
+        ref = datetimes[0] if len(datetimes) else None
+        t = _offsets_us(datetimes, ref) if len(datetimes) else np.zeros(0, dtype=np.int64)
+        steps = np.diff(t)
+        if (steps < 0).any() and (steps > 0).any():
             raise ValueError("Datetimes must be monotonic")
-        selected = np.concatenate(((True,), datetimes[1:] != datetimes[:-1]))
-        if not all(selected):
+        keep = np.ones(len(t), dtype=bool)
+        keep[1:] = steps != 0
+        if not keep.all():
             _warnings.warn("Dropping duplicate datetimes")
-            datetimes = datetimes[selected]
-        distances = pairwise_distance_datetimes(datetimes, self.datetimes)
-        selected = distances.min(axis=1) <= abs(maxdt.total_seconds())
-        if not all(selected):
+            datetimes, t = datetimes[keep], t[keep]
+        pool = np.sort(_offsets_us(self.datetimes, ref)) if len(t) else t
+        _, distance = nearest_in_sorted(pool, t)
+        keep = distance <= abs(maxdt // _US)
+        if not keep.all():
             _warnings.warn("Dropping datetimes not matching any Observers")
-            datetimes = datetimes[selected]
+            datetimes = datetimes[keep]
         if len(datetimes) < 2:
             raise ValueError("Fewer than two valid datetimes")
         return datetimes
 
     def match_datetimes(self, datetimes, maxdt=datetime.timedelta(0)):
-        """tracker.py:466-492."""
+        """tracker.py:466-492: (len(datetimes), len(observers)) object array, the index of each Observer's image
+        nearest to each datetime, None where it is further than |maxdt|."""
+        datetimes = np.asarray(datetimes)
         matches = np.full((len(datetimes), len(self.observers)), None)
-        for i, observer in enumerate(self.observers):
-            distances = pairwise_distance_datetimes(datetimes, observer.datetimes)
-            nearest_index = np.argmin(distances, axis=1)
-            matches[:, i] = nearest_index
-            nearest_distance = distances[np.arange(distances.shape[0]), nearest_index]
-            not_selected = nearest_distance > abs(maxdt.total_seconds())
-            matches[not_selected, i] = None
+        if not len(datetimes):
+            return matches
+        ref = datetimes[0]
+        t = _offsets_us(datetimes, ref)
+        limit = abs(maxdt // _US)
+        for o, observer in enumerate(self.observers):  # (Observer datetimes are strictly increasing)
+            index, distance = nearest_in_sorted(_offsets_us(observer.datetimes, ref), t)
+            column = index.astype(object)
+            column[distance > limit] = None
+            matches[:, o] = column
         return matches
 
     # ---- device context ---------------------------------------------------------------------

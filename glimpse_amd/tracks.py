@@ -86,20 +86,25 @@ class Tracks:
 
     @classmethod
     def from_multiple(cls, runs, ignore_nan=False):
-        """Merge runs over identical timesteps (tracks.py:151-191): per time step, the inverse-variance
-        weighted average of the runs' distributions, assumed uncorrelated."""
+        """Fuse several runs over the same timesteps (e.g. forward + backward; tracks.py:151-191): the product of
+        the runs' independent normal distributions per track, time and state component, i.e. precisions add,
+
+            mean = sum_r m_r / s_r^2 / sum_r 1 / s_r^2,    sigma = sqrt(sum_r (w_r s_r)^2),  w_r = s_r^-2 / sum s^-2
+
+        over the runs that have a value; the result is missing where any run (ignore_nan=False) or every run
+        (ignore_nan=True) is missing."""
         runs = list(runs)
-        datetimes = {tuple(run.datetimes) for run in runs}
-        if len(datetimes) != 1:
-            raise ValueError("Datetimes are not equal for all runs")
-        time_unit = {run.time_unit for run in runs}
-        if len(time_unit) != 1:
-            raise ValueError(f"Time units are not equal for all runs: {time_unit}")
-        means = np.stack([run.means for run in runs], axis=3)
-        sigmas = np.stack([run.sigmas for run in runs], axis=3)
-        means, sigmas = combine_normals(means, sigmas, weights=sigmas ** -2, normalize=True, correlation=0, axis=3,
+        head = runs[0]
+        for run in runs[1:]:
+            if len(run.datetimes) != len(head.datetimes) or any(a != b for a, b in zip(run.datetimes, head.datetimes)):
+                raise ValueError("Datetimes are not equal for all runs")
+            if run.time_unit != head.time_unit:
+                raise ValueError(f"Time units are not equal for all runs: {set(r.time_unit for r in runs)}")
+        m = np.stack([np.asarray(run.means, dtype=float) for run in runs], axis=-1)
+        sd = np.stack([np.asarray(run.sigmas, dtype=float) for run in runs], axis=-1)
+        means, sigmas = combine_normals(m, sd, weights=1.0 / (sd * sd), normalize=True, correlation=0, axis=m.ndim - 1,
                                         ignore_nan=ignore_nan)
-        return cls(datetimes=datetimes.pop(), time_unit=time_unit.pop(), means=means, sigmas=sigmas)
+        return cls(datetimes=head.datetimes, time_unit=head.time_unit, means=means, sigmas=sigmas)
 
     def average(self, ignore_nan=False):
         """Time-averaged mean and sigma of each track (tracks.py:193-213): inverse-variance weights,
@@ -107,37 +112,34 @@ class Tracks:
         return combine_normals(self.means, self.sigmas, weights=self.sigmas ** -2, normalize=True, correlation=1,
                                axis=1, ignore_nan=ignore_nan)
 
-    @property
-    def xyz(self):
-        return self.means[:, :, 0:3]
-
-    @property
-    def vxyz(self):
-        return self.means[:, :, 3:6]
-
-    @property
-    def xyz_sigma(self):
+    # ---- views of the state vector (x, y, z, vx, vy, vz) ----------------------------------------
+    def _spread(self, lo, hi):
+        """Standard deviations of components [lo, hi): `sigmas`, or the diagonal of `covariances`."""
         if self.sigmas is not None:
-            return self.sigmas[:, :, 0:3]
+            return self.sigmas[..., lo:hi]
         if self.covariances is not None:
-            return np.sqrt(self.covariances[:, :, (0, 1, 2), (0, 1, 2)])
+            return np.sqrt(np.diagonal(self.covariances, axis1=-2, axis2=-1)[..., lo:hi])
+        return None
 
-    @property
-    def vxyz_sigma(self):
-        if self.sigmas is not None:
-            return self.sigmas[:, :, 3:6]
-        if self.covariances is not None:
-            return np.sqrt(self.covariances[:, :, (3, 4, 5), (3, 4, 5)])
+    xyz = property(lambda self: self.means[..., 0:3], doc="positions (tracks, times, 3)")
+    vxyz = property(lambda self: self.means[..., 3:6], doc="velocities (tracks, times, 3)")
+    xyz_sigma = property(lambda self: self._spread(0, 3))
+    vxyz_sigma = property(lambda self: self._spread(3, 6))
 
     @property
     def endpoints(self):
-        valid = ~np.isnan(self.means[:, :, 0])
-        first = np.argmax(valid, axis=1)
-        last = valid.shape[1] - 1 - np.argmax(valid[:, ::-1], axis=1)
-        first_valid = valid[np.arange(len(first)), first]
-        return first_valid, first[first_valid], last[first_valid]
+        """tracks.py:116-123: (mask of the tracks with any valid time step, index of their first valid step, of
+        their last)."""
+        ok = ~np.isnan(self.means[..., 0])
+        has = ok.any(axis=1)
+        steps = np.arange(ok.shape[1])
+        first = np.where(ok, steps, ok.shape[1]).min(axis=1)
+        last = np.where(ok, steps, -1).max(axis=1)
+        return has, first[has], last[has]
 
     @property
     def success(self):
-        if self.errors is not None:
-            return np.array([error is None for error in self.errors])
+        """Per track: True where no error was recorded (None when the run kept no error list)."""
+        if self.errors is None:
+            return None
+        return np.fromiter((e is None for e in self.errors), dtype=bool, count=len(self.errors))

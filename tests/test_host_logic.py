@@ -219,3 +219,18 @@ def test_image_reads_files_like_arrays(tmp_path):
         glimpse_amd.Image(tmp_path / "g.png", cam=glimpse_amd.Camera(imgsz=(20, 15), f=100), datetime=T0).read()
     with pytest.raises(ValueError):
         glimpse_amd.Image(cam=cam, datetime=T0)
+
+
+def test_nearest_in_sorted_equals_the_distance_matrix_argmin():
+    """The searchsorted matcher picks what np.argmin over the reference's pairwise distance matrix picks
+    (helpers.py:1831-1854, tracker.py:479-484), ties included."""
+    from glimpse_amd.tracker import nearest_in_sorted
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        times = np.unique(rng.integers(0, 50, int(rng.integers(1, 12)))) * 1000
+        queries = rng.integers(-10, 60, int(rng.integers(1, 20))) * 500  # half-steps: exact ties
+        idx, dist = nearest_in_sorted(times, queries)
+        d = np.abs(queries[:, None] - times[None, :])
+        np.testing.assert_array_equal(idx, d.argmin(axis=1))
+        np.testing.assert_array_equal(dist, d.min(axis=1))
