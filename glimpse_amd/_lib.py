@@ -80,6 +80,8 @@ SIGNATURES = {
     "glh_get_point_error_frame": (_I, [_P, _P]),
     "glh_get_observer_status": (_I, [_P, _P]),
     "glh_get_search_boxes": (_I, [_P, _P]),
+    "glh_get_observer_status_frames": (_I, [_P, _I, _I, _P]),
+    "glh_get_point_state": (_I, [_P, _I, _P, _P]),
     "glh_set_frame": (_I, [_P, _I]),
     "glh_init_particles": (_I, [_P, _I, _P, _U64]),
     "glh_evolve": (_I, [_P, _D, _I, _P, _U64, _U64]),
@@ -314,6 +316,17 @@ class Context:
         out = np.empty((self.O, self.P), dtype=np.int32)
         check(self.lib.glh_get_observer_status(self.handle, _ptr(out)))
         return out
+
+    def observer_status_frames(self, frame0, n_frames):
+        out = np.empty((n_frames, self.O, self.P), dtype=np.int32)
+        check(self.lib.glh_get_observer_status_frames(self.handle, int(frame0), int(n_frames), _ptr(out)))
+        return out
+
+    def get_point_state(self, point):
+        """(particles (N, 6), weights (N,)) of one point."""
+        p, w = np.empty((self.N, 6)), np.empty(self.N)
+        check(self.lib.glh_get_point_state(self.handle, int(point), _ptr(p), _ptr(w)))
+        return p, w
 
     def search_boxes(self):
         out = np.empty((self.O, self.P, 4), dtype=np.int32)

@@ -120,7 +120,8 @@ struct glh_ctx {
   double* uj = nullptr;           // [P][N] host-fed per-particle uniforms (stratified / choice)
   uint8_t *obs_mask = nullptr, *active = nullptr;
   uint32_t* pt_status = nullptr;
-  int32_t *pt_err_frame = nullptr, *obs_status = nullptr, *box = nullptr, *idx = nullptr;
+  int32_t *pt_err_frame = nullptr, *box = nullptr, *idx = nullptr;
+  int32_t* obs_status_all = nullptr;  // [max_frames][O][P]: the per-(observer, point) status of every frame
   int32_t *tmpl_box = nullptr, *tmpl_hist_n = nullptr, *tmpl_valid = nullptr;
   double *tmpl_duv = nullptr, *tmpl_tile64 = nullptr, *tmpl_hist_v = nullptr, *tmpl_hist_q = nullptr;
   float *tmpl_tile32 = nullptr, *search = nullptr;
@@ -153,6 +154,11 @@ struct glh_ctx {
   // multi-GPU (glh_comm.h)
   Comm* comm = nullptr;
 };
+
+// status words [O][P] of the current frame
+static int32_t* cur_status(const glh_ctx* c) {
+  return c->obs_status_all + (size_t)c->frame * c->cfg.n_observers * c->P;
+}
 
 template <typename T>
 static int dalloc(T** p, size_t count) {
@@ -250,7 +256,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   for (auto& r : c->rasters) {
     dfree(r.z); dfree(r.gx); dfree(r.gy);
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
-  dfree(c->pt_err_frame); dfree(c->obs_status); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
+  dfree(c->pt_err_frame); dfree(c->obs_status_all); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
@@ -322,7 +328,7 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   A(dalloc(&c->active, P));
   A(dalloc(&c->pt_status, P));
   A(dalloc(&c->pt_err_frame, P));
-  A(dalloc(&c->obs_status, O * P));
+  A(dalloc(&c->obs_status_all, (size_t)k.max_frames * O * P));
   A(dalloc(&c->box, O * P * 4));
   A(dalloc(&c->tmpl_box, O * P * 4));
   A(dalloc(&c->tmpl_hist_n, O * P));
@@ -557,10 +563,9 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   HIPCHK(hipMemsetAsync(c->pt_err_frame, 0x7f, P * sizeof(int32_t), c->stream));
   HIPCHK(hipMemsetAsync(c->tmpl_valid, 0, O * P * sizeof(int32_t), c->stream));
   {
-    // GLH_OBS_SKIPPED everywhere
-    std::vector<int32_t> st(O * P, GLH_OBS_SKIPPED);
-    HIPCHK(hipMemcpyAsync(c->obs_status, st.data(), st.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // GLH_OBS_SKIPPED everywhere, for every frame
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->obs_status_all, GLH_OBS_SKIPPED, (size_t)c->cfg.max_frames * O * P,
+                             c->stream));
   }
   size_t nm = (size_t)c->cfg.max_frames * P * 12;
   hipLaunchKernelGGL(k_fill_f64, dim3(256), dim3(256), 0, c->stream, c->moments, nm, (double)NAN);
@@ -769,7 +774,23 @@ extern "C" int glh_get_point_error_frame(glh_ctx* c, int32_t* fr) {
 extern "C" int glh_get_observer_status(glh_ctx* c, int32_t* st) {
   CHK(need_seq(c));
   if (!st) return fail(GLH_E_INVALID, "status is null");
-  DOWNLOAD(st, c->obs_status, (size_t)c->cfg.n_observers * c->P, int32_t);
+  DOWNLOAD(st, cur_status(c), (size_t)c->cfg.n_observers * c->P, int32_t);
+  return GLH_OK;
+}
+extern "C" int glh_get_observer_status_frames(glh_ctx* c, int frame0, int n_frames, int32_t* st) {
+  CHK(need_seq(c));
+  if (!st || frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames)
+    return fail(GLH_E_INVALID, "bad frame range");
+  const size_t per = (size_t)c->cfg.n_observers * c->P;
+  DOWNLOAD(st, c->obs_status_all + (size_t)frame0 * per, (size_t)n_frames * per, int32_t);
+  return GLH_OK;
+}
+extern "C" int glh_get_point_state(glh_ctx* c, int point, double* particles, double* weights) {
+  CHK(need_seq(c));
+  CHK(ensure_expanded(c));
+  if (point < 0 || point >= c->P) return fail(GLH_E_INVALID, "point %d out of range", point);
+  if (particles) DOWNLOAD(particles, c->particles[c->cur] + (size_t)point * c->N * 6, (size_t)c->N * 6, double);
+  if (weights) DOWNLOAD(weights, c->weights[c->cur] + (size_t)point * c->N, (size_t)c->N, double);
   return GLH_OK;
 }
 extern "C" int glh_get_log_likelihoods(glh_ctx* c, int o, double* ll) {
@@ -994,7 +1015,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
   for (int o = 0; o < O; ++o) {
     if (images[o] < 0) {
       // no image for this observer at this frame (tracker.py:577): the status must not keep the previous frame's
-      HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(c->obs_status + (size_t)o * c->P), GLH_OBS_SKIPPED, (size_t)c->P,
+      HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(cur_status(c) + (size_t)o * c->P), GLH_OBS_SKIPPED, (size_t)c->P,
                                c->stream));
       continue;
     }
@@ -1017,7 +1038,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.tmpl_hist_q = c->tmpl_hist_q;
     tp.tmpl_hist_n = c->tmpl_hist_n;
     tp.box = c->box;
-    tp.obs_status = c->obs_status;
+    tp.obs_status = cur_status(c);
     tp.search = c->search;
     {
       StageTimer t(c, ST_TILEPREP);
@@ -1034,7 +1055,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     sa.search_cap = c->search_cap;
     sa.sse_cap = c->sse_cap;
     sa.box = c->box;
-    sa.obs_status = c->obs_status;
+    sa.obs_status = cur_status(c);
     sa.search = c->search;
     sa.tmpl = c->tmpl_tile32;
     sa.sse = c->sse;
@@ -1051,7 +1072,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     sf.sse_cap = c->sse_cap;
     sf.max_n = c->cfg.max_search_dim;
     sf.box = c->box;
-    sf.obs_status = c->obs_status;
+    sf.obs_status = cur_status(c);
     sf.lu = c->lu;
     sf.lu_off = c->lu_off;
     sf.inv = c->spl_inv;
@@ -1080,7 +1101,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.active = c->have_active ? c->active : nullptr;
   wa.uv = c->uv;
   wa.box = c->box;
-  wa.obs_status = c->obs_status;
+  wa.obs_status = cur_status(c);
   wa.tmpl_duv = c->tmpl_duv;
   wa.coef = c->sse;
   wa.poly = c->poly;
@@ -1252,7 +1273,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.u = c->u;
   a.uv = c->uv;
   a.box = c->box;
-  a.obs_status = c->obs_status;
+  a.obs_status = cur_status(c);
   a.tmpl_valid = c->tmpl_valid;
   a.tmpl_duv = c->tmpl_duv;
   a.tmpl_tile32 = c->tmpl_tile32;
@@ -1551,7 +1572,7 @@ extern "C" int glh_get_likelihood_debug(glh_ctx* c, int o, int pt, double* uv, i
   if (pt < 0 || pt >= c->P) return fail(GLH_E_INVALID, "point %d out of range", pt);
   const size_t slot = (size_t)o * c->P + pt;
   int32_t st = 0;
-  DOWNLOAD(&st, c->obs_status + slot, 1, int32_t);
+  DOWNLOAD(&st, cur_status(c) + slot, 1, int32_t);
   if (uv) DOWNLOAD(uv, c->uv + slot * c->N * 2, (size_t)c->N * 2, double);
   if (st != GLH_OBS_OK) {
     if (box) box[0] = box[1] = box[2] = box[3] = -1;

@@ -63,6 +63,24 @@ def nearest_in_sorted(times_us, queries_us):
     return np.where(take_left, left, right), np.where(take_left, d_left, d_right)
 
 
+def _parallel_worker(job):
+    """One worker process of Tracker.track(parallel=N): its own Tracker / context on its GPU, its block of tracks."""
+    tracker = Tracker(job["observers"], viewshed=job["viewshed"], resample_method=job["resample_method"],
+                      device=job["device"], max_search_dim=job["max_search_dim"])
+    if job["np_seed"] is not None:
+        np.random.seed(int(job["np_seed"]))
+    t = tracker.track(job["models"], _catch_errors=job["catch"], **job["kw"])
+    out = {k: getattr(t, k) for k in ("datetimes", "time_unit", "means", "sigmas", "covariances", "particles", "weights",
+                                      "images")}
+    out["errors"] = list(t.errors)
+    out["warnings"] = list(t.warnings)
+    out["reduced"] = getattr(t, "reduced", None)
+    out["last_particles"], out["last_weights"] = tracker.particles, tracker.weights
+    if tracker._ctx is not None:
+        tracker._ctx.close()
+    return out
+
+
 class Tracker:
     def __init__(self, observers, viewshed=None, resample_method="systematic", highpass={"size": (5, 5)},  # noqa: B006
                  interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=320):  # noqa: B006
@@ -224,6 +242,12 @@ class Tracker:
         self.reset()
         ntracks = len(motion_models)
         raise_errors = ntracks < 2 if _catch_errors is None else not _catch_errors
+        workers = self._parse_parallel(parallel, ntracks)
+        if workers > 1:
+            return self._track_parallel(workers, motion_models, params, datetimes=datetimes, maxdt=maxdt,
+                                        tile_size=tile_size, observer_mask=observer_mask,
+                                        return_covariances=return_covariances, return_particles=return_particles,
+                                        reduce_particles=reduce_particles, rng=rng, seed=seed, point_offset=point_offset)
         n = motion_models[0].n
         if any(m.n != n for m in motion_models):
             # Motion models with different particle counts (each track of the reference has its own n,
@@ -290,8 +314,7 @@ class Tracker:
                 w.clear()
             out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None
             out_w = np.full((ntracks, ntimes, n), np.nan) if return_particles else None
-            def note_skips(i, running):
-                status = ctx.observer_status()
+            def note_skips(running, status):
                 for o in range(nobs):
                     for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
                         warn_log[p].append(UserWarning(_OOB_WARNING))
@@ -299,20 +322,37 @@ class Tracker:
                         warn_log[p].append(RuntimeWarning(
                             f"search tile exceeds max_search_dim={self.max_search_dim}; observer {o} skipped"))
 
-            for i in range(lo, hi + 1):
+            def common(i):
+                """Every track is running and no template starts at frame i: ONE fused launch does evolve +
+                likelihood + resample + moments (glh_step)."""
+                return (uniform and systematic and bool(((first < i) & (i <= last)).all())
+                        and not (template_indices == i).any())
+
+            i = lo
+            while i <= hi:
                 ctx.set_frame(i)
                 starting = (first == i) & ~empty
                 running = (first < i) & (i <= last)
                 window = starting | running
-                if uniform and running.all() and not (template_indices == i).any() and systematic:
-                    # the common frame: every track is running and no template starts here ->
-                    # ONE fused launch for evolve + likelihood + resample + moments (glh_step)
+                if common(i):
                     set_active(window)
+                    if draws is None and not return_covariances and not return_particles:
+                        # device RNG: the whole run of common frames in one call (glh_track: the launches are
+                        # enqueued back to back, no host round trip per frame); every frame keeps its own status
+                        # words, so the per-frame warnings are read afterwards
+                        j = i
+                        while j + 1 <= hi and common(j + 1):
+                            j += 1
+                        ctx.track(list(range(i, j + 1)), taus[i - 1:j], [images_of(k) for k in range(i, j + 1)], seed=seed)
+                        for status in ctx.observer_status_frames(i, j - i + 1):
+                            note_skips(running, status)
+                        i = j + 1
+                        continue
                     if draws is None:
                         ctx.step(i, taus[i - 1], images_of(i), seed=seed)
                     else:
                         ctx.step(i, taus[i - 1], images_of(i), normals=draws["evolve"][i], u=draws["u"][i])
-                    note_skips(i, running)
+                    note_skips(running, ctx.observer_status())
                 else:
                     if starting.any():
                         set_active(starting)
@@ -333,7 +373,7 @@ class Tracker:
                     if running.any():
                         set_active(running)
                         ctx.update_weights(images_of(i))
-                        note_skips(i, running)
+                        note_skips(running, ctx.observer_status())
                         if draws is None:
                             ctx.resample(seed=seed, step=i, method=method)
                         else:
@@ -347,6 +387,7 @@ class Tracker:
                     P_, W_ = ctx.get_particles(), ctx.get_weights()
                     out_p[window, i] = P_[window]
                     out_w[window, i] = W_[window]
+                i += 1
             return out_p, out_w, ctx.point_status(), ctx.point_error_frame()
 
         if rng == "philox":
@@ -399,8 +440,7 @@ class Tracker:
         if raise_errors and errors[0] is not None:
             raise errors[0]
         # single-track state, like the reference leaves it after the last track
-        self.particles = ctx.get_particles()[-1]
-        self.weights = ctx.get_weights()[-1]
+        self.particles, self.weights = ctx.get_point_state(ntracks - 1)
         kwargs = dict(time_unit=time_unit, datetimes=datetimes, means=means,
                       sigmas=None if return_covariances else sigmas, covariances=covariances,
                       particles=None if reduce_particles else out_particles,
@@ -410,6 +450,65 @@ class Tracker:
         tracks = Tracks(**kwargs)
         if reduce_particles:
             tracks.reduced = [reduce_particles(out_particles[p], out_weights[p]) for p in range(ntracks)]
+        return tracks
+
+    # ---- parallel=N: N worker processes, one GPU each (the reference's process pool, tracker.py:381-387) ----------
+    @staticmethod
+    def _parse_parallel(parallel, ntracks):
+        """helpers._parse_parallel (helpers.py:2008-2017) with GPUs for CPUs: True = one worker per visible GPU, an
+        int = that many workers (they share GPUs round-robin when there are fewer), False / 0 / 1 = this process."""
+        if parallel is True:
+            n = _lib.device_count()
+        elif not parallel:
+            n = 0
+        else:
+            n = int(parallel)
+        return max(0, min(n, ntracks))
+
+    def _track_parallel(self, workers, motion_models, params, observer_mask=None, rng="numpy", seed=0, point_offset=0,
+                        **kw):
+        """Tracks are independent (the reference maps `process` over them, tracker.py:381-387): contiguous blocks of
+        tracks go to `workers` freshly started processes, each with its own context on GPU (worker mod device
+        count) and `point_offset` = its first track, so a device-RNG run draws exactly what the single-process run
+        draws.  The results come back in track order.  With rng="numpy" every worker gets its own np.random seed
+        (drawn here from the global stream): like the reference's pool, a parallel run is not stream-compatible
+        with a serial one."""
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+
+        from . import sharding
+
+        ntracks = len(motion_models)
+        ndev = max(1, _lib.device_count())
+        mask = None if observer_mask is None else np.asarray(observer_mask, dtype=bool)
+        seeds = np.random.randint(0, 2 ** 31 - 1, size=workers) if rng == "numpy" else [None] * workers
+        jobs = []
+        for w in range(workers):
+            a, b = sharding.shard_range(ntracks, workers, w)
+            if a == b:
+                continue
+            jobs.append(dict(observers=self.observers, viewshed=self.viewshed, resample_method=self.resample_method,
+                             device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
+                             np_seed=seeds[w], catch=ntracks >= 2,
+                             kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
+                                     point_offset=point_offset + a)))
+        with ProcessPoolExecutor(max_workers=len(jobs), mp_context=mp.get_context("spawn")) as pool:
+            parts = list(pool.map(_parallel_worker, jobs))
+
+        def cat(name):
+            values = [part[name] for part in parts]
+            return None if values[0] is None else [row for v in values for row in v]
+
+        errors = cat("errors")
+        if ntracks < 2 and errors[0] is not None:
+            raise errors[0]
+        self.particles, self.weights = parts[-1]["last_particles"], parts[-1]["last_weights"]
+        tracks = Tracks(datetimes=parts[0]["datetimes"], time_unit=parts[0]["time_unit"], means=cat("means"),
+                        sigmas=cat("sigmas"), covariances=cat("covariances"), particles=cat("particles"),
+                        weights=cat("weights"), tracker=self, images=parts[0]["images"], params=params, errors=errors,
+                        warnings=cat("warnings"))
+        if kw.get("reduce_particles"):
+            tracks.reduced = [r for part in parts for r in part["reduced"]]
         return tracks
 
     def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0, **kw):

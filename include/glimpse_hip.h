@@ -186,7 +186,14 @@ int glh_get_point_status(glh_ctx* ctx, uint32_t* status);    /* [P]    GLH_PT_* 
  * value if none: the reference aborts the track there, so rows >= this frame are NaN
  * (track/tracker.py:360-368).                                                               */
 int glh_get_point_error_frame(glh_ctx* ctx, int32_t* frames); /* [P] */
-int glh_get_observer_status(glh_ctx* ctx, int32_t* status);  /* [O][P] GLH_OBS_*            */
+int glh_get_observer_status(glh_ctx* ctx, int32_t* status);
+/* The same for frames [frame0, frame0 + n_frames): status [n_frames][O][P] (every frame of a sequence keeps its own
+ * status words, so a run of glh_track frames can be inspected afterwards: one warning per skipped image and track,
+ * tracker.py:597-601).                                                                                      */
+int glh_get_observer_status_frames(glh_ctx* ctx, int frame0, int n_frames, int32_t* status);
+/* Particles [N][6] and weights [N] of ONE point (either may be NULL): what the reference's Tracker.particles /
+ * .weights hold after the last track (tracker.py:35-37).                                                       */
+int glh_get_point_state(glh_ctx* ctx, int point, double* particles, double* weights);  /* [O][P] GLH_OBS_*            */
 /* Search boxes (l,t,r,b) of the last glh_update_weights (tracker.py:595): [O][P][4];
  * entries whose observer status is not GLH_OBS_OK are stale.                                */
 int glh_get_search_boxes(glh_ctx* ctx, int32_t* boxes);

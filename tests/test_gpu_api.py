@@ -449,3 +449,31 @@ def test_ragged_particle_counts_reproduce_reference(golden):
     assert [r[0][1] for r in tracks.reduced] == list(g["reduced_n"])
     np.testing.assert_allclose([r[1] for r in tracks.reduced], g["reduced_w"], rtol=RTOL)
     assert tracks.particles is None and tracks.params["motion_models"] is models
+
+
+def test_parallel_workers_reproduce_the_single_process_run(golden):
+    """Tracker.track(parallel=N) (tracker.py:236, :381-387): N worker processes, each with its own context and its
+    contiguous block of tracks.  The device RNG is keyed on the global track index, so the parallel run IS the
+    single-process run, value for value; warnings, errors and the NaN rows of a failing track come back in order."""
+    g = golden("g8_c2mini.npz")
+    tile = tuple(int(v) for v in g["tile_size"])
+    models = models_from(g)  # the 4th starts outside the image
+    tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        serial = tracker.track(models, tile_size=tile, rng="philox", seed=5)
+        last_p, last_w = tracker.particles.copy(), tracker.weights.copy()
+        for n in (2, 3):
+            par = tracker.track(models, tile_size=tile, rng="philox", seed=5, parallel=n)
+            np.testing.assert_array_equal(par.means, serial.means)
+            np.testing.assert_array_equal(par.sigmas, serial.sigmas)
+            assert [type(e) for e in par.errors] == [type(e) for e in serial.errors]
+            assert isinstance(par.errors[3], IndexError) and np.isnan(par.means[3]).all()
+            assert par.params["parallel"] == n and par.means.shape == serial.means.shape
+            np.testing.assert_array_equal(tracker.particles, last_p)
+            np.testing.assert_array_equal(tracker.weights, last_w)
+        # host-fed draws: each worker consumes its own np.random stream -- a valid filter run, not the serial stream
+        np.random.seed(3)
+        par = tracker.track(models[:3], tile_size=tile, parallel=True)  # True = one worker per GPU (here: one)
+        assert np.isfinite(par.means).all() and abs(np.median(par.means[:, -1, 3]) - 0.15) < 0.05
+    assert glimpse_amd.Tracker._parse_parallel(False, 10) == 0 and glimpse_amd.Tracker._parse_parallel(8, 3) == 3
