@@ -427,8 +427,10 @@ __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-// SURF: the context holds gridded surfaces (dem / dem_sigma / viewshed rasters); compiled out otherwise so
-// that the common constant-surface kernel carries none of their registers.
+// SURF: the general instantiation -- gridded surfaces (dem / dem_sigma / viewshed rasters) and every motion model
+// (Cartesian, Cylindrical and the tangent models that follow the surface, motion.py:92-522; the kind is a property of
+// the point, hence uniform in its workgroup).  The common instantiation (!SURF) evolves CartesianMotion over constant
+// surfaces only and carries none of the other code or its registers.
 // FAST: fast arithmetic (GLH_MATH_FAST, glh_math.h): fused multiply-adds, Newton reciprocals, table exp, and a
 // resampling that scans the raw weights and scales the positions instead of normalising (no NumPy-exact sum tree).
 template <int TB, int PPT, int MINW, int NOBS, bool SURF, bool FAST>
@@ -536,6 +538,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   };
   __syncthreads();
 
+  // (the tangent models have no log-likelihood term: Motion.compute_log_likelihoods returns None, tracker.py:146)
+  const bool motion_term = !SURF || (int)s_m[18] <= GLH_MOTION_CYLINDRICAL;  // uniform
   const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
   // A record is three 16-byte chunks.  One record per particle (what every other kernel reads and writes): chunk c
   // of record r at 3 r + c.  Compact (this kernel's own output): PLANAR, chunk c of record r at c N + r, so that
@@ -549,7 +553,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
-    evolve_cartesian_m<FAST>(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
+    if constexpr (SURF) {
+      bool oob = false;  // (flagged by phase A, which evolved the same particle)
+      evolve_particle<false>(x, m, n, tau, tau2, a.surf, &oob);
+    } else {
+      evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
+    }
   };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
@@ -570,8 +579,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     bool bad = false, raster_oob = false;
     uint32_t view_bits = 0u;
-    const double zs = m[17];
-    const bool gridded = SURF && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
+    const double zs = motion_term ? m[17] : 0.0;
+    const bool gridded = SURF && motion_term && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // record of every particle (compact input state): staged in region 2, which is free until phase B
@@ -602,14 +611,17 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       if (i < N) {
         double n[3];
         evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
-        evolve_cartesian_m<FAST>(x, m, n, tau, tau2);  // glh_step takes this kernel only when every point is CartesianMotion
+        if constexpr (SURF)
+          evolve_particle<false>(x, m, n, tau, tau2, a.surf, &raster_oob);
+        else
+          evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
         if (i == 0) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) s_K[k] = x[k];
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
-        if (a.has_dem) {
+        if (a.has_dem && motion_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
           if (SURF && gridded) {
@@ -920,14 +932,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     __syncthreads();  // region 2 is free for the next observer
   }
-  if (!c_ready)
-    for (int i = tid; i < N; i += TB) c[i] = 0.0;  // every observer skipped (same-thread indices)
+  if (!c_ready) {  // every observer skipped (same-thread indices)
+    if (SURF && !motion_term) {
+      // ... and the motion model has no term either: update_weights leaves the weights as they are
+      // (tracker.py:146-149); they are the input weights, one per input record
+      for (int i = tid; i < N; i += TB) c[i] = W[uin ? (int)uin[i] : i];
+      w_done = true;
+      __syncthreads();
+    } else {
+      for (int i = tid; i < N; i += TB) c[i] = 0.0;
+    }
+  }
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
   if (!w_done) {
     for (int i = tid; i < N; i += TB) {
       double ll = c[i];
-      if (a.has_dem) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
+      if (a.has_dem && motion_term) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
       c[i] = weight_of<FAST>(ll, tab32);  // the weights stay in LDS until the gather of phase E
     }
     __syncthreads();

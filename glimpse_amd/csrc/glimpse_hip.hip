@@ -104,7 +104,7 @@ struct glh_ctx {
   bool have_mask = false, have_active = false, keep_sse = false, keep_idx = false, has_dem = false;
   int fused = 1;    // glh_step: 0 staged kernels, 1 fused per-point kernel, 2 fused with tiles forced to HBM (test)
   int pt_base = 0;  // global index of this context's point 0
-  bool all_cartesian = true;  // every point is CartesianMotion (what the fused kernel evolves)
+  bool all_cartesian = true;  // every point is CartesianMotion (the common fused instantiation; else the general one)
   bool fast_math = false;     // GLH_MATH_FAST (glh_set_math)
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
@@ -636,9 +636,10 @@ static int ensure_expanded(glh_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
 
-// Fast arithmetic is in force for constant-surface contexts (the gridded-surface kernels are exact only).
+// Fast arithmetic is in force for CartesianMotion over constant surfaces (the general kernels -- gridded surfaces, the
+// other motion models -- are exact only).
 static bool use_fast(const glh_ctx* c) {
-  return c->fast_math && !(c->rasters[0].z || c->rasters[1].z || c->rasters[2].z);
+  return c->fast_math && c->all_cartesian && !(c->rasters[0].z || c->rasters[1].z || c->rasters[2].z);
 }
 
 static Surfaces surfaces(const glh_ctx* c) {
@@ -1226,7 +1227,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
 
 static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   const int O = c->cfg.n_observers;
-  if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE || !c->all_cartesian) return false;
+  if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {
@@ -1345,7 +1346,8 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
     if (big && ppt == 4) ppt = 10;
     if (getenv("GLH_PT_UVLDS")) ppt = 0;
-    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z;
+    // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
+    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian;
     const bool fast = use_fast(c);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \

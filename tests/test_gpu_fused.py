@@ -283,3 +283,80 @@ def test_fused_step_with_gridded_surfaces_equals_staged(lib):
     np.testing.assert_allclose(fused["m"], staged["m"], rtol=1e-12, atol=1e-13)
     # the DEM term acts: z stays near the surface (sigma ~0.3) although vz noise accumulates
     assert np.abs(fused["m"][-1, 0, 2]) < 1.0
+
+
+@pytest.mark.parametrize("gridded", [False, True])
+def test_fused_step_evolves_every_motion_model_like_the_staged_kernels(gridded):
+    """CylindricalMotion and the tangent models (motion.py:207-522) in the fused kernel's general instantiation: one
+    context mixing all four kinds (the kind is a per-point parameter), constant and gridded surfaces, a frame on
+    which no observer has an image (the tangent models have no log-likelihood term either: the weights stay as they
+    are, tracker.py:146-149) -- bit for bit the staged kernels, host-fed draws and device draws."""
+    import glimpse_amd
+    from glimpse_amd import _lib as lib
+    from glimpse_amd import workloads
+
+    T, P, N = 5, 8, 1500
+    wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+    frames = [wl.frames(0)]
+    rng = np.random.default_rng(4)
+    lim = (-40.0, 40.0)
+    dem = glimpse_amd.Raster(0.05 * rng.standard_normal((33, 41)), x=lim, y=(40.0, -40.0))
+    dem_sigma = glimpse_amd.Raster(0.3 + 0.1 * rng.random((17, 19)), x=lim, y=lim)
+    params = np.zeros((P, lib.MOTION_FULL_LEN))
+    params[:, :18] = wl.params
+    params[:, 18] = np.arange(P) % 4  # cartesian, cylindrical, tangent cartesian, tangent cylindrical, ...
+    params[:, 19] = 0.05              # slope_sigma of the tangent models
+    params[:, 17] = 0.4               # constant dem_sigma (the Cartesian / Cylindrical likelihood term)
+    for p in range(P):
+        if params[p, 18] in (1, 3):   # (vr, theta, vz) instead of (vx, vy, vz)
+            params[p, 4:7] = (0.15, 0.0, 0.0)
+            params[p, 7:10] = (0.05, 0.3, 0.02)
+            params[p, 13:16] = (0.02, 0.05, 0.005)
+        else:
+            params[p, 7:10] = (0.2, 0.2, 0.02)
+            params[p, 13:16] = (0.05, 0.05, 0.005)
+    if gridded:
+        params[:, 20] = 1.0
+        params[:, 21] = 1.0
+    images = [[1], [2], [-1], [4]]    # frame 3: no image
+    host = np.random.default_rng(12)
+    init, ev, us = host.standard_normal((P, N, 6)), host.standard_normal((T - 1, P, N, 3)), host.random((T - 1, P))
+    for device_rng in (False, True):
+        out = []
+        for mode in (1, 0):
+            with lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
+                workloads.setup_context(ctx, wl, frames)
+                if gridded:
+                    ctx.set_raster(lib.RASTER_DEM, dem)
+                    ctx.set_raster(lib.RASTER_DEM_SIGMA, dem_sigma)
+                ctx.set_motion(params)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=8) if device_rng else ctx.init_particles(normals=init)
+                ctx.init_templates(0, 0)
+                ctx.record_moments(0)
+                ctx.profile_enable(True)
+                idx = []
+                for i in range(1, T):
+                    if device_rng:
+                        ctx.step(i, 1.0, images[i - 1], seed=8)
+                    else:
+                        ctx.step(i, 1.0, images[i - 1], normals=ev[i - 1], u=us[i - 1])
+                    idx.append(ctx.resample_indices())
+                stages = {k for k, v in ctx.profile_get().items() if v[1] > 0}
+                assert ("point_step" in stages) == (mode == 1) and ("resample" in stages) == (mode == 0)
+                out.append(dict(p=ctx.get_particles(), w=ctx.get_weights(), st=ctx.point_status(), idx=np.stack(idx),
+                                m=ctx.get_moments(0, T), obs=ctx.observer_status_frames(1, T - 1)))
+        fused, staged = out
+        assert (staged["st"] == 0).all()
+        np.testing.assert_array_equal(fused["st"], staged["st"])
+        np.testing.assert_array_equal(fused["obs"], staged["obs"])
+        assert (fused["obs"][2] == lib.OBS_SKIPPED).all() and (fused["obs"][3] == lib.OBS_OK).all()
+        np.testing.assert_array_equal(fused["idx"], staged["idx"])
+        np.testing.assert_array_equal(fused["p"], staged["p"])
+        np.testing.assert_array_equal(fused["w"], staged["w"])
+        np.testing.assert_allclose(fused["m"], staged["m"], rtol=1e-11, atol=1e-12)
+        # tangent models leave vz = 0 and follow the surface
+        tangent = params[:, 18] >= 2
+        assert (fused["p"][tangent][..., 5] == 0).all()
