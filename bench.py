@@ -67,6 +67,10 @@ def parse_args(argv=None):
                     help="processes of the parallel CPU baseline (the reference's parallel=True = os.cpu_count(), "
                          "helpers.py:2008-2011); 0 = every core this process may use, 1 disables it")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--motion", default="cartesian",
+                    choices=["cartesian", "cylindrical", "tangent_cartesian", "tangent_cylindrical"],
+                    help="motion model of every tracked point (motion.py:92-522); the configurations of BASELINE.json "
+                         "use CartesianMotion, real glacier runs TangentCartesianMotion")
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
@@ -407,6 +411,16 @@ def worker(args):
     workloads.setup_context(ctx, wl, frames)
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
+    if args.motion != "cartesian":
+        full = np.zeros((wl.P, _lib.MOTION_FULL_LEN))
+        full[:, :_lib.MOTION_LEN] = wl.params
+        full[:, 18] = _lib.MOTION_KINDS[args.motion]
+        full[:, 19] = 0.05  # slope_sigma (tangent models)
+        if "cylindrical" in args.motion:  # (speed, direction, dz/dt) and their sigmas
+            full[:, 4:7] = (workloads.VELOCITY[0], 0.0, 0.0)
+            full[:, 7:10] = (workloads.SIGMA, 0.5, 0.0)
+            full[:, 13:16] = (workloads.SIGMA / 4, 0.1, 0.0)
+        ctx.set_motion(full)
     ctx.set_point_offset(point_offset)
     ctx.set_math(args.math)
     transport = group.attach(ctx, args.transport)
@@ -502,7 +516,8 @@ def worker(args):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": dict(wl.describe(), rng="device Philox4x32-7", math=args.math, parallelism=f"points sharded x{world}",
+            "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
+                           math=args.math if args.motion == "cartesian" else "exact (general kernel)", parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F,
                            timed_from="the prior (frame 0 initialises, every later frame is a timed step)" if B == 0
                            else f"after {B} untimed updates"),

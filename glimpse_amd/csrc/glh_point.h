@@ -807,8 +807,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           for (int i = tid; i < N; i += TB) c[i] = 0.0;
           c_ready = true;
         }
+        // (the next particle's uv is on its way from the scratch while this one is sampled)
+        double2 qn = uvp[tid < N ? tid : 0];
         for (int i = tid; i < N; i += TB) {
-          const double2 q = uvp[i];
+          const double2 q = qn;
+          qn = uvp[i + TB < N ? i + TB : 0];
           if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           c[i] += spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
         }
@@ -946,9 +949,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(5);
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
   if (!w_done) {
+    const bool mterm = a.has_dem && motion_term;  // uniform
+    double wn = mterm ? W[tid < N ? tid : 0] : 0.0;
     for (int i = tid; i < N; i += TB) {
       double ll = c[i];
-      if (a.has_dem && motion_term) ll += W[i];  // the motion model's term is appended last (tracker.py:143)
+      const double wi = wn;
+      if (mterm) wn = W[i + TB < N ? i + TB : 0];
+      if (mterm) ll += wi;  // the motion model's term is appended last (tracker.py:143)
       c[i] = weight_of<FAST>(ll, tab32);  // the weights stay in LDS until the gather of phase E
     }
     __syncthreads();

@@ -117,11 +117,13 @@ class Workload:
     def frames(self, obs):
         return [self.frame(obs, t) for t in range(self.T)]
 
-    def describe(self):
+    def describe(self, motion="cartesian"):
+        name = {"cartesian": "CartesianMotion", "cylindrical": "CylindricalMotion",
+                "tangent_cartesian": "TangentCartesianMotion", "tangent_cylindrical": "TangentCylindricalMotion"}[motion]
         return {
             "workload": f"{self.name}: {self.P} points x {self.N} particles x {self.T} frames "
                         f"{self.imgsz[0]}x{self.imgsz[1]} uint8, tile {self.tile[0]}x{self.tile[1]}, "
-                        f"{self.O} observer(s), CartesianMotion, radial k={tuple(self.cfg['k'])}",
+                        f"{self.O} observer(s), {name}, radial k={tuple(self.cfg['k'])}",
             "points_per_gpu": self.P,
             "particles": self.N,
             "frames": self.T,
