@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GLH_LIB") or os.path.join(HERE, "lib", "libglimpse_hi
 CAM_LEN = 24
 MOTION_LEN = 18
 MOTION_FULL_LEN = 24
-MOTION_KINDS = {"cartesian": 0, "cylindrical": 1, "tangent_cartesian": 2, "tangent_cylindrical": 3}
+MOTION_KINDS = {"cartesian": 0, "cylindrical": 1, "tangent_cartesian": 2, "tangent_cylindrical": 3, "external": 4}
 RNG_HOST, RNG_PHILOX = 0, 1
 MATH_EXACT, MATH_FAST = 0, 1
 RESAMPLE = {"systematic": 0, "stratified": 1, "choice": 2, "residual": 3}
@@ -76,6 +76,7 @@ SIGNATURES = {
     "glh_get_particles": (_I, [_P, _P]),
     "glh_set_weights": (_I, [_P, _P]),
     "glh_get_weights": (_I, [_P, _P]),
+    "glh_set_extra_log_likelihoods": (_I, [_P, _P]),
     "glh_get_point_status": (_I, [_P, _P]),
     "glh_get_point_error_frame": (_I, [_P, _P]),
     "glh_get_observer_status": (_I, [_P, _P]),
@@ -296,6 +297,11 @@ class Context:
     def set_weights(self, w):
         w = _arr(w, np.float64, (self.P, self.N))
         check(self.lib.glh_set_weights(self.handle, _ptr(w)))
+
+    def set_extra_log_likelihoods(self, ll):
+        """A caller-computed log-likelihood term [P][N] for the next update_weights calls (None removes it)."""
+        a = None if ll is None else _arr(ll, np.float64, (self.P, self.N))
+        check(self.lib.glh_set_extra_log_likelihoods(self.handle, _ptr(a)))
 
     def get_weights(self):
         out = np.empty((self.P, self.N))

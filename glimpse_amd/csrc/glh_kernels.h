@@ -222,6 +222,7 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
     evolve_cartesian_m<FAST>(p, m, n, tau, tau2);
     return;
   }
+  if (kind == GLH_MOTION_EXTERNAL) return;  // evolved by the caller (a user-defined Motion): nothing to do here
   const bool cyl = kind == GLH_MOTION_CYLINDRICAL || kind == GLH_MOTION_TANGENT_CYLINDRICAL;
   const bool tangent = kind >= GLH_MOTION_TANGENT_CARTESIAN;
   double a[3];
@@ -1153,6 +1154,8 @@ struct WeightArgs {
   const double* coef;
   const double* poly;  // [GLH_NPOLY][16] basis polynomials (glh_host.h)
   double* ll_out;      // optional [O][P][N] per-observer log likelihoods (debug), NaN = skipped
+  const double* extra; // optional [P][N] log-likelihood term computed by the caller (a user-defined Motion's
+                       // compute_log_likelihoods, motion.py:74-89), appended like the built-in one (tracker.py:143)
   uint32_t* pt_status;
   int32_t* pt_err_frame;
   double inv2s2[MAX_OBS];  // 1 / (2 sigma^2)
@@ -1196,7 +1199,8 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   bool any_obs = false;  // uniform across the block
   for (int o = 0; o < a.O; ++o)
     any_obs |= a.on[o] && a.obs_status[(size_t)o * a.P + pt] == GLH_OBS_OK;
-  if (!has_motion_term && !any_obs && !a.ll_out) return;  // every term is None: weights unchanged (tracker.py:146)
+  const bool has_extra = a.extra != nullptr;
+  if (!has_motion_term && !has_extra && !any_obs && !a.ll_out) return;  // every term is None: weights unchanged (tracker.py:146)
   for (int it = 0; it < WEIGHTS_PER_THREAD; ++it) {
     const int i = (blockIdx.x * WEIGHTS_PER_THREAD + it) * BLK + threadIdx.x;
     if (i >= a.N) break;
@@ -1228,7 +1232,8 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       double d = m[16] - z;
       ll += dem_scale * (d * d);
     }
-    if (has_motion_term || any_obs)
+    if (has_extra) ll += a.extra[(size_t)pt * a.N + i];
+    if (has_motion_term || has_extra || any_obs)
       a.weights[(size_t)pt * a.N + i] = a.fast ? weight_of<true>(ll, tab32) : weight_of<false>(ll, tab32);
   }
   if (oob) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RASTER_OOB, a.frame);

@@ -118,6 +118,8 @@ struct glh_ctx {
   } rasters[3];  // GLH_RASTER_DEM, _DEM_SIGMA, _VIEWSHED
   double* covariances = nullptr;  // [max_frames][P][36], allocated on first use
   double* uj = nullptr;           // [P][N] host-fed per-particle uniforms (stratified / choice)
+  double* extra_ll = nullptr;     // [P][N] caller-computed log-likelihood term of the next glh_update_weights, or null
+  bool have_extra = false;
   uint8_t *obs_mask = nullptr, *active = nullptr;
   uint32_t* pt_status = nullptr;
   int32_t *pt_err_frame = nullptr, *box = nullptr, *idx = nullptr;
@@ -252,7 +254,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
     dfree(c->weights[i]);
   }
   dfree(c->motion); dfree(c->uv); dfree(c->bbox_part); dfree(c->normals); dfree(c->u);
-  dfree(c->mean6); dfree(c->moments); dfree(c->covariances); dfree(c->uj);
+  dfree(c->mean6); dfree(c->moments); dfree(c->covariances); dfree(c->uj); dfree(c->extra_ll);
   for (auto& r : c->rasters) {
     dfree(r.z); dfree(r.gx); dfree(r.gy);
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
@@ -690,7 +692,7 @@ extern "C" int glh_set_motion(glh_ctx* c, const double* params) {
   for (int p = 0; p < c->P; ++p) {
     const double* m = params + (size_t)p * GLH_MOTION_FULL_LEN;
     const int kind = (int)m[18];
-    if (m[18] != (double)kind || kind < GLH_MOTION_CARTESIAN || kind > GLH_MOTION_TANGENT_CYLINDRICAL)
+    if (m[18] != (double)kind || kind < GLH_MOTION_CARTESIAN || kind > GLH_MOTION_EXTERNAL)
       return fail(GLH_E_INVALID, "point %d: unknown motion kind %g", p, m[18]);
     if (kind != GLH_MOTION_CARTESIAN) c->all_cartesian = false;
     if (m[20] != 0.0 && !c->rasters[GLH_RASTER_DEM].z)
@@ -728,6 +730,14 @@ extern "C" int glh_set_active(glh_ctx* c, const uint8_t* active) {
   CHK(need_seq(c));
   c->have_active = active != nullptr;
   if (active) UPLOAD(c->active, active, (size_t)c->P, uint8_t);
+  return GLH_OK;
+}
+extern "C" int glh_set_extra_log_likelihoods(glh_ctx* c, const double* ll) {
+  CHK(need_seq(c));
+  c->have_extra = ll != nullptr;
+  if (!ll) return GLH_OK;
+  if (!c->extra_ll) CHK(dalloc(&c->extra_ll, (size_t)c->cfg.max_points * c->cfg.max_particles));
+  UPLOAD(c->extra_ll, ll, (size_t)c->P * c->N, double);
   return GLH_OK;
 }
 extern "C" int glh_set_particles(glh_ctx* c, const double* p) {
@@ -1107,6 +1117,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.coef = c->sse;
   wa.poly = c->poly;
   wa.ll_out = c->keep_sse ? c->ll_dbg : nullptr;
+  wa.extra = c->have_extra ? c->extra_ll : nullptr;
   wa.pt_status = c->pt_status;
   wa.pt_err_frame = c->pt_err_frame;
   for (int o = 0; o < O; ++o) {
@@ -1441,7 +1452,7 @@ extern "C" int glh_step(glh_ctx* c, int frame, double tau, const int32_t* images
     return fail(GLH_E_INVALID, "unknown rng_mode %d", rng_mode);
   }
   int r2_bytes = 0;
-  if (c->fused && !c->have_active && !c->keep_sse && fused_plan(c, &r2_bytes))
+  if (c->fused && !c->have_active && !c->keep_sse && !c->have_extra && fused_plan(c, &r2_bytes))
     return fused_step(c, frame, tau, images, rng_mode, u, seed, r2_bytes);
   // one pass over the particle state: evolve, NaN test, project, bbox partials
   CHK(launch_evolve_project(c, true, tau, rng_mode, seed, (uint64_t)frame, images));

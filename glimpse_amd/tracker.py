@@ -20,7 +20,7 @@ import warnings as _warnings
 import numpy as np
 
 from . import _lib
-from .motion import CartesianMotion, TangentCartesianMotion
+from .motion import CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion
 from .raster import Raster
 from .tracks import Tracks
 
@@ -35,6 +35,16 @@ _ERRORS = (
 )
 _OOB_WARNING = "Particles too close to or beyond image bounds, skipping image"
 _MAX_HOST_DRAWS_BYTES = 4 << 30
+
+
+_DEVICE_MODELS = (CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion)
+
+
+def _on_device(model):
+    """The four motion models of the reference are initialised and evolved on the device.  Anything else -- a
+    subclass that overrides them, or any object with the interface of motion.py:13-89 -- is a user-defined model: its
+    own initialize_particles / evolve_particles / compute_log_likelihoods run on the host, as the user wrote them."""
+    return type(model) in _DEVICE_MODELS
 
 
 def _vector24(img):
@@ -236,9 +246,10 @@ class Tracker:
             if model.time_unit != time_unit:
                 raise ValueError("Motion models must have equal time units")
         for model in motion_models:
-            if not isinstance(model, (CartesianMotion, TangentCartesianMotion)):
-                raise NotImplementedError(f"{type(model).__name__}: the GPU path evolves Cartesian, Cylindrical, "
-                                          "TangentCartesian and TangentCylindrical motion models")
+            if not _on_device(model) and not (callable(getattr(model, "initialize_particles", None))
+                                              and callable(getattr(model, "evolve_particles", None))):
+                raise TypeError(f"{type(model).__name__} is not a motion model: it needs initialize_particles() and "
+                                "evolve_particles(particles, dt) (motion.py:13-89)")
         self.reset()
         ntracks = len(motion_models)
         raise_errors = ntracks < 2 if _catch_errors is None else not _catch_errors
@@ -249,7 +260,7 @@ class Tracker:
                                         return_covariances=return_covariances, return_particles=return_particles,
                                         reduce_particles=reduce_particles, rng=rng, seed=seed, point_offset=point_offset)
         n = motion_models[0].n
-        if any(m.n != n for m in motion_models):
+        if any(m.n != n for m in motion_models) or not all(_on_device(m) for m in motion_models):
             # Motion models with different particle counts (each track of the reference has its own n,
             # tracker.py:305-314): consecutive models with equal n form one batch, the batches run in order -- so
             # the legacy np.random stream is consumed track after track like the reference -- and are merged.
@@ -512,15 +523,27 @@ class Tracker:
         return tracks
 
     def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0, **kw):
+        """Tracks that cannot share one batch: consecutive device models of equal n form a batch, every user-defined
+        model is a run of its own (`_track_custom`); the runs go in track order, so np.random is consumed like the
+        reference consumes it (one track after another), and are merged."""
         ntracks = len(motion_models)
         if observer_mask is not None:
             observer_mask = np.asarray(observer_mask, dtype=bool)
-        bounds = [0] + [i for i in range(1, ntracks) if motion_models[i].n != motion_models[i - 1].n] + [ntracks]
+
+        def splits(i):
+            a, b = motion_models[i - 1], motion_models[i]
+            return a.n != b.n or not _on_device(a) or not _on_device(b)
+
+        bounds = [0] + [i for i in range(1, ntracks) if splits(i)] + [ntracks]
         parts = []
         for a, b in zip(bounds[:-1], bounds[1:]):
-            parts.append(self.track(motion_models[a:b], observer_mask=None if observer_mask is None else observer_mask[a:b],
-                                    reduce_particles=reduce_particles, point_offset=point_offset + a,
-                                    _catch_errors=ntracks >= 2, **kw))
+            mask = None if observer_mask is None else observer_mask[a:b]
+            if not _on_device(motion_models[a]):
+                parts.append(self._track_custom(motion_models[a], None if mask is None else mask[0],
+                                                reduce_particles=reduce_particles, catch_errors=ntracks >= 2, **kw))
+            else:
+                parts.append(self.track(motion_models[a:b], observer_mask=mask, reduce_particles=reduce_particles,
+                                        point_offset=point_offset + a, _catch_errors=ntracks >= 2, **kw))
 
         def cat(name):
             values = [getattr(part, name) for part in parts]
@@ -533,6 +556,71 @@ class Tracker:
                         warnings=cat("warnings"))
         if reduce_particles:
             tracks.reduced = [r for part in parts for r in part.reduced]
+        return tracks
+
+    def _track_custom(self, model, mask, datetimes=None, maxdt=datetime.timedelta(0), tile_size=(15, 15),
+                      return_covariances=False, return_particles=False, reduce_particles=None, catch_errors=False,
+                      rng="numpy", seed=0):
+        """One track of a user-defined motion model: the reference's per-track loop (`process`, tracker.py:305-374)
+        with the model's own initialize_particles / evolve_particles / compute_log_likelihoods on the host -- they are
+        the user's code -- and this class's step methods (templates, observer likelihoods, weights, resampling,
+        moments: device kernels) in between.  np.random is consumed exactly as the reference consumes it."""
+        if reduce_particles:
+            return_particles = True
+        datetimes = self.datetimes if datetimes is None else self.parse_datetimes(datetimes=datetimes, maxdt=maxdt)
+        nobs = len(self.observers)
+        mask = np.ones(nobs, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        matching = self.match_datetimes(datetimes=datetimes, maxdt=maxdt)
+        has = np.not_equal(matching, None)
+        template_indices = has.argmax(axis=0)
+        ntimes = len(datetimes)
+        dts = np.diff(datetimes)
+        n = int(model.n)
+        means = np.full((ntimes, 6), np.nan)
+        sigmas = np.full((ntimes, 6, 6) if return_covariances else (ntimes, 6), np.nan)
+        particles = np.full((ntimes, n, 6), np.nan) if return_particles else None
+        weights = np.full((ntimes, n), np.nan) if return_particles else None
+        error, caught = None, []
+        self.reset()
+        self._single_tile = tuple(int(v) for v in tile_size)
+        try:
+            with _warnings.catch_warnings(record=True) as caught:
+                _warnings.simplefilter("always")
+                observed = has[:, mask].any(axis=1)
+                first = int(np.argmax(observed))
+                last = len(observed) - 1 - int(np.argmax(observed[::-1]))
+                for i in range(first, last + 1):
+                    if i == first:
+                        self.particles = np.array(model.initialize_particles(), dtype=float)
+                        self.test_particles()
+                        self.initialize_weights()
+                    else:
+                        model.evolve_particles(self.particles, dt=dts[i - 1])
+                        self.test_particles()
+                    for obs in np.nonzero(mask & (template_indices == i))[0]:
+                        self.initialize_template(obs=int(obs), img=matching[i][obs], tile_size=tile_size)
+                    if i > first:
+                        imgs = [img if m else None for img, m in zip(matching[i], mask)]
+                        self.update_weights(imgs=imgs, motion_model=model)
+                        self.resample_particles()
+                    means[i] = self.particle_mean
+                    sigmas[i] = self.particle_covariance if return_covariances else self.compute_particle_sigma()
+                    if return_particles:
+                        particles[i], weights[i] = self.particles, self.weights
+        except Exception as e:  # noqa: BLE001  (tracker.py:360-368: captured for >= 2 tracks, re-raised for one)
+            if not catch_errors:
+                raise
+            error = e
+            first_bad = int(np.argmax(np.isnan(means[:, 0]))) if np.isnan(means[:, 0]).any() else ntimes
+            means[first_bad:] = np.nan
+            sigmas[first_bad:] = np.nan
+        tracks = Tracks(datetimes=datetimes, time_unit=model.time_unit, means=[means],
+                        sigmas=None if return_covariances else [sigmas], covariances=[sigmas] if return_covariances else None,
+                        particles=None if (reduce_particles or not return_particles) else [particles],
+                        weights=None if (reduce_particles or not return_particles) else [weights], tracker=self,
+                        images=matching, errors=[error], warnings=[tuple(caught) if caught else None])
+        if reduce_particles:
+            tracks.reduced = [reduce_particles(particles, weights)]
         return tracks
 
     @staticmethod
@@ -653,12 +741,22 @@ class Tracker:
         self.templates[obs] = {"obs": obs, "img": img, **t}
 
     def update_weights(self, imgs, motion_model=None):
-        """tracker.py:126-149.  `motion_model` must be a CartesianMotion (its DEM term is added) or None."""
+        """tracker.py:126-149.  A device motion model contributes its built-in term (the DEM likelihood of the
+        Cartesian / Cylindrical models, none for the tangent ones); a user-defined model's
+        compute_log_likelihoods(particles) is evaluated on the host and appended by the device (None = no term)."""
         ctx = self._single()
         params = np.zeros((1, _lib.MOTION_FULL_LEN))
-        if motion_model is not None:
+        extra = None
+        if motion_model is not None and _on_device(motion_model):
             params[0] = motion_model.params_full()
+        elif motion_model is not None:
+            params[0, 18] = _lib.MOTION_KINDS["external"]
+            # (called unconditionally, like tracker.py:143: a model without the method fails the way it does there)
+            extra = motion_model.compute_log_likelihoods(self.particles)
+        else:
+            params[0, 18] = _lib.MOTION_KINDS["external"]  # no motion model: no term (not an array of zeros)
         ctx.set_motion(params)
+        ctx.set_extra_log_likelihoods(None if extra is None else np.asarray(extra, dtype=float)[None])
         for o, img in enumerate(imgs):
             if img is not None:
                 self._single_upload(ctx, o, img)
@@ -669,7 +767,8 @@ class Tracker:
             _warnings.warn(_OOB_WARNING)
         if ctx.point_status()[0] & _lib.PT_SAMPLE_OUTSIDE:
             raise ValueError("Some sampling points are outside box")
-        if motion_model is not None or any(s == _lib.OBS_OK for s in st):
+        has_term = (motion_model is not None and _on_device(motion_model) and not motion_model.TANGENT) or extra is not None
+        if has_term or any(s == _lib.OBS_OK for s in st):
             self.weights = ctx.get_weights()[0]
 
     def compute_observer_log_likelihoods(self, obs, img):
@@ -679,6 +778,7 @@ class Tracker:
         ctx = self._single()
         ctx.set_debug(True)
         ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
+        ctx.set_extra_log_likelihoods(None)
         self._single_upload(ctx, obs, img)
         self._push(ctx)
         imgs = [-1] * len(self.observers)

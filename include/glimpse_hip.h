@@ -70,6 +70,10 @@ extern "C" {
 #define GLH_MOTION_CYLINDRICAL 1
 #define GLH_MOTION_TANGENT_CARTESIAN 2
 #define GLH_MOTION_TANGENT_CYLINDRICAL 3
+#define GLH_MOTION_EXTERNAL 4 /* a user-defined Motion (the duck type of motion.py:13-89): the caller initialises and
+                               * evolves the particles (glh_set_particles) and supplies its log-likelihood term
+                               * (glh_set_extra_log_likelihoods); the device does the observer likelihoods,
+                               * resampling and moments                                                          */
 
 /* ---- per-point status bits (sticky; the Python Tracker turns them into Tracks.errors) */
 #define GLH_PT_NAN 1u            /* ValueError "missing (NaN) values"      tracker.py:118  */
@@ -179,7 +183,11 @@ int glh_set_active(glh_ctx* ctx, const uint8_t* active);
 
 int glh_set_particles(glh_ctx* ctx, const double* particles); /* [P][N][6] */
 int glh_get_particles(glh_ctx* ctx, double* particles);
-int glh_set_weights(glh_ctx* ctx, const double* weights); /* [P][N] */
+int glh_set_weights(glh_ctx* ctx, const double* weights);
+/* A log-likelihood term computed by the caller for the NEXT glh_update_weights calls, ll [P][N] (NULL removes it):
+ * Motion.compute_log_likelihoods of a user-defined motion model (motion.py:74-89), appended to the observers' terms
+ * like the built-in one (tracker.py:139-149).                                                                    */
+int glh_set_extra_log_likelihoods(glh_ctx* ctx, const double* ll); /* [P][N] */
 int glh_get_weights(glh_ctx* ctx, double* weights);
 int glh_get_point_status(glh_ctx* ctx, uint32_t* status);    /* [P]    GLH_PT_* bits        */
 /* Frame index (glh_set_frame) at which each point first raised a status bit, or a large

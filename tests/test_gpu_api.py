@@ -477,3 +477,35 @@ def test_parallel_workers_reproduce_the_single_process_run(golden):
         par = tracker.track(models[:3], tile_size=tile, parallel=True)  # True = one worker per GPU (here: one)
         assert np.isfinite(par.means).all() and abs(np.median(par.means[:, -1, 3]) - 0.15) < 0.05
     assert glimpse_amd.Tracker._parse_parallel(False, 10) == 0 and glimpse_amd.Tracker._parse_parallel(8, 3) == 3
+
+
+def test_user_defined_motion_models_reproduce_reference(golden):
+    """Motion models the library does not know (the duck type of motion.py:13-89) in one Tracker.track call with a
+    built-in one: their own initialize / evolve / log-likelihood methods run on the host, everything between them on
+    the device, np.random consumed in the reference's order -- the reference's tracks (g16: generated by running the
+    reference Tracker on the same classes)."""
+    from tests import custom_motion as cm
+
+    g = golden("g16_custom_motion.npz")
+    cam = camera_from(g["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(g["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    xy = g["xy"]
+    models = [cm.DriftMotion(tuple(xy[0]), DAY, n=150), cm.SpeedPriorMotion(tuple(xy[1]), DAY, n=150),
+              glimpse_amd.CartesianMotion(xy=tuple(xy[2]), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=150,
+                                          xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0),
+                                          axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0)),
+              cm.NoTermMotion(tuple(xy[3]), DAY, n=150)]
+    np.random.seed(int(g["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert np.random.random() == float(g["random_after"])
+    assert [e is not None for e in tracks.errors] == list(g["errors"].astype(bool))
+    assert isinstance(tracks.errors[0], AttributeError)  # DriftMotion has no compute_log_likelihoods (tracker.py:143)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8, equal_nan=True)
+    np.testing.assert_allclose(tracks.particles[1][-1], g["last_particles_1"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.weights[1][-1], g["last_weights_1"], rtol=RTOL, atol=1e-290)
+    with pytest.raises(TypeError):
+        tracker.track([type("NotAModel", (), {"time_unit": DAY, "n": 10})()])

@@ -780,7 +780,41 @@ def g15_ragged():
     print("g15 vx:", tracks.means[:, -1, 3], "errors:", out["errors"])
 
 
+def g16_custom_motion():
+    """User-defined motion models (the duck type of motion.py:13-89) through the reference Tracker: the frames of
+    g8_c2mini, four tracks in one call -- tests/custom_motion.py's DriftMotion (no likelihood method),
+    SpeedPriorMotion (array), a built-in CartesianMotion in between, NoTermMotion (None) -- np.random seeded once."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import custom_motion as cm
+
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam, 4, border_px=70.0, seed=3)
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(6)]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+    cart = dict(xy=tuple(pts[2]), dem=0.0, dem_sigma=0.0, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0))
+    models = [cm.DriftMotion(tuple(pts[0]), day, n=150), cm.SpeedPriorMotion(tuple(pts[1]), day, n=150),
+              glimpse.CartesianMotion(time_unit=day, **cart), cm.NoTermMotion(tuple(pts[3]), day, n=150)]
+    np.random.seed(123)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    after = np.random.random()
+    out = {"seed": 123, "xy": np.array([pts[0], pts[1], pts[2], pts[3]]), "means": tracks.means, "sigmas": tracks.sigmas,
+           "errors": np.array([0 if e is None else 1 for e in tracks.errors]), "random_after": after,
+           "frames": np.stack(frames), "cam": cam, "n": np.array([m.n for m in models]),
+           "last_particles_1": tracks.particles[1][-1], "last_weights_1": tracks.weights[1][-1]}
+    np.savez_compressed(os.path.join(OUT, "g16_custom_motion.npz"), **out)
+    print("g16 vx:", tracks.means[:, -1, 3], "errors:", out["errors"])
+
+
 if __name__ == "__main__":
+    if "--g16" in sys.argv:
+        g16_custom_motion()
+        sys.exit(0)
     if "--g15" in sys.argv:
         g15_ragged()
         sys.exit(0)
@@ -817,5 +851,6 @@ if __name__ == "__main__":
     g13_ortho()
     g14_unproject()
     g15_ragged()
+    g16_custom_motion()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
