@@ -98,6 +98,7 @@ SIGNATURES = {
     "glh_track": (_I, [_P, _I, _P, _P, _P, _U64]),
     "glh_set_fused": (_I, [_P, _I]),
     "glh_set_math": (_I, [_P, _I]),
+    "glh_set_highpass": (_I, [_P, _I, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
@@ -125,6 +126,8 @@ SIGNATURES = {
     "glh_stage_unproject": (_I, [_I, _P, _P, _I, _P, _I, _I, _P]),
     "glh_stage_template": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "glh_stage_search_tile": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "glh_stage_template_highpass": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "glh_stage_search_tile_highpass": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
     "glh_stage_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "glh_stage_resample": (_I, [_I, _P, _I, _D, _P]),
@@ -421,6 +424,11 @@ class Context:
         """"exact" (NumPy rounding; default) or "fast" (FMA / reciprocal arithmetic for device-RNG runs)."""
         check(self.lib.glh_set_math(self.handle, {"exact": MATH_EXACT, "fast": MATH_FAST}[mode]))
 
+    def set_highpass(self, size=(5, 5)):
+        """Window of the median high-pass filter, scipy order (rows, columns); odd sizes up to 7."""
+        sy, sx = (int(size), int(size)) if np.isscalar(size) else (int(size[0]), int(size[1]))
+        check(self.lib.glh_set_highpass(self.handle, sx, sy))
+
     def set_point_offset(self, offset):
         check(self.lib.glh_set_point_offset(self.handle, int(offset)))
 
@@ -595,27 +603,33 @@ def _frame_dims(frame):
     return frame, w, h, ch
 
 
-def stage_template(frame, box, device_id=0):
+def _highpass_xy(size):
+    return (int(size), int(size)) if np.isscalar(size) else (int(size[1]), int(size[0]))  # scipy: (rows, columns)
+
+
+def stage_template(frame, box, device_id=0, highpass=(5, 5)):
     frame, w, h, ch = _frame_dims(frame)
+    sx, sy = _highpass_xy(highpass)
     box = _arr(box, np.int32, (4,))
     tw, th = int(box[2] - box[0]), int(box[3] - box[1])
     tile = np.empty((th, tw))
     hv = np.empty(tw * th)
     hq = np.empty(tw * th)
     hn = C.c_int32()
-    check(load().glh_stage_template(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(tile), _ptr(hv), _ptr(hq),
-                                    C.byref(hn)))
+    check(load().glh_stage_template_highpass(device_id, _ptr(frame), w, h, ch, _ptr(box), sx, sy, _ptr(tile), _ptr(hv),
+                                             _ptr(hq), C.byref(hn)))
     return tile, (hv[: hn.value].copy(), hq[: hn.value].copy())
 
 
-def stage_search_tile(frame, box, histogram, device_id=0):
+def stage_search_tile(frame, box, histogram, device_id=0, highpass=(5, 5)):
     frame, w, h, ch = _frame_dims(frame)
+    sx, sy = _highpass_xy(highpass)
     box = _arr(box, np.int32, (4,))
     hv = _arr(histogram[0], np.float64)
     hq = _arr(histogram[1], np.float64)
     out = np.empty((int(box[3] - box[1]), int(box[2] - box[0])), dtype=np.float32)
-    check(load().glh_stage_search_tile(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(hv), _ptr(hq), len(hv),
-                                       _ptr(out)))
+    check(load().glh_stage_search_tile_highpass(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(hv), _ptr(hq),
+                                                len(hv), sx, sy, _ptr(out)))
     return out
 
 

@@ -551,9 +551,32 @@ struct TemplateOut {
   int32_t* hist_n;
 };
 
+// Median of the (2 ry + 1) x (2 rx + 1) window of raw keys around (r, c) of a w x h key tile with row stride `ld`
+// whose row 0 sits at tile row `row0` (scipy.ndimage.median_filter(size=(2 ry + 1, 2 rx + 1)), mode 'reflect':
+// Tracker(highpass={"size": ...}), tracker.py:59, :530).  Any odd size up to 7 x 7: the smallest key with at least
+// half the window at or below it, by bisection over the key range (the 5 x 5 default has its own network).
+__device__ __forceinline__ int median_window(const uint16_t* keys, int ld, int row0, int w, int h, int r, int c,
+                                             int rx, int ry, int max_key) {
+  const int need = ((2 * rx + 1) * (2 * ry + 1) + 1) / 2;
+  int lo = 0, hi = max_key;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int cnt = 0;
+    for (int dr = -ry; dr <= ry; ++dr) {
+      const uint16_t* row = keys + (reflect_index(r + dr, h) - row0) * ld;
+      for (int dc = -rx; dc <= rx; ++dc) cnt += row[reflect_index(c + dc, w)] <= mid;
+    }
+    if (cnt >= need)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  return lo;
+}
+
 __device__ void template_from_box(const uint8_t* frame, int width, int channels, const int* box,
                                   uint16_t* keys, uint32_t* hist, double* red, TemplateOut out,
-                                  bool* const_tile) {
+                                  bool* const_tile, int hp_rx = 2, int hp_ry = 2) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   for (int b = tid; b < NBINS; b += BLK) hist[b] = 0;
@@ -605,6 +628,8 @@ __device__ void template_from_box(const uint8_t* frame, int width, int channels,
       }
     }
     int med = median25(v);
+    if (hp_rx != 2 || hp_ry != 2)
+      med = median_window(keys, w, 0, w, h, r, c, hp_rx, hp_ry, channels == 1 ? 255 : 255 * channels);
     double x = (key_value(keys[idx], channels) - mean) * inv_std;
     double xm = (key_value(med, channels) - mean) * inv_std;
     double t = x - xm;
@@ -622,6 +647,7 @@ struct TemplateArgs {
   const uint8_t* obs_mask;
   ObsFrame obs;
   int32_t o, O, P, tw, th, tile_cap, frame;  // tile_cap = max_tile^2 (per-template stride)
+  int32_t hp_rx, hp_ry;                      // half sizes of the median high-pass window (2, 2 = the 5 x 5 default)
   int32_t* tmpl_box;    // [O][P][4]
   double* tmpl_duv;     // [O][P][2]
   double* tmpl_tile64;  // [O][P][tile_cap]
@@ -671,7 +697,7 @@ __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
   out.hist_v = a.tmpl_hist_v + slot * a.tile_cap;
   out.hist_q = a.tmpl_hist_q + slot * a.tile_cap;
   out.hist_n = a.tmpl_hist_n + slot;
-  template_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box, keys, hist, red, out, &s_const);
+  template_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box, keys, hist, red, out, &s_const, a.hp_rx, a.hp_ry);
   __syncthreads();
   if (threadIdx.x == 0) {
     a.tmpl_valid[slot] = 1;
@@ -684,6 +710,7 @@ struct TemplateBoxArgs {
   const uint8_t* frame;
   int32_t width, channels;
   int32_t box[4];
+  int32_t hp_rx, hp_ry;
   TemplateOut out;
 };
 __global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
@@ -695,7 +722,7 @@ __global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
   if (threadIdx.x < 4) s_box[threadIdx.x] = a.box[threadIdx.x];
   __syncthreads();
   template_from_box(a.frame, a.width, a.channels, s_box, reinterpret_cast<uint16_t*>(smem), hist,
-                    red, a.out, &s_const);
+                    red, a.out, &s_const, a.hp_rx, a.hp_ry);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -708,7 +735,7 @@ __global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
 __device__ void search_tile_from_box(const uint8_t* frame, int width, int channels, const int* box,
                                      const double* hist_v, const double* hist_q, int hist_n,
                                      uint32_t* hist, uint32_t* cum, double* lut, uint16_t* band,
-                                     uint32_t* scan_tmp, float* out) {
+                                     uint32_t* scan_tmp, float* out, int hp_rx = 2, int hp_ry = 2) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   for (int b = tid; b < NBINS; b += BLK) hist[b] = 0;
@@ -746,6 +773,36 @@ __device__ void search_tile_from_box(const uint8_t* frame, int width, int channe
     }
   }
   __syncthreads();
+  if (hp_rx != 2 || hp_ry != 2) {
+    // any other odd window up to 7 x 7: bands with a halo of hp_ry rows, median by bisection
+    const int max_key = channels == 1 ? 255 : 255 * channels;
+    for (int r0 = 0; r0 < h; r0 += BAND_H) {
+      const int rows = min(BAND_H, h - r0);
+      for (int idx = tid; idx < (rows + 2 * hp_ry) * w; idx += BLK) {
+        int br = idx / w, c = idx - br * w;
+        int rr = reflect_index(r0 + br - hp_ry, h);
+        band[idx] = (uint16_t)pixel_key(frame, width, channels, box[1] + rr, box[0] + c);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < rows * w; idx += BLK) {
+        int br = idx / w, c = idx - br * w;
+        // (the band holds reflected rows r0 - ry .. r0 + rows + ry - 1 in order: row index = br + dr + ry)
+        const int need = ((2 * hp_rx + 1) * (2 * hp_ry + 1) + 1) / 2;
+        int lo = 0, hi = max_key;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          int cnt = 0;
+          for (int dr = 0; dr <= 2 * hp_ry; ++dr)
+            for (int dc = -hp_rx; dc <= hp_rx; ++dc) cnt += band[(br + dr) * w + reflect_index(c + dc, w)] <= mid;
+          if (cnt >= need) hi = mid; else lo = mid + 1;
+        }
+        const int key = band[(br + hp_ry) * w + c];
+        out[(size_t)(r0 + br) * w + c] = (float)(lut[key] - lut[lo]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int r0 = 0; r0 < h; r0 += BAND_H) {
     const int rows = min(BAND_H, h - r0);
     // stage rows r0-2 .. r0+rows+1 (reflected at the tile's top/bottom) as keys
@@ -782,6 +839,7 @@ struct TilePrepArgs {
   const uint8_t* obs_mask;
   ObsFrame obs;
   int32_t o, O, P, NB, tw, th, tile_cap, search_cap, max_dim;
+  int32_t hp_rx, hp_ry;     // half sizes of the median high-pass window
   const double* bbox_part;  // [O][P][NB][5]
   const int32_t* tmpl_valid;
   const double* tmpl_hist_v;
@@ -852,7 +910,7 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   search_tile_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box,
                        a.tmpl_hist_v + slot * a.tile_cap, a.tmpl_hist_q + slot * a.tile_cap,
                        a.tmpl_hist_n[slot], hist, cum, lut, reinterpret_cast<uint16_t*>(smem),
-                       scan_tmp, a.search + slot * (size_t)a.search_cap);
+                       scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
 }
 
 // Test hook: search tile from an explicit box (glh_stage_search_tile).
@@ -863,6 +921,7 @@ struct SearchBoxArgs {
   const double* hist_v;
   const double* hist_q;
   int32_t hist_n;
+  int32_t hp_rx, hp_ry;
   float* out;
 };
 __global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
@@ -875,7 +934,7 @@ __global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
   if (threadIdx.x < 4) s_box[threadIdx.x] = a.box[threadIdx.x];
   __syncthreads();
   search_tile_from_box(a.frame, a.width, a.channels, s_box, a.hist_v, a.hist_q, a.hist_n, hist, cum,
-                       lut, reinterpret_cast<uint16_t*>(smem), scan_tmp, a.out);
+                       lut, reinterpret_cast<uint16_t*>(smem), scan_tmp, a.out, a.hp_rx, a.hp_ry);
 }
 
 // ------------------------------------------------------------------------------------------

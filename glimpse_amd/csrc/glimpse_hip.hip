@@ -106,6 +106,7 @@ struct glh_ctx {
   int pt_base = 0;  // global index of this context's point 0
   bool all_cartesian = true;  // every point is CartesianMotion (the common fused instantiation; else the general one)
   bool fast_math = false;     // GLH_MATH_FAST (glh_set_math)
+  int hp_rx = 2, hp_ry = 2;   // half sizes of the median high-pass window (glh_set_highpass; 5 x 5 by default)
   int tile_cap = 0, search_cap = 0, sse_cap = 0, ssd_blocks = 2;
   Observer obs[MAX_OBS];
   // device buffers
@@ -1001,6 +1002,8 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   a.th = c->th;
   a.tile_cap = c->tile_cap;
   a.frame = c->frame;
+  a.hp_rx = c->hp_rx;
+  a.hp_ry = c->hp_ry;
   a.tmpl_box = c->tmpl_box;
   a.tmpl_duv = c->tmpl_duv;
   a.tmpl_tile64 = c->tmpl_tile64;
@@ -1043,6 +1046,8 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.tile_cap = c->tile_cap;
     tp.search_cap = c->search_cap;
     tp.max_dim = c->cfg.max_search_dim;
+    tp.hp_rx = c->hp_rx;
+    tp.hp_ry = c->hp_ry;
     tp.bbox_part = c->bbox_part;
     tp.tmpl_valid = c->tmpl_valid;
     tp.tmpl_hist_v = c->tmpl_hist_v;
@@ -1053,7 +1058,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.search = c->search;
     {
       StageTimer t(c, ST_TILEPREP);
-      size_t lds = (size_t)(BAND_H + 4) * c->cfg.max_search_dim * sizeof(uint16_t);
+      size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * sizeof(uint16_t);  // (halo of up to 3 rows)
       hipLaunchKernelGGL(k_tileprep, dim3(c->P), dim3(BLK), lds, c->stream, tp);
     }
     HIPCHK(hipGetLastError());
@@ -1239,6 +1244,7 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
 static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
+  if (c->hp_rx != 2 || c->hp_ry != 2) return false;  // the fused kernel's median network is the 5 x 5 default
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {
@@ -1522,6 +1528,15 @@ extern "C" int glh_debug_phase_stamps(glh_ctx* c, uint64_t* stamps) {
     return GLH_OK;
   }
   DOWNLOAD(stamps, c->stamps, n, unsigned long long);
+  return GLH_OK;
+}
+
+extern "C" int glh_set_highpass(glh_ctx* c, int size_x, int size_y) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (size_x < 1 || size_y < 1 || size_x > 7 || size_y > 7 || !(size_x & 1) || !(size_y & 1))
+    return fail(GLH_E_UNSUPPORTED, "high-pass window %d x %d: sizes must be odd and at most 7", size_x, size_y);
+  c->hp_rx = size_x / 2;
+  c->hp_ry = size_y / 2;
   return GLH_OK;
 }
 
@@ -1894,9 +1909,22 @@ static int check_box(const int32_t* box, int width, int height) {
   return GLH_OK;
 }
 
+static int check_highpass(int size_x, int size_y) {
+  if (size_x < 1 || size_y < 1 || size_x > 7 || size_y > 7 || !(size_x & 1) || !(size_y & 1))
+    return fail(GLH_E_UNSUPPORTED, "high-pass window %d x %d: sizes must be odd and at most 7", size_x, size_y);
+  return GLH_OK;
+}
+
 extern "C" int glh_stage_template(int dev, const uint8_t* frame, int width, int height, int channels,
                                   const int32_t* box, double* tile, double* hv, double* hq, int32_t* hn) {
+  return glh_stage_template_highpass(dev, frame, width, height, channels, box, 5, 5, tile, hv, hq, hn);
+}
+
+extern "C" int glh_stage_template_highpass(int dev, const uint8_t* frame, int width, int height, int channels,
+                                           const int32_t* box, int size_x, int size_y, double* tile, double* hv,
+                                           double* hq, int32_t* hn) {
   if (!frame || !tile || !hv || !hq || !hn) return fail(GLH_E_INVALID, "null argument");
+  CHK(check_highpass(size_x, size_y));
   if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
   CHK(check_box(box, width, height));
   HIPCHK(hipSetDevice(dev));
@@ -1915,6 +1943,8 @@ extern "C" int glh_stage_template(int dev, const uint8_t* frame, int width, int 
   a.out.hist_v = dv.as<double>();
   a.out.hist_q = dq.as<double>();
   a.out.hist_n = dn.as<int32_t>();
+  a.hp_rx = size_x / 2;
+  a.hp_ry = size_y / 2;
   hipLaunchKernelGGL(k_template_from_box, dim3(1), dim3(BLK), n * sizeof(uint16_t), 0, a);
   CHK(finish());
   CHK(dn.down(hn, 4));
@@ -1925,13 +1955,20 @@ extern "C" int glh_stage_template(int dev, const uint8_t* frame, int width, int 
 
 extern "C" int glh_stage_search_tile(int dev, const uint8_t* frame, int width, int height, int channels,
                                      const int32_t* box, const double* hv, const double* hq, int hn, float* tile) {
+  return glh_stage_search_tile_highpass(dev, frame, width, height, channels, box, hv, hq, hn, 5, 5, tile);
+}
+
+extern "C" int glh_stage_search_tile_highpass(int dev, const uint8_t* frame, int width, int height, int channels,
+                                              const int32_t* box, const double* hv, const double* hq, int hn,
+                                              int size_x, int size_y, float* tile) {
   if (!frame || !tile || !hv || !hq || hn <= 0) return fail(GLH_E_INVALID, "bad argument");
+  CHK(check_highpass(size_x, size_y));
   if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
   CHK(check_box(box, width, height));
   HIPCHK(hipSetDevice(dev));
   const int w = box[2] - box[0], h = box[3] - box[1];
   const size_t n = (size_t)w * h;
-  if ((size_t)(BAND_H + 4) * w * 2 > 60000) return fail(GLH_E_INVALID, "tile too wide for the test hook");
+  if ((size_t)(BAND_H + 6) * w * 2 > 60000) return fail(GLH_E_INVALID, "tile too wide for the test hook");
   DevBuf df, dv, dq, dout;
   CHK(df.up(frame, (size_t)width * height * channels));
   CHK(dv.up(hv, (size_t)hn * 8));
@@ -1945,8 +1982,10 @@ extern "C" int glh_stage_search_tile(int dev, const uint8_t* frame, int width, i
   a.hist_v = dv.as<double>();
   a.hist_q = dq.as<double>();
   a.hist_n = hn;
+  a.hp_rx = size_x / 2;
+  a.hp_ry = size_y / 2;
   a.out = dout.as<float>();
-  hipLaunchKernelGGL(k_search_from_box, dim3(1), dim3(BLK), (size_t)(BAND_H + 4) * w * sizeof(uint16_t), 0, a);
+  hipLaunchKernelGGL(k_search_from_box, dim3(1), dim3(BLK), (size_t)(BAND_H + 6) * w * sizeof(uint16_t), 0, a);
   CHK(finish());
   return dout.down(tile, n * 4);
 }

@@ -76,7 +76,7 @@ def nearest_in_sorted(times_us, queries_us):
 def _parallel_worker(job):
     """One worker process of Tracker.track(parallel=N): its own Tracker / context on its GPU, its block of tracks."""
     tracker = Tracker(job["observers"], viewshed=job["viewshed"], resample_method=job["resample_method"],
-                      device=job["device"], max_search_dim=job["max_search_dim"])
+                      highpass=job["highpass"], device=job["device"], max_search_dim=job["max_search_dim"])
     if job["np_seed"] is not None:
         np.random.seed(int(job["np_seed"]))
     t = tracker.track(job["models"], _catch_errors=job["catch"], **job["kw"])
@@ -100,8 +100,14 @@ class Tracker:
             raise TypeError("viewshed must be a glimpse_amd.Raster")
         if resample_method not in _lib.RESAMPLE:
             raise ValueError(f"resample_method {resample_method!r}: expected one of {sorted(_lib.RESAMPLE)}")
-        if tuple(highpass.get("size", (5, 5))) != (5, 5) or set(highpass) - {"size"}:
-            raise NotImplementedError("the high-pass filter is the reference default: median, size (5, 5)")
+        # tracker.py:59, :530: the dict goes to scipy.ndimage.median_filter; `size` (an int or (rows, columns)) is
+        # what the device implements, odd sizes up to 7
+        size = highpass.get("size", (5, 5))
+        size = (int(size), int(size)) if np.isscalar(size) else tuple(int(v) for v in size)
+        if set(highpass) - {"size"} or len(size) != 2 or any(v < 1 or v > 7 or v % 2 == 0 for v in size):
+            raise NotImplementedError("the high-pass filter is a median with odd size up to (7, 7): "
+                                      f"highpass={highpass!r}")
+        self._highpass_size = size
         if interpolation.get("kx", 3) != 3 or interpolation.get("ky", 3) != 3:
             raise NotImplementedError("sub-pixel interpolation is the reference default: bicubic (kx = ky = 3)")
         self.viewshed = viewshed
@@ -188,6 +194,7 @@ class Tracker:
             ch = 1 if first.ndim == 2 else first.shape[2]
             ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
             ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
+        ctx.set_highpass(self._highpass_size)
         self._ctx, self._ctx_key = ctx, key
         self._uploaded = set()
         return ctx
@@ -499,7 +506,7 @@ class Tracker:
             if a == b:
                 continue
             jobs.append(dict(observers=self.observers, viewshed=self.viewshed, resample_method=self.resample_method,
-                             device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
+                             highpass=self.highpass, device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
                              np_seed=seeds[w], catch=ntracks >= 2,
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
@@ -681,6 +688,7 @@ class Tracker:
                 ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
             ctx.begin_sequence(1, n, tile)
             ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
+            ctx.set_highpass(self._highpass_size)
             self._sctx, self._sctx_key, self._single_tile, self._s_uploaded = ctx, key, tuple(tile), set()
         return self._sctx
 

@@ -267,6 +267,10 @@ int glh_set_fused(glh_ctx* ctx, int on);
 /* GLH_MATH_EXACT (default) or GLH_MATH_FAST for every kernel of this context (the staged and the fused kernels use
  * the same arithmetic in either mode, so they stay bit-identical to each other).                                */
 int glh_set_math(glh_ctx* ctx, int mode);
+/* Window of the median high-pass filter of every tile (Tracker(highpass={"size": (size_y, size_x)}), tracker.py:59,
+ * :530: scipy.ndimage.median_filter): odd sizes up to 7; 5 x 5 (the reference default) unless set.  Other sizes run on
+ * the staged kernels.                                                                                           */
+int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
 
 /* Diagnostic: s_memtime stamps [P][16] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
@@ -360,6 +364,13 @@ int glh_stage_template(int device_id, const uint8_t* frame, int width, int heigh
 int glh_stage_search_tile(int device_id, const uint8_t* frame, int width, int height,
                           int channels, const int32_t* box, const double* hist_values,
                           const double* hist_quantiles, int hist_n, float* tile);
+/* The two tile hooks with another high-pass window (odd sizes up to 7).                                          */
+int glh_stage_template_highpass(int device_id, const uint8_t* frame, int width, int height, int channels,
+                                const int32_t* box, int size_x, int size_y, double* tile, double* hist_values,
+                                double* hist_quantiles, int32_t* hist_n);
+int glh_stage_search_tile_highpass(int device_id, const uint8_t* frame, int width, int height, int channels,
+                                   const int32_t* box, const double* hist_values, const double* hist_quantiles,
+                                   int hist_n, int size_x, int size_y, float* tile);
 /* cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614): float32 in, float32 out.   */
 int glh_stage_ssd(int device_id, const float* search, int hs, int ws, const float* templ, int th,
                   int tw, float* sse);

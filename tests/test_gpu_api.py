@@ -509,3 +509,25 @@ def test_user_defined_motion_models_reproduce_reference(golden):
     np.testing.assert_allclose(tracks.weights[1][-1], g["last_weights_1"], rtol=RTOL, atol=1e-290)
     with pytest.raises(TypeError):
         tracker.track([type("NotAModel", (), {"time_unit": DAY, "n": 10})()])
+
+
+@pytest.mark.parametrize("size", [(3, 3), (7, 7)])
+def test_tracking_with_another_highpass_window_reproduces_reference(golden, size):
+    """Tracker(highpass={"size": size}) end to end against the reference run with the same np.random seed."""
+    g = golden("g17_highpass.npz")
+    scene = golden("g15_ragged.npz")
+    cam = camera_from(scene["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f)
+              for i, f in enumerate(scene["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], highpass={"size": size}, max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in g["e2e_xy"]]
+    np.random.seed(31)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    np.testing.assert_allclose(tracks.means, g[f"e2e_means_{size[0]}"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"e2e_sigmas_{size[0]}"], rtol=RTOL, atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], highpass={"size": (4, 4)})

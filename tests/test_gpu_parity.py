@@ -203,3 +203,26 @@ def test_library_reports_errors(lib):
     with pytest.raises(lib.GlhError):
         ctx.begin_sequence(2, 64, (15, 33))  # tile larger than max_tile
     ctx.close()
+
+
+def test_highpass_window_sizes_match_reference(lib, golden):
+    """Tracker(highpass={"size": ...}) (tracker.py:59, :530): median windows (3, 3), (7, 7), (3, 5) [rows, columns] and
+    the int form, template tiles and search tiles of gray and RGB frames against the reference's extract_tile."""
+    g = golden("g17_highpass.npz")
+    frames = golden("g2_tiles.npz")
+    tbox, sbox = g["tbox"], g["sbox"]
+    for k, size in enumerate(g["sizes"]):
+        size = tuple(int(v) for v in size)
+        for name in ("gray", "rgb"):
+            f = frames[name]
+            tile, (hv, hq) = lib.stage_template(f[0], tbox, highpass=size)
+            np.testing.assert_array_equal(hq, g[f"{name}_{k}_hist_q"])
+            np.testing.assert_allclose(hv, g[f"{name}_{k}_hist_v"], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(tile, g[f"{name}_{k}_tile"], rtol=1e-12, atol=1e-13)
+            hist = (g[f"{name}_{k}_hist_v"], g[f"{name}_{k}_hist_q"])
+            search = lib.stage_search_tile(f[1], sbox, hist, highpass=size)
+            np.testing.assert_array_equal(search, g[f"{name}_{k}_search"].astype(np.float32))
+    with pytest.raises(lib.GlhError):
+        lib.stage_template(frames["gray"][0], tbox, highpass=(4, 4))
+    with pytest.raises(lib.GlhError):
+        lib.stage_template(frames["gray"][0], tbox, highpass=(9, 9))

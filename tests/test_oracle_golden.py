@@ -340,3 +340,19 @@ def test_inverse_projection_matches_reference(golden):
         np.testing.assert_allclose(camera.uv_to_xyz(vec, uv), xd, rtol=1e-13, atol=1e-14)
         np.testing.assert_allclose(camera.uv_to_xyz(vec, uv, directions=False, depth=depth), xa, rtol=1e-13,
                                    atol=1e-10)
+
+
+def test_oracle_highpass_window_sizes(golden):
+    """oracle.tiles.extract_tile(highpass_size=...) against the reference's Tracker(highpass={"size": ...}) tiles."""
+    from oracle import tiles as otiles
+
+    g = golden("g17_highpass.npz")
+    frames = golden("g2_tiles.npz")
+    for k, size in enumerate(g["sizes"]):
+        size = tuple(int(v) for v in size)
+        for name in ("gray", "rgb"):
+            f = frames[name]
+            tile, hist = otiles.extract_tile(f[0], g["tbox"], return_histogram=True, highpass_size=size)
+            np.testing.assert_allclose(tile, g[f"{name}_{k}_tile"], rtol=1e-13, atol=1e-14)
+            search = otiles.extract_tile(f[1], g["sbox"], histogram=hist, highpass_size=size)
+            np.testing.assert_allclose(search, g[f"{name}_{k}_search"], rtol=1e-13, atol=1e-14)

@@ -811,7 +811,60 @@ def g16_custom_motion():
     print("g16 vx:", tracks.means[:, -1, 3], "errors:", out["errors"])
 
 
+def g17_highpass():
+    """Tracker(highpass={"size": ...}) other than the default (5, 5) (tracker.py:59, :530): tiles of the reference's
+    extract_tile for sizes (3, 3), (7, 7), (3, 5) [rows, columns] and 3 on gray and RGB frames, and whole tracks
+    (the g8_c2mini scene) for (3, 3) and (7, 7)."""
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0)
+    frames, _ = synth.make_sequence(cam, 2, seed=5)
+    rgb, _ = synth.make_sequence(cam, 2, seed=6, channels=3)
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    # (the frames are those of g2_tiles.npz and g15_ragged.npz: not stored again)
+    g2 = np.load(os.path.join(OUT, "g2_tiles.npz"))
+    assert np.array_equal(g2["gray"], np.stack(frames)) and np.array_equal(g2["rgb"], np.stack(rgb))
+    out = {}
+    bt, bs = (20, 30, 51, 61), (5, 12, 80, 70)
+    out["tbox"], out["sbox"] = np.array(bt), np.array(bs)
+    sizes = [(3, 3), (7, 7), (3, 5), 3]
+    out["sizes"] = np.array([(s, s) if np.isscalar(s) else s for s in sizes])
+    for k, size in enumerate(sizes):
+        tracker = glimpse.Tracker([glimpse.Observer([ref_image(frames[i], cam, t0 + i * day) for i in range(2)]),
+                                   glimpse.Observer([ref_image(rgb[i], cam, t0 + i * day) for i in range(2)])],
+                                  highpass={"size": size})
+        for o, name in enumerate(["gray", "rgb"]):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tile, hist = tracker.extract_tile(obs=o, img=0, box=np.array(bt), return_histogram=True)
+                search = tracker.extract_tile(obs=o, img=1, box=np.array(bs), histogram=hist)
+            out[f"{name}_{k}_tile"], out[f"{name}_{k}_hist_v"], out[f"{name}_{k}_hist_q"] = tile, hist[0], hist[1]
+            out[f"{name}_{k}_search"] = search
+    # whole tracks
+    cam2 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    seq, _ = synth.make_sequence(cam2, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam2, 3, border_px=70.0, seed=3)
+    g15 = np.load(os.path.join(OUT, "g15_ragged.npz"))
+    assert np.array_equal(g15["frames"], np.stack(seq)) and np.array_equal(g15["cam"], cam2)
+    out["e2e_xy"] = pts
+    for size in [(3, 3), (7, 7)]:
+        imgs = [ref_image(seq[i], cam2, t0 + i * day) for i in range(6)]
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)], highpass={"size": size})
+        models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in pts]
+        np.random.seed(31)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15))
+        out[f"e2e_means_{size[0]}"], out[f"e2e_sigmas_{size[0]}"] = tracks.means, tracks.sigmas
+        print("g17", size, "vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g17_highpass.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g17" in sys.argv:
+        g17_highpass()
+        sys.exit(0)
     if "--g16" in sys.argv:
         g16_custom_motion()
         sys.exit(0)
@@ -852,5 +905,6 @@ if __name__ == "__main__":
     g14_unproject()
     g15_ragged()
     g16_custom_motion()
+    g17_highpass()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
