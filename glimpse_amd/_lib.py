@@ -62,6 +62,7 @@ SIGNATURES = {
     "glh_get_stream": (_I, [_P, _P]),
     "glh_observer_init": (_I, [_P, _I, _I, _I, _I, _I, _D]),
     "glh_observer_set_cameras": (_I, [_P, _I, _I, _I, _P]),
+    "glh_observer_set_depth": (_I, [_P, _I, _I]),
     "glh_observer_upload_frame": (_I, [_P, _I, _I, _P]),
     "glh_observer_upload_frame_async": (_I, [_P, _I, _I, _P]),
     "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
@@ -207,6 +208,7 @@ class Context:
         self.rank, self.world = 0, 1
         self._keep = []  # device-borrowed frame owners
         self._frame_shape = {}  # observer -> (height, width, channels) the library copies per frame
+        self._frame_dtype = {}  # observer -> sample dtype (uint8, or uint16 after observer_set_depth)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -225,12 +227,22 @@ class Context:
     def observer_init(self, obs, n_images, width, height, channels, sigma):
         check(self.lib.glh_observer_init(self.handle, obs, n_images, width, height, channels, float(sigma)))
         self._frame_shape[obs] = (int(height), int(width), int(channels))
+        self._frame_dtype[obs] = np.dtype(np.uint8)
+
+    def observer_set_depth(self, obs, dtype):
+        """Sample type of the observer's frames: uint8 (default) or uint16; before the first upload."""
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+            raise TypeError(f"frames are uint8 or uint16 (got {dtype})")
+        check(self.lib.glh_observer_set_depth(self.handle, obs, 8 * dtype.itemsize))
+        self._frame_dtype[obs] = dtype
 
     def _frame(self, obs, pixels):
         """The C side copies width * height * channels bytes: refuse anything that is not exactly that."""
         a = np.asarray(pixels)
-        if a.dtype != np.uint8:
-            raise TypeError(f"frames are uint8 (got {a.dtype}); the library never casts pixel data")
+        if a.dtype != self._frame_dtype[obs]:
+            raise TypeError(f"observer {obs}: frames are {self._frame_dtype[obs]} (got {a.dtype}); the library never "
+                            "casts pixel data")
         h, w, ch = self._frame_shape[obs]
         want = (h, w) if ch == 1 else (h, w, ch)
         if a.shape != want and not (ch == 1 and a.shape == (h, w, 1)):

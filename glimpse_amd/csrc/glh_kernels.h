@@ -24,9 +24,11 @@ constexpr int BAND_H = 16;  // rows per median band in k_tileprep
 
 struct ObsFrame {
   const CamDev* cam;     // camera of the image matched to this frame
-  const uint8_t* frame;  // uint8 [H][W][C]
+  const uint8_t* frame;  // uint8 [H][W][C], or uint16 [H][W][C] when bits == 16
   int32_t on;            // images[o] >= 0
   int32_t width, height, channels;
+  int32_t bits;          // 8 or 16 (glh_observer_set_depth)
+  uint32_t* bins;        // 16-bit frames: [P][bins16_count(channels)] zeroed key histogram workspace (staged kernels)
 };
 
 // Division of small non-negative integers by a divisor that is the same for the whole workgroup: n / d as
@@ -639,6 +641,183 @@ __device__ void template_from_box(const uint8_t* frame, int width, int channels,
 }
 
 // ------------------------------------------------------------------------------------------
+// 16-bit frames (uint16 gray or RGB; tracker.py:494-534 works on any dtype).  Same algorithms as above on wider
+// keys: a key is the pixel value (gray) or the channel sum (RGB, <= 3 * 65535), the distinct values of a tile and
+// their cumulative counts come from a per-point histogram in HBM (`bins`, zeroed by the host before the launch)
+// instead of 256 / 766 bins in LDS, and the CDF-matched value of a key is interpolated where it is needed instead of
+// being tabulated.  Staged kernels only.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int bins16_count(int channels) { return 65535 * channels + 1; }
+
+__device__ __forceinline__ int pixel_key16(const uint8_t* frame, int width, int channels, int row, int col) {
+  const uint16_t* px = reinterpret_cast<const uint16_t*>(frame) + ((size_t)row * width + col) * channels;
+  if (channels == 1) return px[0];
+  int s = 0;
+  for (int c = 0; c < channels; ++c) s += px[c];
+  return s;
+}
+
+// exclusive prefix of `v` over the block (all threads call); `tmp` holds NWAVES words; *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* tmp, uint32_t* total) {
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    uint32_t t = __shfl_up(incl, off, WAVE);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == WAVE - 1) tmp[tid / WAVE] = incl;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+  for (int w = 0; w < NWAVES; ++w) {
+    if (w < tid / WAVE) base += tmp[w];
+    all += tmp[w];
+  }
+  *total = all;
+  return base + incl - v;
+}
+
+// median of the window around (r, c) of a w x h tile of 32-bit keys (row stride ld, tile row `row0` first)
+__device__ __forceinline__ int median_window32(const uint32_t* keys, int ld, int row0, int w, int h, int r, int c,
+                                               int rx, int ry) {
+  int v[49];
+  const int nx = 2 * rx + 1, n = nx * (2 * ry + 1);
+  for (int dr = -ry; dr <= ry; ++dr) {
+    const uint32_t* row = keys + (reflect_index(r + dr, h) - row0) * ld;
+    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = (int)row[reflect_index(c + dc, w)];
+  }
+  if (rx == 2 && ry == 2) return median25(v);
+  // any other odd window: the smallest element with at least half the window at or below it
+  const int need = (n + 1) / 2;
+  int best = 0x7fffffff;
+  for (int i = 0; i < n; ++i) {
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) cnt += v[j] <= v[i];
+    if (cnt >= need && v[i] < best) best = v[i];
+  }
+  return best;
+}
+
+__device__ void template_from_box16(const uint8_t* frame, int width, int channels, const int* box, uint32_t* keys,
+                                    uint32_t* bins, uint32_t* scan_tmp, double* red, TemplateOut out,
+                                    bool* const_tile, int hp_rx, int hp_ry) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  const int nb = bins16_count(channels);
+  double sx = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    int key = pixel_key16(frame, width, channels, box[1] + r, box[0] + c);
+    keys[idx] = (uint32_t)key;
+    atomicAdd(&bins[key], 1u);
+    sx += key_value(key, channels);
+  }
+  const double mean = block_sum(sx, red) / (double)n;
+  double sq = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    double d = key_value((int)keys[idx], channels) - mean;
+    sq += d * d;
+  }
+  const double var = block_sum(sq, red) / (double)n;
+  const double inv_std = 1.0 / sqrt(var);
+  if (tid == 0) *const_tile = !(var > 0.0);
+  __syncthreads();
+  // np.unique + cumsum(counts) / size in increasing key order: every thread owns a run of bins
+  const int chunk = (nb + BLK - 1) / BLK;
+  const int b0 = min(tid * chunk, nb), b1 = min(b0 + chunk, nb);
+  uint32_t ne = 0, cnt = 0;
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t v = bins[b];
+    ne += v != 0;
+    cnt += v;
+  }
+  uint32_t total_ne, total_cnt;
+  uint32_t k = block_excl_scan_u32(ne, scan_tmp, &total_ne);
+  uint32_t cum = block_excl_scan_u32(cnt, scan_tmp, &total_cnt);
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t v = bins[b];
+    if (v) {
+      cum += v;
+      out.hist_v[k] = (key_value(b, channels) - mean) * inv_std;
+      out.hist_q[k] = (double)cum / (double)n;
+      ++k;
+    }
+  }
+  if (tid == 0) *out.hist_n = (int)total_ne;
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    const int med = median_window32(keys, w, 0, w, h, r, c, hp_rx, hp_ry);
+    double x = (key_value((int)keys[idx], channels) - mean) * inv_std;
+    double xm = (key_value(med, channels) - mean) * inv_std;
+    double t = x - xm;
+    out.tile64[idx] = t;
+    out.tile32[idx] = (float)t;
+  }
+}
+
+__device__ void search_tile_from_box16(const uint8_t* frame, int width, int channels, const int* box,
+                                       const double* hist_v, const double* hist_q, int hist_n, uint32_t* bins,
+                                       uint32_t* band, uint32_t* scan_tmp, float* out, int hp_rx, int hp_ry) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  const int nb = bins16_count(channels);
+  for (int idx = tid; idx < n; idx += BLK) {
+    int r = idx / w, c = idx - r * w;
+    atomicAdd(&bins[pixel_key16(frame, width, channels, box[1] + r, box[0] + c)], 1u);
+  }
+  __syncthreads();
+  // inclusive scan of the bins in place: np.cumsum(counts) by key
+  const int chunk = (nb + BLK - 1) / BLK;
+  const int b0 = min(tid * chunk, nb), b1 = min(b0 + chunk, nb);
+  uint32_t cnt = 0;
+  for (int b = b0; b < b1; ++b) cnt += __hip_atomic_load(&bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t total;
+  uint32_t cum = block_excl_scan_u32(cnt, scan_tmp, &total);
+  for (int b = b0; b < b1; ++b) {
+    cum += __hip_atomic_load(&bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&bins[b], cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  auto matched = [&](int key) -> double {  // helpers.match_cdf for one value (helpers.py:489-493)
+    const uint32_t c = __hip_atomic_load(&bins[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return np_interp((double)c / (double)n, hist_q, hist_v, hist_n);
+  };
+  for (int r0 = 0; r0 < h; r0 += BAND_H) {
+    const int rows = min(BAND_H, h - r0);
+    for (int idx = tid; idx < (rows + 2 * hp_ry) * w; idx += BLK) {
+      int br = idx / w, c = idx - br * w;
+      int rr = reflect_index(r0 + br - hp_ry, h);
+      band[idx] = (uint32_t)pixel_key16(frame, width, channels, box[1] + rr, box[0] + c);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * w; idx += BLK) {
+      int br = idx / w, c = idx - br * w;
+      // the band holds the (already reflected) rows r0 - ry .. r0 + rows + ry - 1: a window never leaves it
+      int v[49];
+      const int nx = 2 * hp_rx + 1, nwin = nx * (2 * hp_ry + 1);
+      for (int dr = 0; dr <= 2 * hp_ry; ++dr)
+        for (int dc = -hp_rx; dc <= hp_rx; ++dc) v[dr * nx + dc + hp_rx] = (int)band[(br + dr) * w + reflect_index(c + dc, w)];
+      int med;
+      if (hp_rx == 2 && hp_ry == 2) {
+        med = median25(v);
+      } else {
+        const int need = (nwin + 1) / 2;
+        med = 0x7fffffff;
+        for (int i = 0; i < nwin; ++i) {
+          int cnt2 = 0;
+          for (int j = 0; j < nwin; ++j) cnt2 += v[j] <= v[i];
+          if (cnt2 >= need && v[i] < med) med = v[i];
+        }
+      }
+      const int key = (int)band[(br + hp_ry) * w + c];
+      out[(size_t)(r0 + br) * w + c] = (float)(matched(key) - matched(med));
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2a  Tracker.initialize_template (tracker.py:536-561) for one observer, one block per point
 // ------------------------------------------------------------------------------------------
 struct TemplateArgs {
@@ -697,7 +876,12 @@ __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
   out.hist_v = a.tmpl_hist_v + slot * a.tile_cap;
   out.hist_q = a.tmpl_hist_q + slot * a.tile_cap;
   out.hist_n = a.tmpl_hist_n + slot;
-  template_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box, keys, hist, red, out, &s_const, a.hp_rx, a.hp_ry);
+  if (a.obs.bits == 16)
+    template_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, reinterpret_cast<uint32_t*>(smem),
+                        a.obs.bins + (size_t)pt * bins16_count(a.obs.channels), hist, red, out, &s_const, a.hp_rx,
+                        a.hp_ry);
+  else
+    template_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box, keys, hist, red, out, &s_const, a.hp_rx, a.hp_ry);
   __syncthreads();
   if (threadIdx.x == 0) {
     a.tmpl_valid[slot] = 1;
@@ -907,10 +1091,16 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   }
   __syncthreads();
   if (s_status != GLH_OBS_OK) return;
-  search_tile_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box,
-                       a.tmpl_hist_v + slot * a.tile_cap, a.tmpl_hist_q + slot * a.tile_cap,
-                       a.tmpl_hist_n[slot], hist, cum, lut, reinterpret_cast<uint16_t*>(smem),
-                       scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
+  if (a.obs.bits == 16)
+    search_tile_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, a.tmpl_hist_v + slot * a.tile_cap,
+                           a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot],
+                           a.obs.bins + (size_t)pt * bins16_count(a.obs.channels), reinterpret_cast<uint32_t*>(smem),
+                           scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
+  else
+    search_tile_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box,
+                         a.tmpl_hist_v + slot * a.tile_cap, a.tmpl_hist_q + slot * a.tile_cap,
+                         a.tmpl_hist_n[slot], hist, cum, lut, reinterpret_cast<uint16_t*>(smem),
+                         scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
 }
 
 // Test hook: search tile from an explicit box (glh_stage_search_tile).

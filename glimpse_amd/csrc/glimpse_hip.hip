@@ -78,6 +78,8 @@ static const char* kStageNames[ST_COUNT] = {"init_particles", "evolve_project", 
 // ------------------------------------------------------------------------------------------
 struct Observer {
   int n_images = 0, width = 0, height = 0, channels = 0;
+  int bits = 8;  // bits per sample of the frames: 8, or 16 (glh_observer_set_depth)
+  size_t frame_bytes() const { return (size_t)width * height * channels * (bits / 8); }
   double sigma = 0.3;
   CamDev* cams = nullptr;               // device [n_images]
   std::vector<CamDev> cams_host;        // same, for kernels that take the camera by value
@@ -132,6 +134,7 @@ struct glh_ctx {
   uint16_t* uidx[2] = {nullptr, nullptr};  // [P][N] record of every particle in particles[b] / weights[b] when compact
   bool compact = false;  // particles[cur] / weights[cur] are run-length compact (left by the fused step)
   int32_t* resid_draws = nullptr;  // [P] uniforms consumed by the last residual resampling
+  uint32_t* bins16 = nullptr;   // [P][65535 * 3 + 1] key histograms of 16-bit frames (staged tile kernels), on first use
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
@@ -261,7 +264,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status_all); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
@@ -453,10 +456,22 @@ extern "C" int glh_observer_init(glh_ctx* c, int o, int n_images, int width, int
   ob.width = width;
   ob.height = height;
   ob.channels = channels;
+  ob.bits = 8;
   ob.sigma = sigma;
   ob.frames.assign(n_images, nullptr);
   ob.owned.assign(n_images, nullptr);
   CHK(dalloc(&ob.cams, (size_t)n_images));
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_set_depth(glh_ctx* c, int o, int bits) {
+  CHK(check_obs(c, o));
+  if (bits != 8 && bits != 16) return fail(GLH_E_UNSUPPORTED, "frames are 8 or 16 bits per sample (got %d)", bits);
+  Observer& ob = c->obs[o];
+  if (ob.n_images <= 0) return fail(GLH_E_STATE, "glh_observer_init first");
+  for (auto& p : ob.owned)
+    if (p) return fail(GLH_E_STATE, "observer %d: set the depth before uploading frames", o);
+  ob.bits = bits;
   return GLH_OK;
 }
 
@@ -485,7 +500,7 @@ extern "C" int glh_observer_upload_frame(glh_ctx* c, int o, int image, const uin
   Observer& ob = c->obs[o];
   if (!pixels || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
   HIPCHK(hipSetDevice(c->cfg.device_id));
-  size_t bytes = (size_t)ob.width * ob.height * ob.channels;
+  size_t bytes = ob.frame_bytes();
   if (!ob.owned[image]) CHK(dalloc(&ob.owned[image], bytes));
   HIPCHK(hipMemcpyAsync(ob.owned[image], pixels, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -501,7 +516,7 @@ extern "C" int glh_observer_upload_frame_async(glh_ctx* c, int o, int image, con
   Observer& ob = c->obs[o];
   if (!pixels || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
   HIPCHK(hipSetDevice(c->cfg.device_id));
-  const size_t bytes = (size_t)ob.width * ob.height * ob.channels;
+  const size_t bytes = ob.frame_bytes();
   if (!c->copy_stream) {
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
@@ -899,6 +914,17 @@ static void fill_obs(glh_ctx* c, int o, int image, ObsFrame* f) {
   f->width = ob.width;
   f->height = ob.height;
   f->channels = ob.channels;
+  f->bits = ob.bits;
+  f->bins = c->bins16;
+}
+
+// 16-bit frames: the zeroed per-point key histograms the staged tile kernels of observer `o` count into
+static int prepare_bins16(glh_ctx* c, int o) {
+  if (c->obs[o].bits != 16) return GLH_OK;
+  const size_t per = (size_t)(65535 * 3 + 1);
+  if (!c->bins16) CHK(dalloc(&c->bins16, (size_t)c->cfg.max_points * per));
+  HIPCHK(hipMemsetAsync(c->bins16, 0, (size_t)c->P * (65535 * c->obs[o].channels + 1) * sizeof(uint32_t), c->stream));
+  return GLH_OK;
 }
 
 static int check_images(glh_ctx* c, const int32_t* images) {
@@ -1014,9 +1040,11 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   a.tmpl_valid = c->tmpl_valid;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
+  CHK(prepare_bins16(c, o));
+  a.obs.bins = c->bins16;
   {
     StageTimer t(c, ST_TEMPLATE);
-    hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK), (size_t)c->tw * c->th * sizeof(uint16_t),
+    hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK), (size_t)c->tw * c->th * (ob.bits == 16 ? 4 : 2),
                        c->stream, a);
   }
   HIPCHK(hipGetLastError());
@@ -1056,9 +1084,11 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.box = c->box;
     tp.obs_status = cur_status(c);
     tp.search = c->search;
+    CHK(prepare_bins16(c, o));
+    tp.obs.bins = c->bins16;
     {
       StageTimer t(c, ST_TILEPREP);
-      size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * sizeof(uint16_t);  // (halo of up to 3 rows)
+      size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * (c->obs[o].bits == 16 ? 4 : 2);  // (halo of up to 3 rows)
       hipLaunchKernelGGL(k_tileprep, dim3(c->P), dim3(BLK), lds, c->stream, tp);
     }
     HIPCHK(hipGetLastError());
@@ -1249,6 +1279,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   int nb = 256;
   for (int o = 0; o < O; ++o) {
     if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
+    if (c->obs[o].bits != 8) return false;  // 16-bit frames: staged kernels (key histograms in HBM)
     if (c->obs[o].channels == 3) nb = 766;
   }
   // c[N] and, behind region 2, the pairwise-sum plan

@@ -115,14 +115,22 @@ class Scene:
             self._maps[key] = uv_to_ground(cam, uv).astype(np.float64)
         return self._maps[key]
 
-    def render(self, cam, t, channels=1):
-        """uint8 frame (ny, nx) or (ny, nx, 3) at time t (in time units)."""
+    def render(self, cam, t, channels=1, bits=8):
+        """uint8 (bits=8) or uint16 (bits=16) frame (ny, nx) or (ny, nx, 3) at time t (in time units)."""
         nx, ny = int(cam[6]), int(cam[7])
         xy = self.ground_map(cam) - self.velocity * t
         tx = (xy[:, 0] - self.origin[0]) / self.texel
         ty = (xy[:, 1] - self.origin[1]) / self.texel
         # texture rows follow -y so that the image is not mirrored for a nadir camera
         vals = scipy.ndimage.map_coordinates(self.texture, [ty, tx], order=1, mode="wrap")
+        if bits == 16:
+            # the same scene on a 16-bit sensor: 257 levels per 8-bit level, so tiles hold thousands of distinct values
+            img = np.clip(np.rint(vals * 257.0), 0, 65535).astype(np.uint16).reshape(ny, nx)
+            if channels == 3:
+                g = img.astype(np.int64)
+                img = np.stack((img, np.clip(g + ((g * 7) % 1291) - 600, 0, 65535).astype(np.uint16),
+                                np.clip(65535 - g // 2, 0, 65535).astype(np.uint16)), axis=2)
+            return img
         img = np.clip(np.rint(vals), 0, 255).astype(np.uint8).reshape(ny, nx)
         if channels == 3:
             # deterministic, channel-dependent remap so RGB differs from gray

@@ -188,11 +188,12 @@ class Tracker:
                            max_search_dim=self.max_search_dim, max_frames=n_frames)
         for o, obs in enumerate(self.observers):
             first = obs.images[0].read()
-            if first.dtype != np.uint8:
-                raise NotImplementedError("frames must be uint8 (gray or RGB) on the GPU path")
+            if first.dtype not in (np.uint8, np.uint16):
+                raise NotImplementedError(f"frames must be uint8 or uint16 (gray or RGB) on the GPU path, not {first.dtype}")
             h, w = first.shape[:2]
             ch = 1 if first.ndim == 2 else first.shape[2]
             ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
+            ctx.observer_set_depth(o, first.dtype)
             ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
         ctx.set_highpass(self._highpass_size)
         self._ctx, self._ctx_key = ctx, key
@@ -211,10 +212,7 @@ class Tracker:
         def pixels(job):
             o, img = job
             obs = self.observers[o]
-            a = obs.images[img].read(cache=obs.cache)
-            if a.dtype != np.uint8:
-                raise NotImplementedError("frames must be uint8 (gray or RGB) on the GPU path")
-            return np.ascontiguousarray(a)
+            return np.ascontiguousarray(obs.images[img].read(cache=obs.cache))  # (dtype checked by the upload)
 
         on_disk = [j for j in todo if self.observers[j[0]].images[j[1]].array is None]
         if len(on_disk) > 1:
@@ -683,8 +681,11 @@ class Tracker:
                                max_search_dim=self.max_search_dim, max_frames=2)
             for o, obs in enumerate(self.observers):
                 a0 = obs.images[0].read()
+                if a0.dtype not in (np.uint8, np.uint16):
+                    raise NotImplementedError(f"frames must be uint8 or uint16 on the GPU path, not {a0.dtype}")
                 ctx.observer_init(o, len(obs.images), a0.shape[1], a0.shape[0], 1 if a0.ndim == 2 else a0.shape[2],
                                   obs.sigma)
+                ctx.observer_set_depth(o, a0.dtype)
                 ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
             ctx.begin_sequence(1, n, tile)
             ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))

@@ -531,3 +531,45 @@ def test_tracking_with_another_highpass_window_reproduces_reference(golden, size
     np.testing.assert_allclose(tracks.sigmas, g[f"e2e_sigmas_{size[0]}"], rtol=RTOL, atol=1e-8)
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(images)], highpass={"size": (4, 4)})
+
+
+@pytest.mark.parametrize("name,channels", [("gray", 1), ("rgb", 3)])
+def test_tracking_on_uint16_frames_reproduces_reference(golden, name, channels):
+    """16-bit frames, gray and RGB (Tracker.extract_tile works on any dtype, tracker.py:494-534): whole tracks against
+    the reference run with the same np.random seed, and the last track's template (tile, histogram, box)."""
+    from glimpse_amd import synth
+
+    g = golden("g18_uint16.npz")
+    cam_vec = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    scene = synth.default_scene(cam_vec, seed=12, velocity=(0.15, 0.0), n_frames=5)
+    frames = [scene.render(cam_vec, float(t), channels=channels, bits=16) for t in range(5)]
+    assert frames[0].dtype == np.uint16 and sum(int(f.astype(np.int64).sum()) for f in frames) == int(g[f"{name}_checksum"])
+    cam = camera_from(cam_vec)
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(frames)]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in g[f"{name}_xy"]]
+    np.random.seed(41)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g[f"{name}_means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"{name}_sigmas"], rtol=RTOL, atol=1e-8)
+    tpl = tracker._ctx.get_template(0, len(models) - 1)
+    np.testing.assert_array_equal(tpl["box"], g[f"{name}_tpl_box"])
+    np.testing.assert_array_equal(tpl["histogram"][1], g[f"{name}_tpl_hist_q"])
+    np.testing.assert_allclose(tpl["histogram"][0], g[f"{name}_tpl_hist_v"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(tpl["tile"], g[f"{name}_tpl_tile"], rtol=1e-12, atol=1e-13)
+    # the device RNG and a 7 x 7 high-pass window run on the same (staged) kernels
+    t2 = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128, highpass={"size": 7})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = t2.track(models, tile_size=(15, 15), rng="philox", seed=3)
+    assert np.isfinite(tr.means).all() and np.all(np.abs(tr.means[:, -1, 3] - 0.15) < 0.06)
+    # other sample types are refused, not cast
+    bad = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f.astype(np.float32))
+           for i, f in enumerate(frames)]
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(bad, sigma=0.3)]).track(models, tile_size=(15, 15))

@@ -356,3 +356,26 @@ def test_oracle_highpass_window_sizes(golden):
             np.testing.assert_allclose(tile, g[f"{name}_{k}_tile"], rtol=1e-13, atol=1e-14)
             search = otiles.extract_tile(f[1], g["sbox"], histogram=hist, highpass_size=size)
             np.testing.assert_allclose(search, g[f"{name}_{k}_search"], rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("name,channels", [("gray", 1), ("rgb", 3)])
+def test_oracle_on_uint16_frames(golden, name, channels):
+    """uint16 frames (tracker.py:494-534 works on any dtype): the oracle's whole-track loop on np.random against the
+    reference run with the same seed (g18; the scene is regenerated from its recipe and checked by checksum)."""
+    from glimpse_amd import synth
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    g = golden("g18_uint16.npz")
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    scene = synth.default_scene(cam, seed=12, velocity=(0.15, 0.0), n_frames=5)
+    frames = [scene.render(cam, float(t), channels=channels, bits=16) for t in range(5)]
+    assert sum(int(f.astype(np.int64).sum()) for f in frames) == int(g[f"{name}_checksum"])
+    observers = [otracker.Observer(frames, np.tile(cam, (5, 1)), 0.3)]
+    models = [omotion.CartesianMotion(xy=xy, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0),
+                                      axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0), dem=0.0, dem_sigma=0.0, n=200)
+              for xy in g[f"{name}_xy"]]
+    np.random.seed(41)
+    res = otracker.track(models, observers, np.arange(5)[:, None], np.ones(4), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g[f"{name}_means"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["sigmas"], g[f"{name}_sigmas"], rtol=1e-9, atol=1e-10)

@@ -861,7 +861,46 @@ def g17_highpass():
     np.savez_compressed(os.path.join(OUT, "g17_highpass.npz"), **out)
 
 
+def scene16(channels):
+    """The 16-bit scene of g18 (tests regenerate it from the same recipe and check `checksum`)."""
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    scene = synth.default_scene(cam, seed=12, velocity=(0.15, 0.0), n_frames=5)
+    frames = [scene.render(cam, float(t), channels=channels, bits=16) for t in range(5)]
+    return cam, frames
+
+
+def g18_uint16():
+    """uint16 frames (Tracker.extract_tile works on any dtype, tracker.py:494-534): whole tracks on a gray and an RGB
+    16-bit scene, plus the last track's template (tile, histogram) as the reference holds it after the run."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    out = {}
+    for name, channels in (("gray", 1), ("rgb", 3)):
+        cam, frames = scene16(channels)
+        assert frames[0].dtype == np.uint16
+        pts = synth.grid_points(cam, 3, border_px=70.0, seed=3)
+        imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(len(frames))]
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+        models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in pts]
+        np.random.seed(41)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15))
+        tpl = tracker.templates[0]
+        out.update({f"{name}_means": tracks.means, f"{name}_sigmas": tracks.sigmas, f"{name}_xy": pts,
+                    f"{name}_checksum": np.int64(sum(int(f.astype(np.int64).sum()) for f in frames)),
+                    f"{name}_tpl_tile": tpl["tile"], f"{name}_tpl_hist_v": tpl["histogram"][0],
+                    f"{name}_tpl_hist_q": tpl["histogram"][1], f"{name}_tpl_box": np.asarray(tpl["box"])})
+        print("g18", name, "vx:", tracks.means[:, -1, 3], "distinct template values:", len(tpl["histogram"][0]))
+    np.savez_compressed(os.path.join(OUT, "g18_uint16.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g18" in sys.argv:
+        g18_uint16()
+        sys.exit(0)
     if "--g17" in sys.argv:
         g17_highpass()
         sys.exit(0)
@@ -906,5 +945,6 @@ if __name__ == "__main__":
     g15_ragged()
     g16_custom_motion()
     g17_highpass()
+    g18_uint16()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
