@@ -365,7 +365,8 @@ def worker(args):
     rank, world = group.rank, group.world
     if "WORLD_SIZE" in os.environ and args.gpus != world and args.gpus != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank))  # test hook: several ranks on one GPU
+    # one GPU per rank (LOCAL_RANK); GLH_BENCH_DEVICE is a test hook (several ranks on one GPU)
+    device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank % max(1, _lib.device_count())))
 
     cfg = workloads.CONFIGS[args.workload]
     W, B = max(0, args.warmup), max(0, args.burn_in)

@@ -313,7 +313,12 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   const int twp = ssd_twp(tw);
   const int spr = (wo + SSD_W - 1) / SSD_W;
   const int nstrips = spr * ho;
-  const int G = ssd_row_split(wo, ho);
+  // 1 024-thread workgroups (one per CU: nothing else runs on the CU meanwhile) split the template rows of a strip over
+  // up to 16 lanes while strips x lanes fit the workgroup; the float64 sum of the float32 row sums is exact, so the
+  // grouping of the rows does not change a bit of the result
+  int G = ssd_row_split(wo, ho);
+  if (TB >= 1024)
+    while (G < 16 && nstrips * (G * 2) <= TB) G *= 2;
   const double inv_area = 1.0 / (double)(tw * th);
   const int lgG = __ffs(G) - 1;  // G is a power of two
   const UDiv by_spr = udiv_make(spr);

@@ -43,6 +43,28 @@ def shard_sizes(n_points, world):
     return [hi - lo for lo, hi in (shard_range(n_points, world, r) for r in range(world))]
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration (native libraries write to the descriptor, not to sys.stdout): a
+    launcher that parses this process's stdout sees only what the caller prints."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:  # what the library printed sits in the C runtime's buffer: push it out while 1 still points at stderr
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 # ---- rendezvous -------------------------------------------------------------------------------
 class FileStore:
     """Key -> bytes through a directory shared by the ranks of one node (tmpfs when there is one).
@@ -159,7 +181,8 @@ class Group:
                 why = "" if cid else "rank 0 could not make an RCCL id"
             if cid:
                 try:
-                    ctx.comm_init(cid, self.rank, self.world)
+                    with _stdout_to_stderr():  # librccl prints a version banner on stdout when it initialises
+                        ctx.comm_init(cid, self.rank, self.world)
                     ok = True
                 except _lib.GlhError as e:  # e.g. several ranks on one GPU
                     why = str(e)
