@@ -9,10 +9,14 @@ frames that are already resident in HBM.  Metric (BASELINE.json): particle-frame
 = points x particles x steps / wall, summed over GPUs.
 
 Default workload = BASELINE config 3 as it is worded: 4096 points x 5000 particles tracked through a
-100-frame sequence FROM THE PRIOR (frame 0 initialises particles and templates, the 99 frame updates are the
-timed steps; the first of them work on the wide prior cloud and run longer than the steady state, which is
-reported beside the headline as `steady_ms_per_step`).  The W warm-up steps run the first W updates of the
-same sequence, untimed; the state is then re-initialised (untimed) and the K timed steps start from the prior.
+100-frame sequence FROM THE PRIOR: frame 0 initialises particles and templates, every later frame is timed (the
+first updates work on the wide prior cloud and run longer than the steady state, which is reported beside the
+headline as `steady_ms_per_frame`).  The timed region is always that whole sequence: without --steps it is 99 steps
+of one frame update; with `--steps K` it is K steps of F = round(99 / K) consecutive frame updates each (the driver's
+`--steps 20`: 20 steps x 5 updates over a 101-frame sequence) -- a step is one pass of the hot path over one batch of
+input, here F frames for all points.  The W warm-up steps run the first W steps of the same sequence, untimed; the
+state is then re-initialised (untimed) and the K timed steps start from the prior.  `--burn-in B` (> 0) instead times
+K single-frame steps after B untimed updates (the steady-state window used for A/B runs).
 
 N > 1: one process per GPU, each tracking its own block of points (weak scaling; `--split strong` divides the
 workload's points instead), no data-path collective, ONE RCCL gather of the posterior moments at the end of
@@ -42,7 +46,13 @@ HBM_ACHIEVABLE_GBS = 6290.0  # float4 copy kernel, same guide ("6.29 TB/s measur
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed frame updates (default: the whole sequence)")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: one per frame update of the whole sequence).  With --burn-in 0 the "
+                         "timed region is ALWAYS the configuration's whole sequence from the prior: K steps of F "
+                         "consecutive frame updates each, F = round((frames - 1) / K) (--steps 20 on the 100-frame C3: 20 "
+                         "steps x 5 updates)")
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="frame updates per timed step (0 = automatic, see --steps; 1 with --burn-in > 0)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--points", type=int, default=None, help="override points per GPU")
@@ -371,14 +381,15 @@ def worker(args):
     cfg = workloads.CONFIGS[args.workload]
     W, B = max(0, args.warmup), max(0, args.burn_in)
     if args.steps is None:
-        T = cfg["frames"]
-        K = T - 1 - B
+        K, F = cfg["frames"] - 1 - B, 1
     else:
         K = args.steps
-        T = 1 + B + K
+        F = args.frames_per_step if args.frames_per_step > 0 else \
+            (max(1, round((cfg["frames"] - 1) / K)) if B == 0 else 1)
     if K < 1:
         raise SystemExit("need at least one timed step")
-    W = min(W, T - 1)
+    T = 1 + B + K * F  # frames of the sequence: frame 0 initialises, then burn-in, then K steps of F updates
+    W = min(W, (T - 1) // F)
     strong = args.split == "strong"
     if strong:
         # the configuration's points (or --points of them) divided over the ranks: every rank builds the same
@@ -436,14 +447,14 @@ def worker(args):
             ctx.init_templates(o, 0)
         ctx.record_moments(0)
 
-    F = K if args.frames_per_call <= 0 else min(args.frames_per_call, K)
+    C = K * F if args.frames_per_call <= 0 else min(args.frames_per_call, K * F)
 
     def run(first, count):
-        """`count` consecutive frame updates from frame `first`: glh_track calls of up to F frames each (the frame
-        loop of tracker.py:326-357, one kernel launch per frame), or glh_step per frame when F == 1."""
+        """`count` consecutive frame updates from frame `first`: glh_track calls of up to C frames each (the frame
+        loop of tracker.py:326-357, one kernel launch per frame), or glh_step per frame when C == 1."""
         i = first
         while i < first + count:
-            n = min(F, first + count - i)
+            n = min(C, first + count - i)
             if n == 1:
                 ctx.step(i, 1.0, images(i), seed=seed)
             else:
@@ -454,7 +465,7 @@ def worker(args):
         return group.gather_moments(ctx, 0, T, sizes)
 
     initialise()
-    run(1, W)  # warm-up: the first W updates of the same sequence, untimed
+    run(1, W * F)  # warm-up: the first W steps of the same sequence, untimed
     if world > 1:
         gather()  # warm the communicator up outside the timed region
     ctx.sync()
@@ -467,7 +478,7 @@ def worker(args):
     ctx.profile_reset()
     group.barrier()
     t0 = time.perf_counter()
-    run(1 + B, K)
+    run(1 + B, K * F)
     gathered = None
     if world > 1:
         ctx.sync()
@@ -495,7 +506,7 @@ def worker(args):
     gathered_ok = None
     if world > 1 and rank == 0:
         allm, allst = gathered
-        gathered_ok = bool(allm.shape == (T, sum(sizes), 12) and np.isfinite(allm[1 + B:1 + B + K]).all()
+        gathered_ok = bool(allm.shape == (T, sum(sizes), 12) and np.isfinite(allm[1 + B:]).all()
                            and np.array_equal(allm[:, :wl.P], moments_local))
         n_err = int((allst != 0).sum())
     rc = 0
@@ -503,7 +514,7 @@ def worker(args):
         np.save(args.dump_moments, gathered[0] if world > 1 else moments_local)
     if rank == 0:
         total_points = sum(sizes)
-        value = total_points * wl.N * K / elapsed
+        value = total_points * wl.N * K * F / elapsed
         out = {
             "metric": "particle-frames/s",
             "value": value,
@@ -512,6 +523,7 @@ def worker(args):
             "steps": K,
             "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
+            "ms_per_frame": 1e3 * elapsed / (K * F),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -519,39 +531,44 @@ def worker(args):
             "data": "synthetic",
             "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
                            math=args.math if args.motion == "cartesian" else "exact (general kernel)", parallelism=f"points sharded x{world}",
-                           total_points=total_points, frames_per_s=K / elapsed, burn_in_steps=B, frames_per_call=F,
-                           timed_from="the prior (frame 0 initialises, every later frame is a timed step)" if B == 0
-                           else f"after {B} untimed updates"),
+                           total_points=total_points, frames_per_s=K * F / elapsed, burn_in_steps=B, frames_per_call=C,
+                           frame_updates_per_step=F,
+                           step=f"{F} consecutive frame update(s) of all {total_points} points",
+                           timed_from="the prior: frame 0 initialises, all the later frames are timed "
+                                      f"({K} steps x {F} updates)" if B == 0 else f"after {B} untimed updates"),
             "rccl_ranks": world if transport == "rccl" else 0,
             "collective": {"none": "none (1 rank)", "rccl": "RCCL ncclSend/ncclRecv gather inside libglimpse_hip.so",
                            "host": "host copies through the rendezvous directory (RCCL unavailable: "
                                    + getattr(group, "why_host", "") + ")"}[transport],
             "health": {"observer_ok_fraction": frac_ok, "points_with_error_bits": n_err,
                        "gathered_moments_finite": gathered_ok,
-                       "final_means_finite": bool(np.isfinite(moments_local[B + K]).all())},
+                       "final_means_finite": bool(np.isfinite(moments_local[T - 1]).all())},
         }
         tot = sum(ms for ms, _ in stage_ms.values())
         dom_ms, dom_n = stage_ms[dom]
         per_launch_ms = dom_ms / max(dom_n, 1)
         launches_per_step = dom_n / K
-        # one launch of the dominant kernel processes P*N particle-frames (SURVEY 8(d) per-unit bytes)
-        ach = abytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9
+        launches_per_frame = dom_n / (K * F)
+        # one launch of the dominant kernel processes P*N particle-frames (SURVEY 8(d) per-unit bytes); `abytes` are
+        # the algorithmic bytes of ONE frame update
+        ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         kern = KERNEL_OF_STAGE.get(dom, dom)
         roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern),
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": abytes / launches_per_step,
+                "algorithmic_bytes_per_launch": abytes / launches_per_frame,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
-                "ssd_fp32_tflops": flops / (tot / K * 1e-3) / 1e12,
+                "ssd_fp32_tflops": flops / (tot / (K * F) * 1e-3) / 1e12,
                 # what a float4 copy kernel reaches on this chip (MI355X_MICROARCH.md), and this GPU's own
                 # hipMemcpyDtoD rate ("a measured device-copy ceiling")
                 "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
         out["roofline"] = roof
         out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
-        if len(launch_ms) == dom_n and launches_per_step == 1:
-            tail = launch_ms[-min(20, K):]
-            out["steady_ms_per_step"] = float(tail.mean())
+        if len(launch_ms) == dom_n and launches_per_frame == 1:
+            tail = launch_ms[-min(20, K * F):]
+            out["steady_ms_per_frame"] = float(tail.mean())
+            out["steady_ms_per_step"] = float(tail.mean()) * F
             out["steady_value"] = wl.P * wl.N / (float(tail.mean()) * 1e-3) * world
             out["steady_roofline_frac"] = abytes / (float(tail.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:8]]

@@ -69,7 +69,7 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(tmp_path):
     """`--gpus 2` starts two ranks; with `--split strong` they track the two halves of the points that one rank
     tracks alone, so the gathered posterior history must be the single-rank one (the device RNG is keyed on the
     global point index)."""
-    common = ["--workload", "C2", "--points", "16", "--particles", "600", "--steps", "3", "--warmup", "1",
+    common = ["--workload", "C2", "--points", "16", "--particles", "600", "--steps", "3", "--warmup", "1", "--frames-per-step", "1",
               "--no-cpu-baseline", "--no-api", "--split", "strong"]
     two = _bench(["--gpus", "2", "--transport", "host", "--dump-moments", str(tmp_path / "two.npy")] + common)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
