@@ -83,8 +83,11 @@ def test_tracker_guards(golden):
     observers = observers_from(g)
     with pytest.raises(ValueError):
         glimpse_amd.Tracker(observers, resample_method="multinomial")
-    with pytest.raises(NotImplementedError):
-        glimpse_amd.Tracker(observers, highpass={"size": (3, 3)})
+    for bad in ({"size": (4, 4)}, {"size": (9, 9)}, {"size": (5, 5), "mode": "nearest"}, {"size": (3, 3, 3)}):
+        with pytest.raises(NotImplementedError):
+            glimpse_amd.Tracker(observers, highpass=bad)
+    assert glimpse_amd.Tracker(observers, highpass={"size": 3})._highpass_size == (3, 3)
+    assert glimpse_amd.Tracker(observers, highpass={"size": (3, 7)})._highpass_size == (3, 7)
     tracker = glimpse_amd.Tracker(observers)
     models = models_from(g)
     other = glimpse_amd.CartesianMotion(xy=(0, 0), time_unit=datetime.timedelta(hours=1), dem=0, dem_sigma=0)
