@@ -572,7 +572,6 @@ def worker(args):
             out["steady_value"] = wl.P * wl.N / (float(tail.mean()) * 1e-3) * world
             out["steady_roofline_frac"] = abytes / (float(tail.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:8]]
-    group_ok = True
     ctx_closed = False
     if rank == 0 and world == 1:
         if not args.no_api:
@@ -595,7 +594,7 @@ def worker(args):
     group.close()
     if not ctx_closed:
         ctx.close()
-    return rc if group_ok else 4
+    return rc
 
 
 def main():
