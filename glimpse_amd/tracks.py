@@ -3,56 +3,40 @@ Same constructor, array shapes and properties, plus the steps that follow a trac
 `reverse` (tracks.py:131-149), `from_multiple` (:151-191, merging e.g. a forward and a backward
 run) and `average` (:193-213).  These are host-side NumPy on (tracks, times, 6) result arrays, as in
 the reference; plotting / animation are out of scope."""
-import warnings as _warnings
-
 import numpy as np
 
 
-def combine_normals(means, sigmas, weights=None, normalize=False, correlation=0, axis=None, keepdims=False,
-                    ignore_nan=False):
-    """Mean and standard deviation of a weighted sum of normal variables along `axis`
-    (helpers.sum_normals, helpers.py:523-610; linear propagation of uncertainty with one common
-    correlation coefficient):
+def fuse_normals(means, sigmas, axis, comonotone=False, ignore_nan=False):
+    """Precision-weighted combination of normal estimates along `axis` (what the reference does with
+    helpers.sum_normals(weights=sigma**-2, normalize=True), tracks.py:185-189 and :207-213).
 
-        m = sum_i w_i m_i          var = sum_i w_i^2 s_i^2 + 2 rho sum_{i<j} w_i w_j s_i s_j
+    With weights w_i = s_i^-2 / sum_j s_j^-2 over the entries that are present,
 
-    NaNs must coincide in `means` and `sigmas`; they are skipped in the sums and make the result NaN
-    where any (ignore_nan=False) or all (ignore_nan=True) inputs are missing.  `normalize` rescales
-    the weights to sum to one over the non-missing inputs."""
-    means = np.asarray(means, dtype=float)
-    sigmas = np.asarray(sigmas, dtype=float)
-    missing = np.isnan(means)
-    if (missing != np.isnan(sigmas)).any():
+        mean = sum_i w_i m_i        sigma = sqrt(sum_i (w_i s_i)^2)      independent estimates (several runs)
+                                    sigma = sum_i w_i s_i                fully correlated ones (`comonotone`: the
+                                                                          time steps of one track; the variance of a
+                                                                          sum with correlation 1 is the square of the
+                                                                          summed sigmas)
+
+    NaN marks a missing estimate and must coincide in `means` and `sigmas`; the result is missing where any
+    (ignore_nan=False) or every (ignore_nan=True) entry along the axis is."""
+    m = np.asarray(means, dtype=float)
+    s = np.asarray(sigmas, dtype=float)
+    present = ~np.isnan(m)
+    if (present != ~np.isnan(s)).any():
         raise ValueError("Means and sigmas have missing values at different indices")
-    if (sigmas == 0).any():
+    if (s == 0).any():
         raise ValueError("Sigmas cannot be zero")
-    w = np.ones(means.shape) if weights is None else np.asarray(weights, dtype=float)
-    if normalize:
-        with _warnings.catch_warnings():
-            _warnings.simplefilter("ignore", RuntimeWarning)
-            w = w * (1 / np.nansum(w * ~missing, axis=axis, keepdims=True))
-    total = np.nansum(w * means, axis=axis, keepdims=True)
-    var = np.nansum(w ** 2 * sigmas ** 2, axis=axis, keepdims=True)
-    gone = missing.all(axis=axis, keepdims=True) if ignore_nan else missing.any(axis=axis, keepdims=True)
-    total[gone] = np.nan
-    var[gone] = np.nan
-    if correlation:
-        n = means.size if axis is None else means.shape[axis]
-        i, j = np.triu_indices(n=n, k=1)
-        ws = w * sigmas if axis is not None else (w * sigmas).ravel()
-        ax = 0 if axis is None else axis
-        cross = np.take(ws, i, axis=ax) * np.take(ws, j, axis=ax)
-        if axis is None:
-            extra = np.nansum(correlation * cross)
-        else:
-            extra = np.nansum(correlation * cross, axis=axis, keepdims=True)
-        var = var + 2 * extra
-    sd = np.sqrt(var)
-    if not keepdims:
-        if axis is None:
-            return total.reshape(-1)[0], sd.reshape(-1)[0]
-        total, sd = np.squeeze(total, axis=axis), np.squeeze(sd, axis=axis)
-    return total, sd
+    with np.errstate(invalid="ignore", divide="ignore"):
+        precision = np.where(present, 1.0 / (s * s), 0.0)
+        w = precision * (1.0 / precision.sum(axis=axis, keepdims=True))
+        mean = np.where(present, w * m, 0.0).sum(axis=axis)
+        spread = np.where(present, w * s, 0.0)
+        sigma = spread.sum(axis=axis) if comonotone else np.sqrt((spread * spread).sum(axis=axis))
+    gone = (~present).all(axis=axis) if ignore_nan else (~present).any(axis=axis)
+    mean[gone] = np.nan
+    sigma[gone] = np.nan
+    return mean, sigma
 
 
 class Tracks:
@@ -102,15 +86,13 @@ class Tracks:
                 raise ValueError(f"Time units are not equal for all runs: {set(r.time_unit for r in runs)}")
         m = np.stack([np.asarray(run.means, dtype=float) for run in runs], axis=-1)
         sd = np.stack([np.asarray(run.sigmas, dtype=float) for run in runs], axis=-1)
-        means, sigmas = combine_normals(m, sd, weights=1.0 / (sd * sd), normalize=True, correlation=0, axis=m.ndim - 1,
-                                        ignore_nan=ignore_nan)
+        means, sigmas = fuse_normals(m, sd, axis=m.ndim - 1, ignore_nan=ignore_nan)
         return cls(datetimes=head.datetimes, time_unit=head.time_unit, means=means, sigmas=sigmas)
 
     def average(self, ignore_nan=False):
-        """Time-averaged mean and sigma of each track (tracks.py:193-213): inverse-variance weights,
-        time steps assumed fully correlated."""
-        return combine_normals(self.means, self.sigmas, weights=self.sigmas ** -2, normalize=True, correlation=1,
-                               axis=1, ignore_nan=ignore_nan)
+        """Time-averaged mean and sigma of each track (tracks.py:193-213): precision weights, the time steps of a
+        track taken as fully correlated."""
+        return fuse_normals(self.means, self.sigmas, axis=1, comonotone=True, ignore_nan=ignore_nan)
 
     # ---- views of the state vector (x, y, z, vx, vy, vz) ----------------------------------------
     def _spread(self, lo, hi):
