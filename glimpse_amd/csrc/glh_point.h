@@ -447,6 +447,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ double bred[NOBS][PT_WAVES][5];
   __shared__ uint32_t scan_tmp[PT_WAVES];
   __shared__ int s_box[NOBS][4];
+  __shared__ double s_uvbb[NOBS][4];  // min u, min v, max u, max v of the point's projected particles (phase A)
   __shared__ int s_status[NOBS];
   __shared__ double s_u;     // np.random.random() of this point's systematic resampling (tracker.py:173)
   __shared__ double s_K[6];  // the point's first evolved particle: pivot of the shifted moments (phase A -> F)
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           nf = fmax(nf, bred[o][w][4]);
         }
         st = GLH_OBS_OK;
+        s_uvbb[o][0] = mnu; s_uvbb[o][1] = mnv; s_uvbb[o][2] = mxu; s_uvbb[o][3] = mxv;
         const ObsFrame& ob = a.obs[o];
         if (search_box(mnu, mnv, mxu, mxv, nf != 0.0, a.tw, a.th, a.cam[o].imgsz[0], a.cam[o].imgsz[1], s_box[o]))
           st = GLH_OBS_OUT_OF_BOUNDS;
@@ -771,9 +773,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double scale = a.inv2s2[o];
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
+      // "Some sampling points are outside box" (observer.py:201-202): some particle's uv is outside the box exactly
+      // when the bounding box of all of them is (NaNs never get here: they skip the observer) -- one test per
+      // point instead of four comparisons per particle
+      if (!(s_uvbb[o][0] >= sb[0] && s_uvbb[o][2] <= sb[2] && s_uvbb[o][1] >= sb[1] && s_uvbb[o][3] <= sb[3]))
+        outside = true;
       if (o == 0) {
         auto sample_one = [&](double2 q) -> double {
-          if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           const double term = spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           // a single observer and no motion-model term: this IS the log likelihood, the weight follows at once
@@ -817,7 +823,6 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int i = tid; i < N; i += TB) {
           const double2 q = qn;
           qn = uvp[i + TB < N ? i + TB : 0];
-          if (!(q.x >= sb[0] && q.x <= sb[2] && q.y >= sb[1] && q.y <= sb[3])) outside = true;
           c[i] += spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
         }
       }
