@@ -389,9 +389,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
 #define GLH_PT_VARIANTS(SURF_, FAST_)                                                                             \
   (const void*)k_point_step<512, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 0, 4, 2, SURF_, FAST_>,     \
   (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_>,    \
-  (const void*)k_point_step<512, 4, 4, 2, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 2, SURF_, FAST_>,    \
   (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_>,   \
-  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 10, 4, 2, SURF_, FAST_>
+  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_>
     for (const void* f : {GLH_PT_VARIANTS(false, false), GLH_PT_VARIANTS(true, false), GLH_PT_VARIANTS(false, true)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
@@ -1387,13 +1386,14 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
                        pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
     const dim3 grid(c->P);
     // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  uv of observer 0
-    // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that.
+    // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that -- and always
+    // with two observers: their register-resident variants spill (37 VGPRs at PPT = 10) and measured 4 % slower at C5.
     const bool big = c->N > 10 * PT_BLK;
     const int tb = big ? PT_BLK_BIG : PT_BLK;
     const dim3 block(tb);
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
     if (big && ppt == 4) ppt = 10;
-    if (getenv("GLH_PT_UVLDS")) ppt = 0;
+    if (getenv("GLH_PT_UVLDS") || O == 2) ppt = 0;
     // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian;
     const bool fast = use_fast(c);
@@ -1412,17 +1412,14 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
         else if (ppt == 10) GLH_LAUNCH_POINT(512, 10, 1);
         else GLH_LAUNCH_POINT(512, 0, 1);
       } else {
-        if (ppt == 4) GLH_LAUNCH_POINT(512, 4, 2);
-        else if (ppt == 10) GLH_LAUNCH_POINT(512, 10, 2);
-        else GLH_LAUNCH_POINT(512, 0, 2);
+        GLH_LAUNCH_POINT(512, 0, 2);
       }
     } else {
       if (O == 1) {
         if (ppt == 10) GLH_LAUNCH_POINT(1024, 10, 1);
         else GLH_LAUNCH_POINT(1024, 0, 1);
       } else {
-        if (ppt == 10) GLH_LAUNCH_POINT(1024, 10, 2);
-        else GLH_LAUNCH_POINT(1024, 0, 2);
+        GLH_LAUNCH_POINT(1024, 0, 2);
       }
     }
 #undef GLH_LAUNCH_POINT

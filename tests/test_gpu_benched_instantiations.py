@@ -3,7 +3,7 @@
 
     C3:  N =  5 000  -> k_point_step<512, 10, 4, 1, ...>
     C4:  N = 10 000  -> k_point_step<1024, 10, 4, 1, ...>
-    C5:  N =  5 000, two observers, DEM term -> k_point_step<512, 10, 4, 2, ...>
+    C5:  N =  5 000, two observers, DEM term -> k_point_step<512, 0, 4, 2, ...>
 
 resample indices bit for bit, posteriors to 1e-7 (a few points are enough: the oracle is a NumPy loop)."""
 import numpy as np
