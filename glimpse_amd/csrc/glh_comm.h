@@ -83,6 +83,7 @@ struct Comm {
   int rank = 0, world = 1;
   double* stage = nullptr;   // root: [sum_r n_frames * P_r * 12] doubles, then [sum_r P_r] status words
   size_t stage_bytes = 0;
+  size_t gathered_doubles = 0, gathered_points = 0, gathered_status_off = 0;  // what the last gather left in `stage`
   double* scalar = nullptr;  // one double / one int for the barrier and the max-reduction
 };
 

@@ -1795,7 +1795,6 @@ extern "C" int glh_gather_moments(glh_ctx* c, int root, int frame0, int n_frames
     return fail(GLH_E_INVALID, "points_per_rank[%d] = %d, but this context tracks %d points", k->rank,
                 points_per_rank[k->rank], c->P);
   const bool is_root = k->rank == root;
-  if (is_root && !out) return fail(GLH_E_INVALID, "the root needs an output buffer");
   HIPCHK(hipSetDevice(c->cfg.device_id));
   size_t total_pts = 0;
   for (int r = 0; r < k->world; ++r) {
@@ -1833,11 +1832,30 @@ extern "C" int glh_gather_moments(glh_ctx* c, int root, int frame0, int n_frames
   for (ncclResult_t r : {r1, r2, r3, r4})
     if (r != ncclSuccess) return fail(GLH_E_COMM, "moments gather failed: %s", api->GetErrorString(r));
   if (is_root) {
-    HIPCHK(hipMemcpyAsync(out, k->stage, mom_doubles * 8, hipMemcpyDeviceToHost, c->stream));
-    if (status)
+    k->gathered_doubles = mom_doubles;
+    k->gathered_points = total_pts;
+    k->gathered_status_off = st_off;
+    if (out) HIPCHK(hipMemcpyAsync(out, k->stage, mom_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out && status)
       HIPCHK(hipMemcpyAsync(status, reinterpret_cast<uint8_t*>(k->stage) + st_off, total_pts * 4, hipMemcpyDeviceToHost,
                             c->stream));
   }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return GLH_OK;
+}
+
+// Host copy of what the last glh_gather_moments left on the root's device (when it was called with out = NULL: the
+// exchange itself is then all that a caller times).
+extern "C" int glh_get_gathered(glh_ctx* c, double* out, uint32_t* status) {
+  CHK(need_comm(c));
+  Comm* k = c->comm;
+  if (!k->stage || !k->gathered_doubles) return fail(GLH_E_STATE, "no gathered moments on this rank");
+  if (!out) return fail(GLH_E_INVALID, "out is null");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  HIPCHK(hipMemcpyAsync(out, k->stage, k->gathered_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+  if (status)
+    HIPCHK(hipMemcpyAsync(status, reinterpret_cast<uint8_t*>(k->stage) + k->gathered_status_off, k->gathered_points * 4,
+                          hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return GLH_OK;
 }

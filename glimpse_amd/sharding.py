@@ -222,12 +222,13 @@ class Group:
         self.store.put(f"max.{k}.{self.rank}", repr(float(value)).encode())
         return max(float(self.store.get(f"max.{k}.{r}").decode()) for r in range(self.world))
 
-    def gather_moments(self, ctx, frame0, n_frames, points_per_rank, root=0):
+    def gather_moments(self, ctx, frame0, n_frames, points_per_rank, root=0, download=True):
         """Every rank's moments history [n_frames][P_rank][12] and status words to `root`: (moments
         (n_frames, sum P, 12), status (sum P,)) there, None elsewhere.  RCCL inside the library, or host copies
-        through the store when the group runs on the "host" transport."""
+        through the store when the group runs on the "host" transport.  download=False (RCCL): the blocks stay on
+        the root's device -- the exchange is all that happens -- and `ctx.gathered()` fetches them later."""
         if self.transport == "rccl":
-            return ctx.gather_moments(frame0, n_frames, points_per_rank, root=root)
+            return ctx.gather_moments(frame0, n_frames, points_per_rank, root=root, download=download)
         mine = ctx.get_moments(frame0, n_frames)
         status = ctx.point_status()
         if self.world == 1:

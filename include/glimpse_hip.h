@@ -345,6 +345,9 @@ int glh_comm_max_f64(glh_ctx* ctx, double* value);
  * | P_0 | P_1 | ... |; other ranks pass NULL.  Blocks until the exchange is over.                        */
 int glh_gather_moments(glh_ctx* ctx, int root, int frame0, int n_frames, const int32_t* points_per_rank,
                        double* out, uint32_t* status);
+/* On the root, `out` may be NULL: the blocks then stay in the root's device memory (the exchange is all the call does)
+ * and glh_get_gathered copies them to the host later, in the layout above.                                        */
+int glh_get_gathered(glh_ctx* ctx, double* out, uint32_t* status);
 
 /* ---- stage-level test hooks (stateless; each runs one kernel on explicit inputs) -------- */
 /* Camera.xyz_to_uv (camera.py:591-628): xyz [n][3] -> uv [n][2].                            */

@@ -46,6 +46,11 @@ def test_rccl_communicator_one_rank():
         # a sub-range of the frames
         mom2, _ = group.gather_moments(ctx, 1, 2, [ctx.P])
         np.testing.assert_array_equal(mom2, ctx.get_moments(1, 2))
+        # the exchange alone (what bench.py times), the host copy afterwards
+        assert group.gather_moments(ctx, 0, T, [ctx.P], download=False) is None
+        mom3, status3 = ctx.gathered()
+        np.testing.assert_array_equal(mom3, mom)
+        np.testing.assert_array_equal(status3, status)
         with pytest.raises(lib.GlhError):
             ctx.gather_moments(0, T, [ctx.P + 1])
         group.close()
