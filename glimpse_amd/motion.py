@@ -59,21 +59,30 @@ class CartesianMotion(Motion):
     N_INIT_V = 3      # velocity normals drawn by initialize_particles: randn(n, 3)
     TANGENT = False   # evolve draws randn(n, 3) (False) or randn(n, 2) then randn(n) (True)
 
-    def params_full(self):
-        """GLH_MOTION_FULL_LEN doubles (include/glimpse_hip.h): params() | kind | slope_sigma | 0 0 0 0."""
-        return np.concatenate((self.params(), [self.KIND, getattr(self, "slope_sigma", 0.0),
-                                               isinstance(self.dem, Raster), isinstance(self.dem_sigma, Raster), 0, 0]))
+    def _rates(self):
+        """(velocity, its sigma, acceleration, its sigma) in the model's own coordinates, 3 components each."""
+        return self.vxyz, self.vxyz_sigma, self.axyz, self.axyz_sigma
 
-    def _surface_scalars(self):
-        return [0.0 if isinstance(self.dem, Raster) else self.dem,
-                0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma]
+    def fill_params(self, row):
+        """Write this model into one row of the [P][GLH_MOTION_FULL_LEN] table of glh_set_motion (slice assignment
+        broadcasts scalars: the Tracker fills thousands of rows per run)."""
+        v, vs, a, as_ = self._rates()
+        row[0:2], row[2:4] = self.xy, self.xy_sigma
+        row[4:7], row[7:10], row[10:13], row[13:16] = v, vs, a, as_
+        row[16] = 0.0 if isinstance(self.dem, Raster) else self.dem
+        row[17] = 0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma
+        row[18], row[19] = self.KIND, getattr(self, "slope_sigma", 0.0)
+        row[20], row[21] = isinstance(self.dem, Raster), isinstance(self.dem_sigma, Raster)
+
+    def params_full(self):
+        """GLH_MOTION_FULL_LEN doubles (include/glimpse_hip.h): params() | kind | slope_sigma | raster flags | 0 0."""
+        row = np.zeros(24)
+        self.fill_params(row)
+        return row
 
     def params(self):
         """GLH_MOTION_LEN doubles (include/glimpse_hip.h)."""
-        def v(x, n):
-            return np.broadcast_to(np.asarray(x, dtype=float), (n,))
-        return np.concatenate((v(self.xy, 2), v(self.xy_sigma, 2), v(self.vxyz, 3), v(self.vxyz_sigma, 3),
-                               v(self.axyz, 3), v(self.axyz_sigma, 3), self._surface_scalars()))
+        return self.params_full()[:18]
 
     def initialize_particles(self):
         """motion.py:149-163."""
@@ -102,10 +111,6 @@ class CartesianMotion(Motion):
         return ll
 
 
-def _v(x, n):
-    return np.broadcast_to(np.asarray(x, dtype=float), (n,)).astype(float)
-
-
 class CylindricalMotion(CartesianMotion):
     """motion.py:207-311: like CartesianMotion with velocity / acceleration given as (radius rate,
     direction theta in radians, dz/dt)."""
@@ -119,9 +124,8 @@ class CylindricalMotion(CartesianMotion):
         self.xy, self.time_unit, self.n, self.xy_sigma = xy, time_unit, int(n), xy_sigma
         self.vrthz, self.vrthz_sigma, self.arthz, self.arthz_sigma = vrthz, vrthz_sigma, arthz, arthz_sigma
 
-    def params(self):
-        return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(self.vrthz, 3), _v(self.vrthz_sigma, 3),
-                               _v(self.arthz, 3), _v(self.arthz_sigma, 3), self._surface_scalars()))
+    def _rates(self):
+        return self.vrthz, self.vrthz_sigma, self.arthz, self.arthz_sigma
 
     def initialize_particles(self):
         """motion.py:262-286."""
@@ -166,16 +170,23 @@ class TangentCartesianMotion(Motion):
     def _v4(self):
         return self.vxy, self.vxy_sigma, self.axy, self.axy_sigma
 
-    def params(self):
+    def fill_params(self, row):
+        """One row of the [P][GLH_MOTION_FULL_LEN] table (two horizontal components; the third slots stay 0)."""
         v, vs, a, as_ = self._v4()
-        z = [0.0]
-        return np.concatenate((_v(self.xy, 2), _v(self.xy_sigma, 2), _v(v, 2), z, _v(vs, 2), z, _v(a, 2), z,
-                               _v(as_, 2), z, [0.0 if isinstance(self.dem, Raster) else self.dem,
-                                               0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma]))
+        row[0:2], row[2:4] = self.xy, self.xy_sigma
+        row[4:6], row[7:9], row[10:12], row[13:15] = v, vs, a, as_
+        row[16] = 0.0 if isinstance(self.dem, Raster) else self.dem
+        row[17] = 0.0 if isinstance(self.dem_sigma, Raster) else self.dem_sigma
+        row[18], row[19] = self.KIND, self.slope_sigma
+        row[20], row[21] = isinstance(self.dem, Raster), isinstance(self.dem_sigma, Raster)
 
     def params_full(self):
-        return np.concatenate((self.params(), [self.KIND, self.slope_sigma, isinstance(self.dem, Raster),
-                                               isinstance(self.dem_sigma, Raster), 0, 0]))
+        row = np.zeros(24)
+        self.fill_params(row)
+        return row
+
+    def params(self):
+        return self.params_full()[:18]
 
     def _initial_velocity(self, normals):
         return self.vxy + self.vxy_sigma * normals
