@@ -578,20 +578,28 @@ def worker(args):
             out["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:8]]
     ctx_closed = False
     if rank == 0 and world == 1:
+        # the side legs must not cost the headline: a failure is reported in the line, the run then exits non-zero
         if not args.no_api:
             ctx.close()
             ctx_closed = True
-            out.update(api_leg(wl, frames, T, seed, device, args.max_search_dim))
+            try:
+                out.update(api_leg(wl, frames, T, seed, device, args.max_search_dim))
+            except Exception as e:  # noqa: BLE001
+                out["api_error"] = repr(e)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, frames, T, args.cpu_seconds)
-            workers = args.cpu_workers if args.cpu_workers > 0 else usable_cores()
-            if workers > 1 and wl.P >= 2 * workers:
-                out["cpu_baseline_parallel"] = cpu_baseline_parallel(
-                    wl, frames, T, cpu_baseline.per_point_seconds, args.cpu_seconds, workers)
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, frames, T, args.cpu_seconds)
+                workers = args.cpu_workers if args.cpu_workers > 0 else usable_cores()
+                if workers > 1 and wl.P >= 2 * workers:
+                    out["cpu_baseline_parallel"] = cpu_baseline_parallel(
+                        wl, frames, T, cpu_baseline.per_point_seconds, args.cpu_seconds, workers)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline_error"] = repr(e)
     if rank == 0:
         h = out["health"]
         if h["points_with_error_bits"] or h["observer_ok_fraction"] < 0.99 or not h["final_means_finite"] \
-                or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False:
+                or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False \
+                or "api_error" in out or "cpu_baseline_error" in out:
             rc = 3
             out["health"]["verdict"] = "UNHEALTHY"
         print(json.dumps(out), flush=True)
