@@ -199,3 +199,17 @@ def test_fast_arithmetic_restatements_stay_within_a_few_ulp(hc, golden):
         assert np.array_equal(np.isnan(got), np.isnan(uv))
         ok = ~np.isnan(uv[:, 0])
         np.testing.assert_allclose(got[ok], uv[ok], rtol=1e-12, atol=1e-8)
+
+
+def test_host_tables_and_stage_math_under_sanitizers():
+    """AddressSanitizer + UndefinedBehaviorSanitizer over the host-side tables of the C ABI (pairwise-sum plans, spline
+    LU factors / inverses / basis polynomials, camera expansion) and the inline stage math shared with the kernels
+    (tests/hostcheck/sanitize_main.cpp).  GPU sanitizers are not available on the pool; this is the CPU build."""
+    src = os.path.join(ROOT, "tests", "hostcheck", "sanitize_main.cpp")
+    exe = os.path.join(ROOT, "tests", "hostcheck", "_build", "sanitize_main")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-ffp-contract=off", "-o", exe, src], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert r.returncode == 0 and "SANITIZE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
