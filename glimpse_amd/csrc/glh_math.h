@@ -675,6 +675,10 @@ GLH_HD void philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
                          uint32_t k1, uint32_t* out) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #if defined(__HIP_DEVICE_COMPILE__)
+  // The key is uniform (it comes from the seed).  Opaque to the optimiser at every call: otherwise the 2 x ROUNDS round
+  // keys are hoisted out of the particle loops as kernel-wide constants, spilled for lack of scalar registers and
+  // restored by ~9 v_readlane per call; recomputed here they are scalar adds beside the vector work.
+  asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
 #endif
   for (int r = 0; r < ROUNDS; ++r) {
