@@ -5,6 +5,7 @@ import datetime
 import numpy as np
 
 from . import _lib
+from .timeutil import select_datetimes
 
 
 class Observer:
@@ -63,3 +64,56 @@ class Observer:
         if outside.any():
             raise ValueError("Some sampling points are outside box")
         return values
+
+    def shift_tile(self, tile, duv, **kwargs):
+        """observer.py:146-176: resample a tile at pixel centres moved by (du, dv), each at most half a pixel
+        (host spline: a plotting / alignment helper, not on the tracking path)."""
+        import scipy.interpolate
+        du, dv = (float(v) for v in duv)
+        if max(abs(du), abs(dv)) > 0.5:
+            raise ValueError("Shift larger than 0.5 pixels")
+        tile = np.asarray(tile)
+        rows, cols = np.arange(tile.shape[0]) + 0.5, np.arange(tile.shape[1]) + 0.5
+        bands = tile[:, :, None] if tile.ndim == 2 else tile
+        for b in range(bands.shape[2]):  # in place, like the reference
+            bands[:, :, b] = scipy.interpolate.RectBivariateSpline(rows, cols, bands[:, :, b], **kwargs)(
+                rows + dv, cols + du, grid=True)
+        return tile
+
+    def _pick(self, index):
+        return np.asarray(self.images, dtype=object)[index].tolist() if not isinstance(index, slice) else \
+            self.images[index]
+
+    def cache_images(self, index=slice(None)):
+        """observer.py:256-264."""
+        for img in self._pick(index):
+            img.read(cache=True)
+
+    def clear_images(self, index=slice(None)):
+        """observer.py:266-274."""
+        for img in self._pick(index):
+            img.array = None
+
+    def subset(self, **kwargs):
+        """observer.py:455-464: a new Observer over the images select_datetimes(**kwargs) keeps."""
+        keep = select_datetimes(self.datetimes, **kwargs)
+        return type(self)([img for img, k in zip(self.images, keep) if k], sigma=self.sigma, cache=self.cache)
+
+    def split(self, n, overlap=1):
+        """observer.py:466-493: `n` equal time spans (int) or the spans between datetime breaks (iterable); each
+        following Observer starts `overlap` images before the end of the previous one."""
+        first, last = self.datetimes[0], self.datetimes[-1]
+        if np.iterable(n):
+            breaks = sorted(set(n) | {first, last})
+        else:
+            span = (last - first) / n
+            breaks = [first + k * span for k in range((last - first) // span + 1)]
+        parts, start = [], breaks[0]
+        for stop in breaks[1:]:
+            part = self.subset(start=start, end=stop)
+            parts.append(part)
+            if overlap:
+                start = part.datetimes[-min(overlap, len(part.datetimes))]
+            else:
+                start = part.datetimes[-1] + datetime.timedelta(microseconds=1)
+        return parts

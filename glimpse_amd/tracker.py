@@ -22,6 +22,7 @@ import numpy as np
 from . import _lib
 from .motion import CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion
 from .raster import Raster
+from .timeutil import _US, _offsets_us, nearest_in_sorted  # noqa: F401  (re-exported)
 from .tracks import Tracks
 
 _ERRORS = (
@@ -50,27 +51,6 @@ def _on_device(model):
 def _vector24(img):
     """Camera vector of an Observer image: an Image's camera, or a Raster's own grid (observer.py:26)."""
     return img.cam.vector24 if hasattr(img, "cam") else img.vector24
-
-
-_US = datetime.timedelta(microseconds=1)
-
-
-def _offsets_us(dts, ref):
-    """Datetimes as exact integer microseconds from `ref` (timedelta arithmetic, no float timestamps)."""
-    return np.fromiter(((d - ref) // _US for d in dts), dtype=np.int64, count=len(dts))
-
-
-def nearest_in_sorted(times_us, queries_us):
-    """For every query the index of the nearest entry of the ascending `times_us` and its distance (microseconds).
-    One binary search per query (np.searchsorted) instead of the reference's len(queries) x len(times) distance
-    matrix (helpers.py:1831-1854); a tie goes to the earlier entry, like np.argmin over that matrix."""
-    times_us = np.asarray(times_us, dtype=np.int64)
-    queries_us = np.asarray(queries_us, dtype=np.int64)
-    right = np.clip(np.searchsorted(times_us, queries_us, side="left"), 0, len(times_us) - 1)
-    left = np.maximum(right - 1, 0)
-    d_left, d_right = np.abs(queries_us - times_us[left]), np.abs(times_us[right] - queries_us)
-    take_left = d_left <= d_right
-    return np.where(take_left, left, right), np.where(take_left, d_left, d_right)
 
 
 def _parallel_worker(job):
@@ -736,6 +716,25 @@ class Tracker:
         """tracker.py:106-119 (NaN test; no viewshed)."""
         if np.isnan(self.particles).any():
             raise ValueError("Some particles have missing (NaN) values")
+
+    def extract_tile(self, obs, img, box, histogram=None, return_histogram=False):
+        """tracker.py:494-534: the grayscale, normalised, (optionally histogram-matched) and median high-passed tile
+        of one image box, computed by the same device tile-prep code the frame step uses.  Without `histogram` the
+        result is float64 (the template path, bit-equal to the reference's); with one it is the float32 search tile
+        the SSD consumes, widened to float64.  8-bit frames only: 16-bit frames are prepared inside the context."""
+        frame = self.observers[obs].images[img].read()
+        if np.asarray(frame).dtype != np.uint8:
+            raise NotImplementedError("extract_tile: standalone tile prep takes uint8 frames; 16-bit frames are "
+                                      "prepared on the device inside track()")
+        box = np.asarray(box).astype(int)
+        if histogram is None:
+            tile, own = _lib.stage_template(frame, box, device_id=self.device, highpass=self._highpass_size)
+            return (tile, own) if return_histogram else tile
+        if return_histogram:
+            raise NotImplementedError("extract_tile: histogram= together with return_histogram=True (no caller on "
+                                      "the tracking path asks for the histogram of a matched tile)")
+        return _lib.stage_search_tile(frame, box, histogram, device_id=self.device,
+                                      highpass=self._highpass_size).astype(float)
 
     def initialize_template(self, obs, img, tile_size):
         """tracker.py:536-561."""

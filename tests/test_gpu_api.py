@@ -573,3 +573,26 @@ def test_tracking_on_uint16_frames_reproduces_reference(golden, name, channels):
            for i, f in enumerate(frames)]
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(bad, sigma=0.3)]).track(models, tile_size=(15, 15))
+
+
+@pytest.mark.parametrize("name", ["gray", "rgb"])
+def test_tracker_extract_tile_matches_reference(golden, name):
+    """Tracker.extract_tile (tracker.py:494-534) as the reference's own callers use it: return_histogram=True for a
+    template (tracker.py:554-556) and histogram= for a search tile (tracker.py:608)."""
+    g = golden("g2_tiles.npz")
+    cam = camera_from(g["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(g[name][:2])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images)])
+    for b in range(3):
+        tbox, sbox = g[f"{name}_{b}_tbox"], g[f"{name}_{b}_sbox"]
+        tile, (hv, hq) = tracker.extract_tile(0, 0, tbox, return_histogram=True)
+        assert tile.dtype == np.float64
+        np.testing.assert_array_equal(hq, g[f"{name}_{b}_hist_q"])
+        np.testing.assert_allclose(hv, g[f"{name}_{b}_hist_v"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(tile, g[f"{name}_{b}_tile"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_array_equal(tracker.extract_tile(0, 0, tbox), tile)
+        search = tracker.extract_tile(0, 1, sbox, histogram=(hv, hq))
+        assert search.dtype == np.float64
+        np.testing.assert_allclose(search, g[f"{name}_{b}_search"], rtol=0, atol=2e-6)  # float32 search tile
+    with pytest.raises(NotImplementedError):
+        tracker.extract_tile(0, 1, sbox, histogram=(hv, hq), return_histogram=True)

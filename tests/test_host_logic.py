@@ -237,3 +237,75 @@ def test_nearest_in_sorted_equals_the_distance_matrix_argmin():
         d = np.abs(queries[:, None] - times[None, :])
         np.testing.assert_array_equal(idx, d.argmin(axis=1))
         np.testing.assert_array_equal(dist, d.min(axis=1))
+
+
+def _schedule_observer(secs):
+    blank = np.zeros((8, 8), dtype=np.uint8)
+    cam = glimpse_amd.Camera(imgsz=(8, 8), f=(10, 10))
+    return glimpse_amd.Observer([glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + datetime.timedelta(seconds=int(s)),
+                                                   array=blank) for s in secs])
+
+
+def test_observer_subset_split_and_shift_equal_reference(golden):
+    """Observer.subset / split / shift_tile (observer.py:146-176, 455-493) against the reference's own results on an
+    irregular schedule (tools/make_golden.py --g19)."""
+    from glimpse_amd.timeutil import select_datetimes
+    g = golden("g19_observer_helpers.npz")
+    secs = g["secs"]
+    obs = _schedule_observer(secs)
+    when = lambda s: T0 + datetime.timedelta(seconds=int(s))  # noqa: E731
+    position = {d: i for i, d in enumerate(obs.datetimes)}
+    for k, (a, b, snap, maxdt) in enumerate(g["cases"]):
+        kw = {}
+        if a >= 0:
+            kw["start"] = when(a)
+        if b >= 0:
+            kw["end"] = when(b)
+        if snap:
+            kw["snap"] = datetime.timedelta(seconds=int(snap))
+            if maxdt >= 0:
+                kw["maxdt"] = datetime.timedelta(seconds=int(maxdt))
+        want = g[f"mask_{k}"]
+        np.testing.assert_array_equal(select_datetimes(obs.datetimes, **kw), want, err_msg=f"case {k}: {kw}")
+        if want.sum() >= 2:
+            sub = obs.subset(**kw)
+            assert [position[d] for d in sub.datetimes] == list(np.flatnonzero(want))
+            assert sub.sigma == obs.sigma and sub.cache == obs.cache
+        else:
+            with pytest.raises(ValueError, match="two or greater"):
+                obs.subset(**kw)
+    with pytest.raises(ValueError, match="after end"):
+        obs.subset(start=when(secs[5]), end=when(secs[2]))
+
+    def spans(parts):
+        return [[position[p.datetimes[0]], position[p.datetimes[-1]], len(p.images)] for p in parts]
+
+    for n, overlap in [(3, 1), (4, 0), (5, 2)]:
+        assert spans(obs.split(n, overlap=overlap)) == g[f"split_{n}_{overlap}"].tolist()
+    assert spans(obs.split([when(s) for s in g["breaks_secs"]])) == g["split_breaks"].tolist()
+
+    for i, duv in enumerate(g["duv"]):
+        np.testing.assert_allclose(obs.shift_tile(g["tile"].copy(), duv), g[f"shift_{i}"], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(obs.shift_tile(g["rgb"].copy(), duv), g[f"shift_rgb_{i}"], rtol=0, atol=1e-13)
+    with pytest.raises(ValueError, match="0.5"):
+        obs.shift_tile(g["tile"].copy(), (0.6, 0.0))
+
+
+def test_observer_image_cache_helpers(tmp_path):
+    """Observer.cache_images / clear_images (observer.py:256-274) on images read from files."""
+    import PIL.Image
+    frames = [np.full((6, 7), 10 * i, dtype=np.uint8) for i in range(3)]
+    cam = glimpse_amd.Camera(imgsz=(7, 6), f=(10, 10))
+    images = []
+    for i, f in enumerate(frames):
+        path = tmp_path / f"f{i}.png"
+        PIL.Image.fromarray(f).save(path)
+        images.append(glimpse_amd.Image(str(path), cam=cam, datetime=T0 + i * DAY))
+    obs = glimpse_amd.Observer(images)
+    assert all(img.array is None for img in images)
+    obs.cache_images([0, 2])
+    assert images[0].array is not None and images[1].array is None and images[2].array is not None
+    obs.cache_images()
+    np.testing.assert_array_equal(images[1].array, frames[1])
+    obs.clear_images(slice(1, None))
+    assert images[0].array is not None and images[1].array is None and images[2].array is None

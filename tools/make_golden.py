@@ -897,7 +897,66 @@ def g18_uint16():
     np.savez_compressed(os.path.join(OUT, "g18_uint16.npz"), **out)
 
 
+def g19_observer_helpers():
+    """Observer.subset / split (observer.py:455-493 over helpers.select_datetimes, helpers.py:1883-1951) on an
+    irregular image schedule, and Observer.shift_tile (observer.py:146-176).  Times are stored as integer seconds
+    from 2020-01-01."""
+    t0 = datetime.datetime(2020, 1, 1)
+    rng = np.random.default_rng(19)
+    secs = np.cumsum(rng.integers(1, 5000, 40)).astype(np.int64)
+    cam = synth.nadir_camera((32, 32), f=100.0, height=10.0)
+    blank = np.zeros((32, 32), dtype=np.uint8)
+    obs = glimpse.Observer([ref_image(blank, cam, t0 + datetime.timedelta(seconds=int(s))) for s in secs])
+    out = {"secs": secs}
+    when = lambda s: t0 + datetime.timedelta(seconds=int(s))  # noqa: E731
+    index_of = {d: i for i, d in enumerate(obs.datetimes)}
+    cases = []
+    for k in range(24):
+        a, b = sorted(rng.integers(secs[0] - 3000, secs[-1] + 3000, 2))
+        snap = [None, 3600, 7200, 1800][k % 4]
+        maxdt = [None, None, 600, 0][(k // 4) % 4] if snap else None
+        kw = {}
+        if k % 3 != 0:
+            kw["start"] = when(a)
+        if k % 5 != 0:
+            kw["end"] = when(b)
+        if snap:
+            kw["snap"] = datetime.timedelta(seconds=snap)
+            if maxdt is not None:
+                kw["maxdt"] = datetime.timedelta(seconds=maxdt)
+        try:
+            sub = obs.subset(**kw)
+            keep = np.zeros(len(secs), dtype=bool)
+            keep[[index_of[d] for d in sub.datetimes]] = True
+        except ValueError:  # fewer than two images left
+            keep = glimpse.helpers.select_datetimes(obs.datetimes, **kw)
+        cases.append([a if "start" in kw else -1, b if "end" in kw else -1, snap or 0, -1 if maxdt is None else maxdt])
+        out[f"mask_{k}"] = keep
+    out["cases"] = np.array(cases, dtype=np.int64)
+    for n, overlap in [(3, 1), (4, 0), (5, 2)]:
+        parts = obs.split(n, overlap=overlap)
+        out[f"split_{n}_{overlap}"] = np.array([[index_of[p.datetimes[0]], index_of[p.datetimes[-1]], len(p.images)]
+                                                for p in parts])
+    brk = [when(secs[9] + 7), when(secs[25])]
+    parts = obs.split(brk, overlap=1)
+    out["split_breaks"] = np.array([[index_of[p.datetimes[0]], index_of[p.datetimes[-1]], len(p.images)] for p in parts])
+    out["breaks_secs"] = np.array([secs[9] + 7, secs[25]])
+    tile = rng.standard_normal((9, 11))
+    rgb = rng.standard_normal((7, 8, 3))
+    out["tile"], out["rgb"] = tile.copy(), rgb.copy()
+    out["duv"] = np.array([[0.3, -0.2], [-0.5, 0.5], [0.0, 0.25]])
+    for i, duv in enumerate(out["duv"]):
+        out[f"shift_{i}"] = obs.shift_tile(tile.copy(), duv)
+        out[f"shift_rgb_{i}"] = obs.shift_tile(rgb.copy(), duv)
+    np.savez_compressed(os.path.join(OUT, "g19_observer_helpers.npz"), **out)
+    print("g19", {k: int(v.sum()) for k, v in out.items() if k.startswith("mask_")})
+    print("g19 splits", out["split_3_1"].tolist(), out["split_4_0"].tolist(), out["split_breaks"].tolist())
+
+
 if __name__ == "__main__":
+    if "--g19" in sys.argv:
+        g19_observer_helpers()
+        sys.exit(0)
     if "--g18" in sys.argv:
         g18_uint16()
         sys.exit(0)
@@ -946,5 +1005,6 @@ if __name__ == "__main__":
     g16_custom_motion()
     g17_highpass()
     g18_uint16()
+    g19_observer_helpers()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
