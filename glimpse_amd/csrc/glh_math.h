@@ -600,6 +600,38 @@ GLH_HD double spline_eval_poly_fast(const double* tab, const double* coef, int l
   }
   return sp;
 }
+// ---- per-cell power form of the fitted surface (fast arithmetic only) ----------------------------------------
+// On cell (qv, qu) the spline is a bicubic in the local offsets (sv, su): sum_ab P[a][b] sv^a su^b with
+// P = Mv^T * Z[qv..qv+3][qu..qu+3] * Mu (M = the cell's basis matrices above, [m][d]).  Built once per surface, a
+// particle then reads ONE contiguous 128-byte block and runs 15 fused multiply-adds, instead of two basis matrices
+// (256 B), 16 scattered coefficients and 44 operations.  Cells are GLH_CELL_LD doubles apart (144 B: rows stay
+// 16-byte aligned and consecutive cells start 4 banks apart).
+constexpr int GLH_CELL_LD = 18;
+GLH_HD int spline_cells(int n) { return n - 3; }
+// row a (the power of sv) of cell (qv, qu): out4[b], b = the power of su
+GLH_HD void spline_cell_row(const double* tab, const double* coef, int ld, int ho, int wo, int qv, int qu, int a,
+                            double* out4) {
+  const double* mv = tab + 16 * spline_poly_index(ho, qv);
+  const double* mu = tab + 16 * spline_poly_index(wo, qu);
+  const double* z = coef + (size_t)qv * ld + qu;
+  double t[4];
+  for (int j = 0; j < 4; ++j)
+    t[j] = glh_fma(mv[12 + a], z[3 * ld + j], glh_fma(mv[8 + a], z[2 * ld + j], glh_fma(mv[4 + a], z[ld + j], mv[a] * z[j])));
+  for (int b = 0; b < 4; ++b)
+    out4[b] = glh_fma(t[3], mu[12 + b], glh_fma(t[2], mu[8 + b], glh_fma(t[1], mu[4 + b], t[0] * mu[b])));
+}
+GLH_HD double spline_eval_cell(const double* cells, int ho, int wo, double cv0, double cu0, double u, double v) {
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
+  const int qv = spline_interval(vl, ho);
+  const int qu = spline_interval(ul, wo);
+  const double sv = vl - spline_interval_start(qv), su = ul - spline_interval_start(qu);
+  const double* p = cells + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD;
+  double r[4];
+  for (int a = 0; a < 4; ++a)
+    r[a] = glh_fma(glh_fma(glh_fma(p[4 * a + 3], su, p[4 * a + 2]), su, p[4 * a + 1]), su, p[4 * a]);
+  return glh_fma(glh_fma(glh_fma(r[3], sv, r[2]), sv, r[1]), sv, r[0]);
+}
 template <bool FAST>
 GLH_HD double spline_eval_poly_m(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,
                                  double cu0, double u, double v) {

@@ -766,13 +766,18 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     load_template(o);
     // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
     //      once per branch below so that the coefficient loads keep their address space
-    auto sample_all = [&](const double* Z) {
+    auto sample_all = [&](const double* Z, auto cells_tag) {
+      constexpr bool CELLS = decltype(cells_tag)::value;  // Z = the per-cell power form, not the coefficients
       // geometry is derived here, not before the tile stages: nothing extra stays live across them
       double sb[4];
       sse_box_of(box, a.tmpl_duv + slot * 2, tw, th, sb);
       const double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double scale = a.inv2s2[o];
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
+      auto eval = [&](double u, double v) -> double {
+        if constexpr (CELLS) return spline_eval_cell(Z, ho, wo, cv0, cu0, u, v);
+        else return spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, u, v);
+      };
       // "Some sampling points are outside box" (observer.py:201-202): some particle's uv is outside the box exactly
       // when the bounding box of all of them is (NaNs never get here: they skip the observer) -- one test per
       // point instead of four comparisons per particle
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         outside = true;
       if (o == 0) {
         auto sample_one = [&](double2 q) -> double {
-          const double term = spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          const double term = eval(q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
           // a single observer and no motion-model term: this IS the log likelihood, the weight follows at once
           return w_here ? weight_of<FAST>(ll, tab32) : ll;
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int i = tid; i < N; i += TB) {
           const double2 q = qn;
           qn = uvp[i + TB < N ? i + TB : 0];
-          c[i] += spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, q.x, q.y) * scale;
+          c[i] += eval(q.x, q.y) * scale;
         }
       }
     };
@@ -875,7 +880,19 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         pt_spline_fit<TB>(ws, wo, ho);
       }
       PT_STAMP(4);
-      sample_all(ws.Z);
+      // fast arithmetic: the surface in per-cell power form over the dead template / CDF / search tile, when it fits
+      const int ncells = spline_cells(ho) * spline_cells(wo);
+      if (FAST && ncells * GLH_CELL_LD * 8 <= off + s_bytes) {
+        double* PC = reinterpret_cast<double*>(r2);
+        for (int t = tid; t < ncells * 4; t += TB) {
+          const int cell = t >> 2, qv = cell / spline_cells(wo), qu = cell - qv * spline_cells(wo);
+          spline_cell_row(tab, ws.Z, wo, ho, wo, qv, qu, t & 3, PC + (size_t)cell * GLH_CELL_LD + 4 * (t & 3));
+        }
+        __syncthreads();
+        sample_all(PC, std::true_type{});
+      } else {
+        sample_all(ws.Z, std::false_type{});
+      }
     } else {
       // big tile: search / keys / surface in the HBM workspaces, histogram + LUT stay in LDS (over the LDS
       // copy of the template CDF: this path reads the CDF from memory)
@@ -936,11 +953,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         ws.Z1 = fl;
         pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
-        sample_all(Zl);
+        sample_all(Zl, std::false_type{});
       } else {
         pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
-        sample_all(ws.Z);
+        sample_all(ws.Z, std::false_type{});
       }
     }
     __syncthreads();  // region 2 is free for the next observer
