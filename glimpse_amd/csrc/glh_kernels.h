@@ -1411,6 +1411,7 @@ struct WeightArgs {
   int32_t on[MAX_OBS];
   int32_t N, P, O, tw, th, sse_cap, frame;
   int32_t fast;  // GLH_MATH_FAST
+  int32_t cell_cap;  // fast: surfaces of up to this many cells are evaluated in per-cell form (the fused kernel's bound)
   Surfaces surf;
 };
 
@@ -1468,8 +1469,11 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
         flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
       double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double* coef = a.coef + slot * (size_t)a.sse_cap;
-      double val = a.fast ? spline_eval_poly_fast(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
-                          : spline_eval_poly(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y);
+      // fast arithmetic: surfaces the fused kernel holds in per-cell form are evaluated by that formula here too
+      const bool by_cell = a.fast && spline_cells(ho) * spline_cells(wo) <= a.cell_cap;
+      double val = by_cell  ? spline_eval_cell_direct(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+                   : a.fast ? spline_eval_poly_fast(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+                            : spline_eval_poly(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y);
       if (a.ll_out) a.ll_out[slot * a.N + i] = val * a.inv2s2[o];
       ll += val * a.inv2s2[o];
     }

@@ -620,17 +620,34 @@ GLH_HD void spline_cell_row(const double* tab, const double* coef, int ld, int h
   for (int b = 0; b < 4; ++b)
     out4[b] = glh_fma(t[3], mu[12 + b], glh_fma(t[2], mu[8 + b], glh_fma(t[1], mu[4 + b], t[0] * mu[b])));
 }
+// Horner in su along each row, then in sv across the rows; p = 16 doubles [a][b]
+GLH_HD double spline_cell_horner(const double* p, double sv, double su) {
+  double r[4];
+  for (int a = 0; a < 4; ++a)
+    r[a] = glh_fma(glh_fma(glh_fma(p[4 * a + 3], su, p[4 * a + 2]), su, p[4 * a + 1]), su, p[4 * a]);
+  return glh_fma(glh_fma(glh_fma(r[3], sv, r[2]), sv, r[1]), sv, r[0]);
+}
+// sample a surface held in per-cell form (cells = GLH_CELL_LD doubles per cell, row-major over (qv, qu))
 GLH_HD double spline_eval_cell(const double* cells, int ho, int wo, double cv0, double cu0, double u, double v) {
   const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
   const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
   const int qv = spline_interval(vl, ho);
   const int qu = spline_interval(ul, wo);
   const double sv = vl - spline_interval_start(qv), su = ul - spline_interval_start(qu);
-  const double* p = cells + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD;
-  double r[4];
-  for (int a = 0; a < 4; ++a)
-    r[a] = glh_fma(glh_fma(glh_fma(p[4 * a + 3], su, p[4 * a + 2]), su, p[4 * a + 1]), su, p[4 * a]);
-  return glh_fma(glh_fma(glh_fma(r[3], sv, r[2]), sv, r[1]), sv, r[0]);
+  return spline_cell_horner(cells + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD, sv, su);
+}
+// the same value without a cell table: the particle's cell is converted on the spot (the staged kernels; every
+// operation is the one spline_cell_row / spline_eval_cell perform, so the result is bit-identical)
+GLH_HD double spline_eval_cell_direct(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,
+                                      double cu0, double u, double v) {
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
+  const int qv = spline_interval(vl, ho);
+  const int qu = spline_interval(ul, wo);
+  const double sv = vl - spline_interval_start(qv), su = ul - spline_interval_start(qu);
+  double p[16];
+  for (int a = 0; a < 4; ++a) spline_cell_row(tab, coef, ld, ho, wo, qv, qu, a, p + 4 * a);
+  return spline_cell_horner(p, sv, su);
 }
 template <bool FAST>
 GLH_HD double spline_eval_poly_m(const double* tab, const double* coef, int ld, int ho, int wo, double cv0,

@@ -144,6 +144,7 @@ struct PointArgs {
   Surfaces surf;           // gridded dem / dem_sigma / viewshed (null pointers when absent)
   uint32_t cam_flags[PT_MAX_OBS];  // cam_flags(cam[o]): scalar, so the optional projection terms branch uniformly
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
+  int32_t cell_cap;  // fast arithmetic: surfaces of up to this many cells are sampled in per-cell form (0: never)
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
   int32_t nleaves, nnodes, nlevels, nroots;
@@ -832,6 +833,38 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       }
     };
+    // Fast arithmetic: the fitted surface goes into per-cell power form (glh_math.h) at the start of region 2 --
+    // everything else there is dead once the fit is done -- when its cells fit (a.cell_cap: the same bound the
+    // staged kernels apply, so that both evaluate a given surface by the same formula).  Rows are computed into
+    // registers first: the table may overlay the coefficients it is made from.
+    bool cells = false;  // uniform
+    auto to_cells = [&](const double* Z) -> bool {
+      const int ncu = spline_cells(wo), nrows = 4 * spline_cells(ho) * ncu;
+      if (!FAST || nrows > 4 * a.cell_cap) return false;
+      double row[2][4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = k * TB + tid;
+        if (t < nrows) {
+          const int cell = t >> 2, qv = cell / ncu;
+          spline_cell_row(tab, Z, wo, ho, wo, qv, cell - qv * ncu, t & 3, row[k]);
+        }
+      }
+      __syncthreads();
+      double* PC = reinterpret_cast<double*>(r2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = k * TB + tid;
+        if (t < nrows) {
+          double2* d = reinterpret_cast<double2*>(PC + (size_t)(t >> 2) * GLH_CELL_LD + 4 * (t & 3));
+          d[0] = make_double2(row[k][0], row[k][1]);
+          d[1] = make_double2(row[k][2], row[k][3]);
+        }
+      }
+      __syncthreads();
+      cells = true;
+      return true;
+    };
     if (fits) {
       ws.ld = ld_lds;
       ws.S = reinterpret_cast<float*>(r2 + off);
@@ -880,19 +913,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         pt_spline_fit<TB>(ws, wo, ho);
       }
       PT_STAMP(4);
-      // fast arithmetic: the surface in per-cell power form over the dead template / CDF / search tile, when it fits
-      const int ncells = spline_cells(ho) * spline_cells(wo);
-      if (FAST && ncells * GLH_CELL_LD * 8 <= off + s_bytes) {
-        double* PC = reinterpret_cast<double*>(r2);
-        for (int t = tid; t < ncells * 4; t += TB) {
-          const int cell = t >> 2, qv = cell / spline_cells(wo), qu = cell - qv * spline_cells(wo);
-          spline_cell_row(tab, ws.Z, wo, ho, wo, qv, qu, t & 3, PC + (size_t)cell * GLH_CELL_LD + 4 * (t & 3));
-        }
-        __syncthreads();
-        sample_all(PC, std::true_type{});
-      } else {
-        sample_all(ws.Z, std::false_type{});
-      }
+      if (!to_cells(ws.Z)) sample_all(ws.Z, std::false_type{});
     } else {
       // big tile: search / keys / surface in the HBM workspaces, histogram + LUT stay in LDS (over the LDS
       // copy of the template CDF: this path reads the CDF from memory)
@@ -953,13 +974,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         ws.Z1 = fl;
         pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
-        sample_all(Zl, std::false_type{});
+        if (!to_cells(Zl)) sample_all(Zl, std::false_type{});
       } else {
         pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
-        sample_all(ws.Z, std::false_type{});
+        sample_all(ws.Z, std::false_type{});  // (a surface this large is beyond the cell form as well)
       }
     }
+    if (cells) sample_all(reinterpret_cast<const double*>(r2), std::true_type{});  // one instance for every branch
     __syncthreads();  // region 2 is free for the next observer
   }
   if (!c_ready) {  // every observer skipped (same-thread indices)

@@ -1132,6 +1132,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
   return GLH_OK;
 }
 
+static int cell_cap(const glh_ctx* c);  // (defined with the fused kernel's LDS plan below)
 static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected) {
   CHK(ensure_expanded(c));
   const int O = c->cfg.n_observers;
@@ -1166,6 +1167,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.sse_cap = c->sse_cap;
   wa.frame = c->frame;
   wa.fast = use_fast(c);
+  wa.cell_cap = cell_cap(c);
   wa.surf = surfaces(c);
   {
     StageTimer t(c, ST_WEIGHTS);
@@ -1270,7 +1272,8 @@ extern "C" int glh_record_moments(glh_ctx* c, int frame) {
 // LDS plan of the fused kernel (glh_point.h): c[N] + region 2.  Two workgroups per CU when the
 // state and a typical tile fit in half the LDS, otherwise one.
 
-static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
+static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
+  if (mode < 0) mode = c->fused;
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
   if (c->hp_rx != 2 || c->hp_ry != 2) return false;  // the fused kernel's median network is the 5 x 5 default
@@ -1295,10 +1298,20 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes) {
   else
     r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
   if (getenv("GLH_PT_ONE_BLOCK")) r2 = std::min(PT_LDS_MAX - cN, 100 * 1024);  // experiment: 1 workgroup / CU
-  if (c->fused == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
+  if (mode == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
   if (r2 < r2_min || cN + r2 > PT_LDS_MAX) return false;  // (N beyond ~10 900: the staged kernels take the step)
   *r2_bytes = r2;
   return true;
+}
+
+// Fast arithmetic samples small fitted surfaces in per-cell power form (glh_math.h: spline_cell_row).  The fused
+// kernel holds the cell table in region 2 and converts at most two rows per thread; the staged kernels apply the
+// same bound, so that a given surface is evaluated by the same formula on either path (bit-identical results).
+static int cell_cap(const glh_ctx* c) {
+  int r2 = 0;
+  if (!fused_plan(c, &r2, c->fused == 2 ? 2 : 1)) return 0;
+  const int tb = c->N > 10 * PT_BLK ? PT_BLK_BIG : PT_BLK;
+  return std::min(r2 / (GLH_CELL_LD * 8), 2 * tb / 4);
 }
 
 // The fused frame step (glh_point.h): ONE launch, one workgroup per point.
@@ -1374,6 +1387,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.rng_mode = rng_mode;
   a.has_dem = c->has_dem;
   a.r2_bytes = r2_bytes;
+  a.cell_cap = cell_cap(c);
   a.pt_base = c->pt_base;
   a.surf = surfaces(c);
   a.nleaves = c->nleaves;
