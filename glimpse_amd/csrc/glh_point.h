@@ -30,7 +30,7 @@ namespace glh {
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
-constexpr int PT_NSTAMP = 16;
+constexpr int PT_NSTAMP = 20;
 constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
 // Wave64 reductions on the DPP data path (VALU moves; the canonical row_shr / row_bcast ladder) instead
@@ -496,17 +496,57 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   int32_t* p_ops = p_leaf_len + a.nleaves;
   int32_t* p_level_off = p_ops + 3 * (a.nnodes - a.nleaves);
   int32_t* p_roots = p_level_off + a.nlevels + 1;
-  for (int k = tid; k < a.nleaves; k += TB) {
-    p_leaf_off[k] = a.leaf_off[k];
-    p_leaf_len[k] = a.leaf_len[k];
+  if constexpr (!FAST) {  // (fast arithmetic scans the raw weights: no sum tree)
+    for (int k = tid; k < a.nleaves; k += TB) {
+      p_leaf_off[k] = a.leaf_off[k];
+      p_leaf_len[k] = a.leaf_len[k];
+    }
+    for (int k = tid; k < 3 * (a.nnodes - a.nleaves); k += TB) p_ops[k] = a.ops[k];
+    if (tid <= a.nlevels) p_level_off[tid] = a.level_off[tid];
+    if (tid < a.nroots) p_roots[tid] = a.roots[tid];
   }
-  for (int k = tid; k < 3 * (a.nnodes - a.nleaves); k += TB) p_ops[k] = a.ops[k];
-  if (tid <= a.nlevels) p_level_off[tid] = a.level_off[tid];
-  if (tid < a.nroots) p_roots[tid] = a.roots[tid];
   bool live[NOBS];  // uniform across the block
 #pragma unroll
   for (int o = 0; o < NOBS; ++o) live[o] = a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
+  // fetched here, used at the end of phase A: no memory latency between the last particle and the search box
+  const int hist_n0 = a.tmpl_hist_n[pt];
+  const int valid_o = tid < NOBS ? (int)a.tmpl_valid[(size_t)tid * a.P + pt] : 0;
   // Template tile (zero padded rows) and template CDF of one observer into the head of region 2: [T | cq | cv].
+  // The usual sizes (two entries per thread): every load of this thread is in flight before the first LDS store (one
+  // memory latency instead of four) -- and, in two halves, observer 0's loads are issued at the end of phase A, so
+  // that they travel while the search box is being reduced.
+  struct TmplRegs {
+    float f0, f1;
+    double q0, v0, q1, v1;
+  };
+  auto tmpl_small = [&](int hist_n) { return a.th * ssd_twp(a.tw) <= 2 * TB && hist_n <= 2 * TB; };
+  auto tmpl_issue = [&](int o, int hist_n, TmplRegs& t) {
+    const size_t slot = (size_t)o * a.P + pt;
+    const int tw = a.tw, th = a.th, twp = ssd_twp(tw);
+    const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
+    const UDiv by_twp = udiv_make(twp);
+    const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
+    const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
+    const int i0 = tid, i1 = tid + TB;
+    const int r0 = udiv(by_twp, i0), j0 = i0 - r0 * twp, r1 = udiv(by_twp, i1), j1 = i1 - r1 * twp;
+    const bool t0 = i0 < th * twp && j0 < tw, t1 = i1 < th * twp && j1 < tw;
+    t.f0 = t0 ? tg[r0 * tw + j0] : 0.0f;
+    t.f1 = t1 ? tg[r1 * tw + j1] : 0.0f;
+    const bool h0 = i0 < hist_n, h1 = i1 < hist_n;
+    t.q0 = h0 ? hq_g[i0] : 0.0; t.v0 = h0 ? hv_g[i0] : 0.0;
+    t.q1 = h1 ? hq_g[i1] : 0.0; t.v1 = h1 ? hv_g[i1] : 0.0;
+  };
+  auto tmpl_store = [&](int hist_n, const TmplRegs& t) {
+    const int th = a.th, twp = ssd_twp(a.tw);
+    float* T = reinterpret_cast<float*>(r2);
+    double* cq = reinterpret_cast<double*>(r2 + pt_align16(th * twp * 4));
+    double* cv = cq + pt_align16(hist_n * 8) / 8;
+    const int i0 = tid, i1 = tid + TB;
+    if (i0 < th * twp) T[i0] = t.f0;
+    if (i1 < th * twp) T[i1] = t.f1;
+    if (i0 < hist_n) { cq[i0] = t.q0; cv[i0] = t.v0; }
+    if (i1 < hist_n) { cq[i1] = t.q1; cv[i1] = t.v1; }
+  };
   auto load_template = [&](int o) {
     const size_t slot = (size_t)o * a.P + pt;
     const int tw = a.tw, th = a.th, twp = ssd_twp(tw);
@@ -518,20 +558,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     double* cv = cq + pt_align16(hist_n * 8) / 8;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
-    if (th * twp <= 2 * TB && hist_n <= 2 * TB) {
-      // the usual sizes: every load of this thread is in flight before the first LDS store (one memory latency
-      // instead of four)
-      const int i0 = tid, i1 = tid + TB;
-      const int r0 = udiv(by_twp, i0), j0 = i0 - r0 * twp, r1 = udiv(by_twp, i1), j1 = i1 - r1 * twp;
-      const bool t0 = i0 < th * twp && j0 < tw, t1 = i1 < th * twp && j1 < tw;
-      const float f0 = t0 ? tg[r0 * tw + j0] : 0.0f, f1 = t1 ? tg[r1 * tw + j1] : 0.0f;
-      const bool h0 = i0 < hist_n, h1 = i1 < hist_n;
-      const double q0 = h0 ? hq_g[i0] : 0.0, v0 = h0 ? hv_g[i0] : 0.0;
-      const double q1 = h1 ? hq_g[i1] : 0.0, v1 = h1 ? hv_g[i1] : 0.0;
-      if (i0 < th * twp) T[i0] = f0;
-      if (i1 < th * twp) T[i1] = f1;
-      if (h0) { cq[i0] = q0; cv[i0] = v0; }
-      if (h1) { cq[i1] = q1; cv[i1] = v1; }
+    if (tmpl_small(hist_n)) {
+      TmplRegs t;
+      tmpl_issue(o, hist_n, t);
+      tmpl_store(hist_n, t);
     } else {
       for (int idx = tid; idx < th * twp; idx += TB) {
         const int i = udiv(by_twp, idx), j = idx - i * twp;
@@ -543,11 +573,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
   };
+  // record of every particle (compact input state): staged in region 2, which is free until phase B -- together with
+  // the tables above, so that the kernel starts with one memory latency, not two
+  const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
+  uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
+  if (uin) {
+    if ((N & 7) == 0)  // whole 16-byte words (the rows of uidx are N uint16 apart): every load of a thread in flight at once
+      pt_stage<TB>(reinterpret_cast<uint4*>(s_rec), reinterpret_cast<const uint4*>(uin), N >> 3);
+    else
+      pt_stage<TB>(s_rec, uin, N);
+  } else {
+    for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
+  }
   __syncthreads();
+  PT_STAMP(15);
 
   // (the tangent models have no log-likelihood term: Motion.compute_log_likelihoods returns None, tracker.py:146)
   const bool motion_term = !SURF || (int)s_m[18] <= GLH_MOTION_CYLINDRICAL;  // uniform
-  const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
   // A record is three 16-byte chunks.  One record per particle (what every other kernel reads and writes): chunk c
   // of record r at 3 r + c.  Compact (this kernel's own output): PLANAR, chunk c of record r at c N + r, so that
   // consecutive lanes store, and mostly load, consecutive 16-byte words.
@@ -573,6 +615,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // PPT == 0: u parked in c[i] and v in the first N doubles of the observer-0 slot of the uv scratch
   // (L2 / Infinity Cache).
   constexpr int NREG = PPT > 0 ? PPT : 1;
+  TmplRegs tmpl0{};
+  const bool tmpl_early = live[0] && tmpl_small(hist_n0);  // uniform
   const int rounds = (N + TB - 1) / TB;  // <= PPT when PPT > 0 (the host picks the variant)
   double* V0 = a.uv + (size_t)pt * N * 2;
   double u0[NREG];
@@ -590,20 +634,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const bool gridded = SURF && motion_term && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
-    // record of every particle (compact input state): staged in region 2, which is free until phase B
-    uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
-    if (uin) {
-      pt_stage<TB>(s_rec, uin, N);
-    } else {
-      for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
-    }
-    pt_lds_barrier();
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
     {
       const double2* src = Pin2 + (size_t)s_rec[tid < N ? tid : 0] * rec_stride;
       nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
     }
+    PT_STAMP(16);
     auto a_iter = [&](int r) {
       // compiler barrier: camera / motion constants are re-read from LDS (broadcast) every iteration
       // instead of being hoisted into ~100 registers that would spill
@@ -674,6 +711,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll 1
       for (int r = 0; r < rounds; ++r) a_iter(r);
     }
+    PT_STAMP(17);
+    if (tmpl_early) tmpl_issue(0, hist_n0, tmpl0);
     if (bad) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_NAN, a.frame);
     if (raster_oob) view_bits |= GLH_PT_RASTER_OOB;
     if (view_bits) flag_point(a.pt_status, a.pt_err_frame, pt, view_bits, a.frame);
@@ -688,13 +727,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     __syncthreads();
+    PT_STAMP(18);
     if (tid < NOBS) {
       const int o = tid;
       const size_t slot = (size_t)o * a.P + pt;
       int st;
       if (!live[o]) {
         st = GLH_OBS_SKIPPED;
-      } else if (!a.tmpl_valid[slot]) {
+      } else if (!valid_o) {
         st = GLH_OBS_NO_TEMPLATE;
       } else {
         double mnu = bred[o][0][0], mnv = bred[o][0][1], mxu = bred[o][0][2], mxv = bred[o][0][3],
@@ -723,6 +763,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       s_status[o] = st;
       a.obs_status[slot] = st;
     }
+    PT_STAMP(19);
     __syncthreads();
   }
 
@@ -741,7 +782,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int ws_ = box[2] - box[0], hs = box[3] - box[1];
     const int wo = ws_ - tw + 1, ho = hs - th + 1;
     const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
-    const int hist_n = a.tmpl_hist_n[slot];
+    const int hist_n = o == 0 ? hist_n0 : a.tmpl_hist_n[slot];
     const int twp = ssd_twp(tw);
     // ---- LDS carve: [T | cq | cv | S | X] with X = max(hist + cum + lut + keys, Z + LU)
     TileWs ws;
@@ -764,7 +805,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
     const double* fw_g = a.lu + a.lu_off[wo];
-    load_template(o);
+    if (o == 0 && tmpl_early)
+      tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
+    else
+      load_template(o);
     // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
     //      once per branch below so that the coefficient loads keep their address space
     auto sample_all = [&](const double* Z, auto cells_tag) {

@@ -38,6 +38,8 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
     sub = st[:, 10:13]
     tp = st[:, 13:15]
     print('  tile_prep split (median ticks): fetch+hist', np.median(tp[:,0]-st[:,1]), 'scan+lut', np.median(tp[:,1]-tp[:,0]), 'median+write', np.median(st[:,2]-tp[:,1]))
+    asub = st[:, 15:20]
+    print('  A split (median ticks): prologue', np.median(asub[:,0]-st[:,0]), 'record staging', np.median(asub[:,1]-asub[:,0]), 'particle loop', np.median(asub[:,2]-asub[:,1]), 'wait for the other waves + reduce', np.median(asub[:,3]-asub[:,2]), 'box (thread 0)', np.median(asub[:,4]-asub[:,3]), 'barrier', np.median(st[:,1]-asub[:,4]))
     st = st[:, :10]
     d = np.diff(st, axis=1)  # (P, 9)
     tot = d.sum(axis=1)
