@@ -604,7 +604,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
-      evolve_particle<false>(x, m, n, tau, tau2, a.surf, &oob);
+      evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &oob);
     } else {
       evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
     }
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         double n[3];
         evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
         if constexpr (SURF)
-          evolve_particle<false>(x, m, n, tau, tau2, a.surf, &raster_oob);
+          evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &raster_oob);
         else
           evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
         if (i == 0) {

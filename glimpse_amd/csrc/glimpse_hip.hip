@@ -391,7 +391,8 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_>,    \
   (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_>,   \
   (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_>
-    for (const void* f : {GLH_PT_VARIANTS(false, false), GLH_PT_VARIANTS(true, false), GLH_PT_VARIANTS(false, true)}) {
+    for (const void* f : {GLH_PT_VARIANTS(false, false), GLH_PT_VARIANTS(true, false), GLH_PT_VARIANTS(false, true),
+                          GLH_PT_VARIANTS(true, true)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
@@ -653,11 +654,10 @@ static int ensure_expanded(glh_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
 
-// Fast arithmetic is in force for CartesianMotion over constant surfaces (the general kernels -- gridded surfaces, the
-// other motion models -- are exact only).
-static bool use_fast(const glh_ctx* c) {
-  return c->fast_math && c->all_cartesian && !(c->rasters[0].z || c->rasters[1].z || c->rasters[2].z);
-}
+// Fast arithmetic (glh_set_math): every kernel has it.  What it changes in the general instantiation (gridded surfaces,
+// the other motion models) is the projection, the sampling, the weights and the resampling; their evolve steps and
+// surface lookups have one form only.
+static bool use_fast(const glh_ctx* c) { return c->fast_math; }
 
 static Surfaces surfaces(const glh_ctx* c) {
   Surfaces s{};
@@ -1413,7 +1413,9 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const bool fast = use_fast(c);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \
-    if (surf)                                                                                                  \
+    if (surf && fast)                                                                                          \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true>), grid, block, lds, c->stream, a);     \
+    else if (surf)                                                                                             \
       hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, false>), grid, block, lds, c->stream, a);    \
     else if (fast)                                                                                             \
       hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, true>), grid, block, lds, c->stream, a);    \

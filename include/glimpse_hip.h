@@ -106,8 +106,9 @@ extern "C" {
                           * indices are the reference's bit for bit                                           */
 #define GLH_MATH_FAST 1  /* same formulas with fused multiply-adds, Newton reciprocals instead of IEEE divisions, a
                           * table exp and no normalisation pass in the systematic resampling: ~1e-13 relative on the
-                          * posteriors, ~10 % faster; meant for device-RNG runs, where no reference stream exists to be
-                          * bit-exact with.  Applies to contexts without gridded surfaces.                        */
+                          * posteriors, 10-15 % faster; meant for device-RNG runs, where no reference stream exists to be
+                          * bit-exact with.  Small fitted surfaces are sampled in a per-cell power form.  Every motion
+                          * model and surface kind has it (their own evolve steps and lookups have one form only).    */
 
 typedef struct glh_ctx glh_ctx;
 
@@ -276,7 +277,7 @@ int glh_set_math(glh_ctx* ctx, int mode);
  * the staged kernels.                                                                                           */
 int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
 
-/* Diagnostic: s_memtime stamps [P][16] at the phase boundaries of the fused kernel during the
+/* Diagnostic: s_memtime stamps [P][20] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
 

@@ -285,8 +285,9 @@ def test_fused_step_with_gridded_surfaces_equals_staged(lib):
     assert np.abs(fused["m"][-1, 0, 2]) < 1.0
 
 
+@pytest.mark.parametrize("math", ["exact", "fast"])
 @pytest.mark.parametrize("gridded", [False, True])
-def test_fused_step_evolves_every_motion_model_like_the_staged_kernels(gridded):
+def test_fused_step_evolves_every_motion_model_like_the_staged_kernels(gridded, math):
     """CylindricalMotion and the tangent models (motion.py:207-522) in the fused kernel's general instantiation: one
     context mixing all four kinds (the kind is a per-point parameter), constant and gridded surfaces, a frame on
     which no observer has an image (the tangent models have no log-likelihood term either: the weights stay as they
@@ -331,6 +332,7 @@ def test_fused_step_evolves_every_motion_model_like_the_staged_kernels(gridded):
                     ctx.set_raster(lib.RASTER_DEM_SIGMA, dem_sigma)
                 ctx.set_motion(params)
                 ctx.set_fused(mode)
+                ctx.set_math(math)  # (fast: the general instantiation in fast arithmetic, glh_set_math)
                 ctx.set_debug(2)
                 ctx.set_frame(0)
                 ctx.init_particles(seed=8) if device_rng else ctx.init_particles(normals=init)
