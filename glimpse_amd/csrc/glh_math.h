@@ -620,6 +620,19 @@ GLH_HD void spline_cell_row(const double* tab, const double* coef, int ld, int h
   for (int b = 0; b < 4; ++b)
     out4[b] = glh_fma(t[3], mu[12 + b], glh_fma(t[2], mu[8 + b], glh_fma(t[1], mu[4 + b], t[0] * mu[b])));
 }
+// interval q = spline_interval(xl, n) and the offset xl - spline_interval_start(q) of a clamped coordinate, without
+// leaving float64: q = clamp(floor(xl) - 1, 0, n - 4) and start = q + min(q, 1) (0 for the double-width first
+// interval, q + 1 after it) are small integers, exact in either type
+GLH_HD double spline_cell_offset(double xl, int n, int& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double fl = __builtin_floor(xl);
+#else
+  const double fl = floor(xl);
+#endif
+  const double qd = min_nn(max_nn(fl - 1.0, 0.0), (double)(n - 4));
+  q = (int)qd;
+  return xl - (qd + min_nn(qd, 1.0));
+}
 // Horner in su along each row, then in sv across the rows; p = 16 doubles [a][b]
 GLH_HD double spline_cell_horner(const double* p, double sv, double su) {
   double r[4];
@@ -631,9 +644,8 @@ GLH_HD double spline_cell_horner(const double* p, double sv, double su) {
 GLH_HD double spline_eval_cell(const double* cells, int ho, int wo, double cv0, double cu0, double u, double v) {
   const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
   const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
-  const int qv = spline_interval(vl, ho);
-  const int qu = spline_interval(ul, wo);
-  const double sv = vl - spline_interval_start(qv), su = ul - spline_interval_start(qu);
+  int qv, qu;
+  const double sv = spline_cell_offset(vl, ho, qv), su = spline_cell_offset(ul, wo, qu);
   return spline_cell_horner(cells + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD, sv, su);
 }
 // the same value without a cell table: the particle's cell is converted on the spot (the staged kernels; every
@@ -642,9 +654,8 @@ GLH_HD double spline_eval_cell_direct(const double* tab, const double* coef, int
                                       double cu0, double u, double v) {
   const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
   const double vl = min_nn(max_nn(v - cv0, 0.0), vmax), ul = min_nn(max_nn(u - cu0, 0.0), umax);
-  const int qv = spline_interval(vl, ho);
-  const int qu = spline_interval(ul, wo);
-  const double sv = vl - spline_interval_start(qv), su = ul - spline_interval_start(qu);
+  int qv, qu;
+  const double sv = spline_cell_offset(vl, ho, qv), su = spline_cell_offset(ul, wo, qu);
   double p[16];
   for (int a = 0; a < 4; ++a) spline_cell_row(tab, coef, ld, ho, wo, qv, qu, a, p + 4 * a);
   return spline_cell_horner(p, sv, su);
