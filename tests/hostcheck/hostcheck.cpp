@@ -167,6 +167,25 @@ double hc_exp_fast(double x) {
   }
   return weight_of<true>(-x, tab) - 1e-300;
 }
+// the fast arithmetic's sampling: per-cell power form, as a table (the fused kernel) and converted on the spot (the
+// staged kernels); out[0] = coefficient form (exact arithmetic), out[1] = table, out[2] = on the spot
+void hc_spline_cell_forms(const double* coef, int ho, int wo, double cv0, double cu0, const double* uv, int n,
+                          double* out) {
+  std::vector<double> tab(16 * GLH_NPOLY);
+  basis_poly_table(tab.data());
+  std::vector<double> cells((size_t)spline_cells(ho) * spline_cells(wo) * GLH_CELL_LD, 0.0);
+  for (int qv = 0; qv < spline_cells(ho); ++qv)
+    for (int qu = 0; qu < spline_cells(wo); ++qu)
+      for (int r = 0; r < 4; ++r)
+        spline_cell_row(tab.data(), coef, wo, ho, wo, qv, qu, r,
+                        cells.data() + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD + 4 * r);
+  for (int i = 0; i < n; ++i) {
+    const double u = uv[2 * i], v = uv[2 * i + 1];
+    out[3 * i] = spline_eval_poly(tab.data(), coef, wo, ho, wo, cv0, cu0, u, v);
+    out[3 * i + 1] = spline_eval_cell(cells.data(), ho, wo, cv0, cu0, u, v);
+    out[3 * i + 2] = spline_eval_cell_direct(tab.data(), coef, wo, ho, wo, cv0, cu0, u, v);
+  }
+}
 void hc_project_fast(const double* cam24, const double* xyz, int n, double* uv) {
   CamDev c;
   expand_camera(cam24, &c);

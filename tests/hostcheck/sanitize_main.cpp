@@ -77,6 +77,17 @@ int main() {
     const double b = spline_eval_poly_fast(tab.data(), coef.data(), wo, ho, wo, 0.0, 0.0, u, v);
     const double c = spline_eval(coef.data(), wo, ho, wo, 0.0, 0.0, u, v);
     REQUIRE(std::isfinite(a) && std::fabs(a - b) < 1e-12 && std::fabs(a - c) < 1e-12);
+    // the per-cell power form: the table and the on-the-spot conversion are the same number, within rounding of the
+    // coefficient form
+    std::vector<double> cells((size_t)spline_cells(ho) * spline_cells(wo) * GLH_CELL_LD, 0.0);
+    for (int qv = 0; qv < spline_cells(ho); ++qv)
+      for (int qu = 0; qu < spline_cells(wo); ++qu)
+        for (int r = 0; r < 4; ++r)
+          spline_cell_row(tab.data(), coef.data(), wo, ho, wo, qv, qu, r,
+                          cells.data() + (size_t)(qv * spline_cells(wo) + qu) * GLH_CELL_LD + 4 * r);
+    const double d = spline_eval_cell(cells.data(), ho, wo, 0.0, 0.0, u, v);
+    const double e = spline_eval_cell_direct(tab.data(), coef.data(), wo, ho, wo, 0.0, 0.0, u, v);
+    REQUIRE(d == e && std::fabs(a - d) < 1e-12);
   }
   // cameras, projection (both arithmetics), search / template boxes, np_interp, reflect, median network
   for (int trial = 0; trial < 500; ++trial) {

@@ -213,3 +213,31 @@ def test_host_tables_and_stage_math_under_sanitizers():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0 and "SANITIZE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_cell_form_of_the_fitted_surface_equals_the_coefficient_form(hc):
+    """GLH_MATH_FAST samples a fitted surface in per-cell power form (glh_math.h: spline_cell_row / spline_eval_cell):
+    for every surface side 4 .. 34 (the short sides have their own basis matrices) and arguments inside, on the knots,
+    on the border and outside (clamped), (a) the table the fused kernel builds and the on-the-spot conversion of the
+    staged kernels are the same float64, (b) both are the exact arithmetic's coefficient form to rounding."""
+    rng = np.random.default_rng(23)
+    worst = 0.0
+    for ho, wo in [(n, m) for n in range(4, 20) for m in (4, 5, 8, 9, 13, 20)] + [(34, 34), (12, 31), (31, 12)]:
+        coef = np.ascontiguousarray(rng.standard_normal((ho, wo)) * 3.0)
+        n = 400
+        uv = np.empty((n, 2))
+        uv[:, 0] = rng.uniform(-2.0, wo + 1.0, n)
+        uv[:, 1] = rng.uniform(-2.0, ho + 1.0, n)
+        uv[:40, 0] = rng.integers(0, wo, 40)           # on the knots
+        uv[40:80, 1] = rng.integers(0, ho, 40)
+        uv[80:90] = [[0.0, 0.0], [wo - 1.0, ho - 1.0], [1.0, 1.0], [2.0, 2.0], [wo - 2.0, ho - 2.0], [wo - 3.0, 1.5],
+                     [1.999999999, 2.000000001], [wo - 1.0 - 1e-12, 0.5], [0.5, ho - 1.0 + 1e-9], [-0.0, 3.0]]
+        cu0, cv0 = 100.25, -7.5
+        uv_abs = np.ascontiguousarray(uv + [cu0, cv0])
+        out = np.empty((n, 3))
+        hc.hc_spline_cell_forms(p(coef), ho, wo, C.c_double(cv0), C.c_double(cu0), p(uv_abs), n, p(out))
+        assert np.isfinite(out).all()
+        np.testing.assert_array_equal(out[:, 1], out[:, 2])
+        scale = np.abs(coef).max()
+        worst = max(worst, np.abs(out[:, 1] - out[:, 0]).max() / scale)
+    assert worst < 5e-14, worst
