@@ -215,6 +215,25 @@ GLH_HD void project_fast(const CamDev& c, uint32_t f, double x, double y, double
   u = glh_fma(qx, c.f[0], c.off[0]);
   v = glh_fma(qy, c.f[1], c.off[1]);
 }
+// project_fast for the cameras most sequences have -- perspective, radial distortion without a denominator (k4..k6 = 0),
+// no tangential terms, no elevation correction, world coordinates: the same operations in the same order without the
+// uniform branches (a pinhole's k = 0 gives dr = 1 exactly and qx = px * 1).  The fused kernel's common instantiation
+// in fast arithmetic compiles this form only; other cameras run on the general instantiation.
+constexpr uint32_t CAM_F_NOT_SIMPLE = CAM_F_CORR | CAM_F_ANYKDEN | CAM_F_ANYP | CAM_F_GRID | CAM_F_DIRECTIONS;
+GLH_HD void project_simple_fast(const CamDev& c, double x, double y, double z, double& u, double& v) {
+  const double dx = x - c.xyz[0], dy = y - c.xyz[1], dz = z - c.xyz[2];
+  const double cx = glh_fma(c.R[0], dx, glh_fma(c.R[1], dy, c.R[2] * dz));
+  const double cy = glh_fma(c.R[3], dx, glh_fma(c.R[4], dy, c.R[5] * dz));
+  const double cz = glh_fma(c.R[6], dx, glh_fma(c.R[7], dy, c.R[8] * dz));
+  const double inv = rcp_nr(cz);
+  const double px = cx * inv, py = cy * inv;
+  const double r2 = glh_fma(px, px, py * py);
+  const double dr = glh_fma(r2, glh_fma(r2, glh_fma(r2, c.k[2], c.k[1]), c.k[0]), 1.0);
+  const double uu = glh_fma(px * dr, c.f[0], c.off[0]), vv = glh_fma(py * dr, c.f[1], c.off[1]);
+  const bool front = cz > 0.0;
+  u = front ? uu : NAN;
+  v = front ? vv : NAN;
+}
 template <bool FAST>
 GLH_HD void project_m(const CamDev& c, uint32_t f, double x, double y, double z, double& u, double& v) {
   if (FAST)

@@ -681,7 +681,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
           double u, v;
-          project_m<FAST>(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
+          if constexpr (FAST && !SURF)
+            project_simple_fast(s_cam[o], x[0], x[1], x[2], u, v);  // (the host sends other cameras to the general instantiation)
+          else
+            project_m<FAST>(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
           if (o == 0) {
             if constexpr (PPT > 0) {
               pt_put<NREG>(u0, r, u);

@@ -1409,8 +1409,12 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     if (big && ppt == 4) ppt = 10;
     if (getenv("GLH_PT_UVLDS") || O == 2) ppt = 0;
     // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
-    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian;
     const bool fast = use_fast(c);
+    // ... and, in fast arithmetic, cameras beyond perspective + radial numerator (the common instantiation compiles
+    // project_simple_fast only)
+    bool plain_cameras = true;
+    for (int o = 0; o < O; ++o) plain_cameras &= !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
+    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !plain_cameras);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \
     if (surf && fast)                                                                                          \
