@@ -468,9 +468,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   double* W = a.weights_tmp + (size_t)pt * N;
   const double tau = a.tau, tau2 = a.tau * a.tau;
 
+  // The common instantiation in fast arithmetic is compiled for the configuration long device-RNG runs have on all but
+  // their first frame -- device Philox draws, every observer on and unmasked, compact input records, plain cameras --
+  // so that none of those tests is a branch in its particle loops; the host (fused_step) sends every other case to the
+  // general instantiation.
+  constexpr bool COMMON = FAST && !SURF;
+  const int rng_mode = COMMON ? (int)GLH_RNG_PHILOX : a.rng_mode;
   PT_STAMP(0);
   if (tid == 0) {
-    if (a.rng_mode == GLH_RNG_HOST) {
+    if (rng_mode == GLH_RNG_HOST) {
       s_u = a.u[pt];
     } else {
       uint32_t r[4];
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   }
   bool live[NOBS];  // uniform across the block
 #pragma unroll
-  for (int o = 0; o < NOBS; ++o) live[o] = a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]);
+  for (int o = 0; o < NOBS; ++o) live[o] = COMMON || (a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]));
   // fetched here, used at the end of phase A: no memory latency between the last particle and the search box
   const int hist_n0 = a.tmpl_hist_n[pt];
   const int valid_o = tid < NOBS ? (int)a.tmpl_valid[(size_t)tid * a.P + pt] : 0;
@@ -575,9 +581,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   };
   // record of every particle (compact input state): staged in region 2, which is free until phase B -- together with
   // the tables above, so that the kernel starts with one memory latency, not two
-  const uint16_t* uin = a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
+  const uint16_t* uin = COMMON || a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
   uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
-  if (uin) {
+  if (COMMON || uin) {
     if ((N & 7) == 0)  // whole 16-byte words (the rows of uidx are N uint16 apart): every load of a thread in flight at once
       pt_stage<TB>(reinterpret_cast<uint4*>(s_rec), reinterpret_cast<const uint4*>(uin), N >> 3);
     else
@@ -593,15 +599,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // A record is three 16-byte chunks.  One record per particle (what every other kernel reads and writes): chunk c
   // of record r at 3 r + c.  Compact (this kernel's own output): PLANAR, chunk c of record r at c N + r, so that
   // consecutive lanes store, and mostly load, consecutive 16-byte words.
-  const int rec_stride = uin ? 1 : 3, chunk_stride = uin ? N : 1;
+  const int rec_stride = COMMON || uin ? 1 : 3, chunk_stride = COMMON || uin ? N : 1;
   const double2* Pin2 = reinterpret_cast<const double2*>(Pin);
   auto evolved = [&](int k, double* x) {
-    const int rec = uin ? (int)uin[k] : k;
+    const int rec = COMMON || uin ? (int)uin[k] : k;
     const double2* src = Pin2 + (size_t)rec * rec_stride;
     const double2 v0 = src[0], v1 = src[chunk_stride], v2 = src[2 * chunk_stride];
     x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
     double n[3];
-    evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
+    evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
       evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &oob);
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       if (i < N) {
         double n[3];
-        evolve_noise(a.rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
         if constexpr (SURF)
           evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &raster_oob);
         else

@@ -1410,11 +1410,12 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     if (getenv("GLH_PT_UVLDS") || O == 2) ppt = 0;
     // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
     const bool fast = use_fast(c);
-    // ... and, in fast arithmetic, cameras beyond perspective + radial numerator (the common instantiation compiles
-    // project_simple_fast only)
-    bool plain_cameras = true;
-    for (int o = 0; o < O; ++o) plain_cameras &= !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
-    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !plain_cameras);
+    // ... and, in fast arithmetic, everything the common instantiation is not compiled for (glh_point.h: COMMON): it
+    // takes device Philox draws, compact input records, every observer on and unmasked, and cameras within
+    // perspective + radial numerator (project_simple_fast)
+    bool common = rng_mode == GLH_RNG_PHILOX && c->compact && !c->have_mask;
+    for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
+    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \
     if (surf && fast)                                                                                          \
