@@ -711,9 +711,10 @@ GLH_HD double exp_fast(double x, const double* tab32) {
 template <bool FAST>
 GLH_HD double weight_of(double ll, const double* tab32) {
   if (FAST) {
-    // exp underflows to 0 below -745.2, like the library's (ki stays a small int: ll < 2^24)
+    // exp underflows to 0 below -745.2, like the library's.  Arguments below -746 are replaced by -800 (whose
+    // 2^-1154 scaling rounds to 0 as well) rather than branched around: ki stays a small int, a NaN stays a NaN
     const double x = -ll;
-    return (x < -746.0 ? 0.0 : exp_fast(x, tab32)) + 1e-300;
+    return exp_fast(x < -746.0 ? -800.0 : x, tab32) + 1e-300;
   }
   return exp(-ll) + 1e-300;
 }

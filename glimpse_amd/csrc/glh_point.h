@@ -853,14 +853,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           for (int r = 0; r < NREG; ++r) {
             if (r < rounds) {  // uniform
               const int i = r * TB + tid;
-              if (i < N) u0[r] = sample_one(make_double2(u0[r], c[i]));
+              if constexpr (FAST && !CELLS) {
+                // (the coefficient form in fast arithmetic is the fallback for surfaces beyond the cell table, the
+                // first frames after a wide prior: its results are stored at once -- held back like the others they
+                // made this loop the register peak of the whole kernel)
+                if (i < N) c[i] = sample_one(make_double2(u0[r], c[i]));
+              } else {
+                if (i < N) u0[r] = sample_one(make_double2(u0[r], c[i]));
+              }
             }
           }
+          if constexpr (!(FAST && !CELLS)) {
 #pragma unroll
-          for (int r = 0; r < NREG; ++r) {
-            if (r < rounds) {
-              const int i = r * TB + tid;
-              if (i < N) c[i] = u0[r];
+            for (int r = 0; r < NREG; ++r) {
+              if (r < rounds) {
+                const int i = r * TB + tid;
+                if (i < N) c[i] = u0[r];
+              }
             }
           }
         } else {
