@@ -101,6 +101,7 @@ SIGNATURES = {
     "glh_set_math": (_I, [_P, _I]),
     "glh_set_highpass": (_I, [_P, _I, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
+    "glh_debug_last_variant": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
     "glh_get_template": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -450,6 +451,13 @@ class Context:
         out = np.zeros((self.P, 20), dtype=np.uint64)
         check(self.lib.glh_debug_phase_stamps(self.handle, _ptr(out)))
         return out
+
+    def last_variant(self):
+        """Diagnostic: (threads, particles in registers, observers, flags) of the fused kernel instantiation that took
+        the last fused step; flags bit 0 = fast arithmetic, bit 1 = the general instantiation."""
+        out = np.zeros(4, dtype=np.int32)
+        check(self.lib.glh_debug_last_variant(self.handle, _ptr(out)))
+        return tuple(int(v) for v in out)
 
     def sync(self):
         check(self.lib.glh_sync(self.handle))

@@ -145,6 +145,7 @@ struct glh_ctx {
   int32_t *leaf_off = nullptr, *leaf_len = nullptr, *sum_ops = nullptr, *level_off = nullptr, *roots = nullptr;
   int nleaves = 0, nnodes = 0, nlevels = 0, nroots = 0;
   int moments_frame = -1;  // history slot already filled by the fused resample kernel
+  int32_t last_variant[4] = {0, 0, 0, 0};  // fused kernel instantiation of the last step: TB, PPT, NOBS, fast | general << 1
   size_t normals_cap = 0;
   // profiling
   bool profiling = false;
@@ -1418,6 +1419,8 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \
+    c->last_variant[0] = TB_; c->last_variant[1] = PPT_; c->last_variant[2] = NOBS_;                           \
+    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0);                                                      \
     if (surf && fast)                                                                                          \
       hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true>), grid, block, lds, c->stream, a);     \
     else if (surf)                                                                                             \
@@ -1561,6 +1564,12 @@ extern "C" int glh_measure_copy_bandwidth(glh_ctx* c, uint64_t bytes, int iters,
   dfree(dst);
   if (err != hipSuccess) return fail(GLH_E_HIP, "copy bandwidth measurement failed: %s", hipGetErrorString(err));
   *gbps = 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+  return GLH_OK;
+}
+
+extern "C" int glh_debug_last_variant(glh_ctx* c, int32_t* variant) {
+  if (!c || !variant) return fail(GLH_E_INVALID, "null argument");
+  for (int k = 0; k < 4; ++k) variant[k] = c->last_variant[k];
   return GLH_OK;
 }
 

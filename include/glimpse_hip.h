@@ -280,6 +280,10 @@ int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
 /* Diagnostic: s_memtime stamps [P][20] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
+/* Diagnostic: which instantiation of the fused kernel took the last fused glh_step / glh_track frame:
+ * variant[0..3] = threads per workgroup, particles kept in registers per thread, observers, flags (bit 0: fast
+ * arithmetic, bit 1: the general instantiation; flags == 1 is the common one bench.py times).  Zeros before any.  */
+int glh_debug_last_variant(glh_ctx* ctx, int32_t* variant);
 
 /* ---- results --------------------------------------------------------------------------- */
 /* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
