@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     int rank = incl_s - nsurv;
     for (int w = 0; w < wave; ++w) rank += (int)scan_tmp[w];
     if (tid == TB - 1) s_U = rank + nsurv;
-    for (int j = tid; j < N; j += TB) ufill[j] = 0;
+    for (int q = tid; q < n16 / 8; q += TB) reinterpret_cast<uint4*>(ufill)[q] = make_uint4(0u, 0u, 0u, 0u);  // (n16: whole 16-byte words)
     pt_lds_barrier();
     if (s_U == 0 && tid == 0) {  // no comparison succeeded (NaN weights): every output is a copy of source 0
       usrc[0] = 0;
@@ -1272,10 +1272,30 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     pt_lds_barrier();
+    // Whole segments of an even length up to 10 (the benched shapes): the segment as 32-bit words, its prefix
+    // maxima kept in registers until the maxima of the segments before it are known -- one read and one write per
+    // word instead of two reads and two writes per entry.
+    constexpr int MS_W = 5;
+    const bool words = (seg & 1) == 0 && seg <= 2 * MS_W && N % seg == 0;  // uniform
+    uint32_t* segw = reinterpret_cast<uint32_t*>(ufill + k0);            // (k0 is even: 4-byte aligned)
+    uint32_t wv[MS_W];
     uint32_t runmax = 0;
-    for (int j = k0; j < k1; ++j) {
-      runmax = max(runmax, (uint32_t)ufill[j]);
-      ufill[j] = (uint16_t)runmax;
+    if (words) {
+#pragma unroll
+      for (int q = 0; q < MS_W; ++q) {
+        wv[q] = 0;
+        if (2 * q < seg && k0 < N) {
+          const uint32_t w = segw[q];
+          const uint32_t lo = max(w & 0xffffu, runmax), hi = max(w >> 16, lo);
+          runmax = hi;
+          wv[q] = lo | (hi << 16);
+        }
+      }
+    } else {
+      for (int j = k0; j < k1; ++j) {
+        runmax = max(runmax, (uint32_t)ufill[j]);
+        ufill[j] = (uint16_t)runmax;
+      }
     }
     uint32_t incl_m = runmax;
 #pragma unroll
@@ -1289,8 +1309,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (lane == 0) before = 0;
     pt_lds_barrier();
     for (int w = 0; w < wave; ++w) before = max(before, scan_tmp[w]);
-    if (before > 0)
+    if (words) {
+      const glh_us2 bb = {(unsigned short)before, (unsigned short)before};
+#pragma unroll
+      for (int q = 0; q < MS_W; ++q)
+        if (2 * q < seg && k0 < N)
+          segw[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(glh_us2, wv[q]), bb));
+    } else if (before > 0) {
       for (int j = k0; j < k1; ++j) ufill[j] = (uint16_t)max((uint32_t)ufill[j], before);
+    }
   }
   pt_lds_barrier();
 
@@ -1350,10 +1377,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   {
     // which record every output is, and (debug) which source it came from
     uint16_t* uout = a.uidx_out + (size_t)pt * N;
-    for (int j = tid; j < N; j += TB) {
-      const int h = max((int)ufill[j], 1) - 1;
-      uout[j] = (uint16_t)h;
-      if (a.idx_out) a.idx_out[(size_t)pt * N + j] = usrc[h];
+    if (!a.idx_out && (N & 7) == 0) {
+      // eight outputs per thread: one 16-byte LDS read, packed 16-bit max / subtract, one 16-byte store
+      const glh_us2 one = {1, 1};
+      for (int q = tid; q < N / 8; q += TB) {
+        uint4 v = reinterpret_cast<const uint4*>(ufill)[q];
+        uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          w[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(glh_us2, w[k]), one) - one);
+        reinterpret_cast<uint4*>(uout)[q] = v;
+      }
+    } else {
+      for (int j = tid; j < N; j += TB) {
+        const int h = max((int)ufill[j], 1) - 1;
+        uout[j] = (uint16_t)h;
+        if (a.idx_out) a.idx_out[(size_t)pt * N + j] = usrc[h];
+      }
     }
   }
   PT_STAMP(8);
