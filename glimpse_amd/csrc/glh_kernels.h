@@ -185,6 +185,66 @@ __device__ __forceinline__ double dem_log_likelihood(const double* m, const Surf
   return 0.0;
 }
 
+// Wave64 reductions and inclusive scans on the DPP data path (VALU moves; the canonical row_shr / row_bcast ladder)
+// instead of ds_bpermute shuffles through the LDS crossbar: lane i ends with OP over lanes 0 .. i (lane 63: the total).
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool ZERO_FILL>
+__device__ __forceinline__ double pt_dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  // ZERO_FILL: lanes without a source read 0 (identity of +); otherwise they keep their own value
+  // (identity of min / max)
+  lo = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : lo, lo, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
+  hi = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : hi, hi, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
+  return __hiloint2double(hi, lo);
+}
+// row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+#define PT_DPP_LADDER(OP, ZF)                          \
+  v = OP(v, (pt_dpp_mov<0x111, 0xf, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x112, 0xf, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x114, 0xf, 0xe, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x118, 0xf, 0xc, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x142, 0xa, 0xf, ZF>(v)));     \
+  v = OP(v, (pt_dpp_mov<0x143, 0xc, 0xf, ZF>(v)));
+__device__ __forceinline__ double pt_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double pt_wave_sum63(double v) {
+  PT_DPP_LADDER(pt_add, true)
+  return v;
+}
+__device__ __forceinline__ double pt_wave_min63(double v) {
+  PT_DPP_LADDER(fmin, false)
+  return v;
+}
+__device__ __forceinline__ double pt_wave_max63(double v) {
+  PT_DPP_LADDER(fmax, false)
+  return v;
+}
+
+// inclusive scans of 32-bit values (lanes without a source read 0: the identity of + and of an unsigned max)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t pt_dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+#define PT_DPP_LADDER_U32(OP)                        \
+  v = OP(v, (pt_dpp_u32<0x111, 0xf, 0xf>(v)));       \
+  v = OP(v, (pt_dpp_u32<0x112, 0xf, 0xf>(v)));       \
+  v = OP(v, (pt_dpp_u32<0x114, 0xf, 0xe>(v)));       \
+  v = OP(v, (pt_dpp_u32<0x118, 0xf, 0xc>(v)));       \
+  v = OP(v, (pt_dpp_u32<0x142, 0xa, 0xf>(v)));       \
+  v = OP(v, (pt_dpp_u32<0x143, 0xc, 0xf>(v)));
+__device__ __forceinline__ uint32_t pt_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t pt_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+  PT_DPP_LADDER_U32(pt_add_u32)
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
+  PT_DPP_LADDER_U32(pt_max_u32)
+  return v;
+}
+__device__ __forceinline__ double wave_scan_add_f64(double v) { return pt_wave_sum63(v); }
+// lane i takes lane i - 1's value, lane 0 takes 0 (wave_shr:1 = 0x138)
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) { return pt_dpp_u32<0x138, 0xf, 0xf>(v); }
+__device__ __forceinline__ double wave_shr1_f64(double v) { return pt_dpp_mov<0x138, 0xf, 0xf, true>(v); }
+
 // Motion.evolve_particles for one particle p[6], tau2 = tau * tau, n = the step's three normals
 // (randn(n,3); the tangent models draw randn(n,2) then randn(n)):
 // motion.py:165-179, :288-311, :396-412, :490-522.
@@ -1619,15 +1679,20 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
       run += divide ? c[k] / quot : c[k];
       c[k] = run;
     }
-    double incl = run;
+    double incl = run, prev;
+    if (fast_sys) {  // (the fused kernel's fast arithmetic scans with the DPP ladder: same association here)
+      incl = wave_scan_add_f64(run);
+      prev = wave_shr1_f64(incl);
+    } else {
 #pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      double t = __shfl_up(incl, off, WAVE);
-      if (lane >= off) incl += t;
+      for (int off = 1; off < WAVE; off <<= 1) {
+        double t = __shfl_up(incl, off, WAVE);
+        if (lane >= off) incl += t;
+      }
+      prev = __shfl_up(incl, 1, WAVE);  // exclusive prefix inside the wave (no subtraction)
+      if (lane == 0) prev = 0.0;
     }
     if (lane == WAVE - 1) wave_tot[tid / WAVE] = incl;
-    double prev = __shfl_up(incl, 1, WAVE);  // exclusive prefix inside the wave (no subtraction)
-    if (lane == 0) prev = 0.0;
     __syncthreads();
     double base = 0.0;
     for (int w = 0; w < tid / WAVE; ++w) base += wave_tot[w];

@@ -33,39 +33,6 @@ constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handl
 constexpr int PT_NSTAMP = 20;
 constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
 
-// Wave64 reductions on the DPP data path (VALU moves; the canonical row_shr / row_bcast ladder) instead
-// of ds_bpermute shuffles through the LDS crossbar: the result is valid in LANE 63.
-template <int CTRL, int ROW_MASK, int BANK_MASK, bool ZERO_FILL>
-__device__ __forceinline__ double pt_dpp_mov(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  // ZERO_FILL: lanes without a source read 0 (identity of +); otherwise they keep their own value
-  // (identity of min / max)
-  lo = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : lo, lo, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
-  hi = __builtin_amdgcn_update_dpp(ZERO_FILL ? 0 : hi, hi, CTRL, ROW_MASK, BANK_MASK, ZERO_FILL);
-  return __hiloint2double(hi, lo);
-}
-// row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-#define PT_DPP_LADDER(OP, ZF)                          \
-  v = OP(v, (pt_dpp_mov<0x111, 0xf, 0xf, ZF>(v)));     \
-  v = OP(v, (pt_dpp_mov<0x112, 0xf, 0xf, ZF>(v)));     \
-  v = OP(v, (pt_dpp_mov<0x114, 0xf, 0xe, ZF>(v)));     \
-  v = OP(v, (pt_dpp_mov<0x118, 0xf, 0xc, ZF>(v)));     \
-  v = OP(v, (pt_dpp_mov<0x142, 0xa, 0xf, ZF>(v)));     \
-  v = OP(v, (pt_dpp_mov<0x143, 0xc, 0xf, ZF>(v)));
-__device__ __forceinline__ double pt_add(double a, double b) { return a + b; }
-__device__ __forceinline__ double pt_wave_sum63(double v) {
-  PT_DPP_LADDER(pt_add, true)
-  return v;
-}
-__device__ __forceinline__ double pt_wave_min63(double v) {
-  PT_DPP_LADDER(fmin, false)
-  return v;
-}
-__device__ __forceinline__ double pt_wave_max63(double v) {
-  PT_DPP_LADDER(fmax, false)
-  return v;
-}
-
 template <int TB>
 __device__ __forceinline__ double pt_block_sum(double v, double* red) {
   v = wave_sum(v);
@@ -238,13 +205,8 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
     const uint32_t h0 = b0 < nb ? ws.hist[b0] : 0u, h1 = b1 < nb ? ws.hist[b1] : 0u;
     const uint32_t local = h0 + h1;
-    uint32_t incl = local;
+    const uint32_t incl = wave_scan_add_u32(local);
     const int lane = tid & (WAVE - 1);
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      uint32_t t = __shfl_up(incl, off, WAVE);
-      if (lane >= off) incl += t;
-    }
     if (lane == WAVE - 1) scan_tmp[tid / WAVE] = incl;
     __syncthreads();
     uint32_t base = 0;
@@ -1128,15 +1090,22 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   } else {
     for (int k = k0; k < k1; ++k) run += FAST ? c[k] : c[k] / total;
   }
-  double incl = run;
+  double incl = run, prev;
+  if constexpr (FAST) {
+    // (the DPP ladder: VALU moves instead of twelve ds_bpermute round trips; its association differs from the
+    // shuffle scan's, so the exact arithmetic -- pinned bit for bit by the host-RNG goldens -- keeps that one)
+    incl = wave_scan_add_f64(run);
+    prev = wave_shr1_f64(incl);
+  } else {
 #pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    double t = __shfl_up(incl, off, WAVE);
-    if (lane >= off) incl += t;
+    for (int off = 1; off < WAVE; off <<= 1) {
+      double t = __shfl_up(incl, off, WAVE);
+      if (lane >= off) incl += t;
+    }
+    prev = __shfl_up(incl, 1, WAVE);
+    if (lane == 0) prev = 0.0;
   }
   if (lane == WAVE - 1) wave_tot[wave] = incl;
-  double prev = __shfl_up(incl, 1, WAVE);
-  if (lane == 0) prev = 0.0;
   __syncthreads();
   double base = 0.0;
   for (int w = 0; w < wave; ++w) base += wave_tot[w];
@@ -1219,12 +1188,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     // exclusive scan of the survivor counts over the block
-    int incl_s = nsurv;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      const int t = __shfl_up(incl_s, off, WAVE);
-      if (lane >= off) incl_s += t;
-    }
+    const int incl_s = (int)wave_scan_add_u32((uint32_t)nsurv);
     if (lane == WAVE - 1) scan_tmp[wave] = (uint32_t)incl_s;
     pt_lds_barrier();  // every thread has read clast by now: the tables may overwrite it and the tree nodes
     int rank = incl_s - nsurv;
@@ -1297,16 +1261,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         ufill[j] = (uint16_t)runmax;
       }
     }
-    uint32_t incl_m = runmax;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-      const uint32_t t = __shfl_up(incl_m, off, WAVE);
-      if (lane >= off) incl_m = max(incl_m, t);
-    }
+    const uint32_t incl_m = wave_scan_max_u32(runmax);
     pt_lds_barrier();  // scan_tmp is reused: the survivor scan has been consumed
     if (lane == WAVE - 1) scan_tmp[wave] = incl_m;
-    uint32_t before = __shfl_up(incl_m, 1, WAVE);
-    if (lane == 0) before = 0;
+    uint32_t before = wave_shr1_u32(incl_m);
     pt_lds_barrier();
     for (int w = 0; w < wave; ++w) before = max(before, scan_tmp[w]);
     if (words) {
