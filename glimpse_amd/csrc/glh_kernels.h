@@ -245,6 +245,19 @@ __device__ __forceinline__ double wave_scan_add_f64(double v) { return pt_wave_s
 __device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) { return pt_dpp_u32<0x138, 0xf, 0xf>(v); }
 __device__ __forceinline__ double wave_shr1_f64(double v) { return pt_dpp_mov<0x138, 0xf, 0xf, true>(v); }
 
+// Sum over groups of G = 2, 4, 8 or 16 adjacent lanes, every lane ending with its group's total: the butterfly
+// v += shfl_xor(v, 1), 2, 4, 8 on the DPP path.  quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 exchanges; for
+// the third and fourth step row_half_mirror (i <-> 7 - i) and row_mirror (i <-> 15 - i) pair every lane with one of
+// the OTHER half, which by then holds that half's total in all its lanes -- the same two operands as the xor
+// exchange, and a + b == b + a, so the float64 result is bit for bit the shuffle butterfly's.
+__device__ __forceinline__ double group_sum_dpp(double v, int G) {
+  if (G > 1) v += pt_dpp_mov<0xb1, 0xf, 0xf, false>(v);   // quad_perm:[1,0,3,2]
+  if (G > 2) v += pt_dpp_mov<0x4e, 0xf, 0xf, false>(v);   // quad_perm:[2,3,0,1]
+  if (G > 4) v += pt_dpp_mov<0x141, 0xf, 0xf, false>(v);  // row_half_mirror
+  if (G > 8) v += pt_dpp_mov<0x140, 0xf, 0xf, false>(v);  // row_mirror
+  return v;
+}
+
 // Motion.evolve_particles for one particle p[6], tau2 = tau * tau, n = the step's three normals
 // (randn(n,3); the tangent models draw randn(n,2) then randn(n)):
 // motion.py:165-179, :288-311, :396-412, :490-522.

@@ -294,10 +294,8 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
 #pragma unroll
     for (int k = 0; k < SSD_W; ++k) acc64[k] = 0.0;
     if (live) ssd_strip_rows(ws.S, ws.ld, ws.T, tw, th, twp, rr, cc, g, G, acc64);
-    for (int off = 1; off < G; off <<= 1) {
 #pragma unroll
-      for (int k = 0; k < SSD_W; ++k) acc64[k] += __shfl_xor(acc64[k], off, WAVE);
-    }
+    for (int k = 0; k < SSD_W; ++k) acc64[k] = group_sum_dpp(acc64[k], G);  // (G <= 16: inside a DPP row)
     if (live && g == 0) {
 #pragma unroll
       for (int k = 0; k < SSD_W; ++k) {
