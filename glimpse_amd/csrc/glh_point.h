@@ -1078,7 +1078,27 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const int k0 = min(tid * seg, N), k1 = min(k0 + seg, N);
   double run = 0.0;
   double qn[NREG];
-  if constexpr (PPT > 0) {
+  if constexpr (PPT > 0 && FAST && (NREG & 1) == 0) {
+    // whole segments of the full (even) length: aligned 16-byte reads, no guards (adding the 0.0 of an idle thread's
+    // registers changes nothing: the sums are of non-negative weights, never -0.0)
+    if (seg == NREG && N % seg == 0) {  // uniform
+      const double2* c2 = reinterpret_cast<const double2*>(c + (k0 < N ? k0 : 0));
+#pragma unroll
+      for (int j = 0; j < NREG; j += 2) {
+        const double2 q = c2[j >> 1];
+        qn[j] = k0 < N ? q.x : 0.0;
+        qn[j + 1] = k0 < N ? q.y : 0.0;
+        run += qn[j];
+        run += qn[j + 1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NREG; ++j) {
+        qn[j] = k0 + j < k1 ? c[k0 + j] : 0.0;
+        if (k0 + j < k1) run += qn[j];
+      }
+    }
+  } else if constexpr (PPT > 0) {
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
       // (FAST: the raw weights are scanned; the positions are scaled by N / total instead)
@@ -1117,11 +1137,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(12);
   const double u = s_u;  // the point's resample offset (drawn once, in the prologue)
   const double inv_n = 1.0 / (double)N;
-  // Region 2 once the tree nodes and clast are dead: three tables of N uint16 each.
+  // Region 2 once the tree nodes and clast are dead: N uint16 (rank per output) and N uint32 (source and copies per rank).
   const int n16 = pt_align16(N * 2) / 2;
   uint16_t* ufill = reinterpret_cast<uint16_t*>(r2);  // rank + 1 of the source that serves output j
-  uint16_t* usrc = ufill + n16;                        // source of rank h
-  uint16_t* ucnt = usrc + n16;                         // copies of the source of rank h
+  uint32_t* usc = reinterpret_cast<uint32_t*>(ufill + n16);  // rank h: its source | copies of it << 16 (one word)
   __shared__ int s_U;
   {
     // f(ck) = #{j : pos_j <= ck}, pos_j = (j + u) * (1 / n) exactly as tracker.py:173 rounds it.  The guess
@@ -1195,8 +1214,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int q = tid; q < n16 / 8; q += TB) reinterpret_cast<uint4*>(ufill)[q] = make_uint4(0u, 0u, 0u, 0u);  // (n16: whole 16-byte words)
     pt_lds_barrier();
     if (s_U == 0 && tid == 0) {  // no comparison succeeded (NaN weights): every output is a copy of source 0
-      usrc[0] = 0;
-      ucnt[0] = (uint16_t)N;
+      usc[0] = (uint32_t)N << 16;
       ufill[0] = 1;
     }
     // pass 2: survivors take their rank
@@ -1210,8 +1228,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           if (k < k1) {
             const int f = fk[j];
             if (f > f_prev) {
-              usrc[rank] = (uint16_t)k;
-              ucnt[rank] = (uint16_t)(f - f_prev);
+              usc[rank] = (uint32_t)k | ((uint32_t)(f - f_prev) << 16);
               ufill[f_prev] = (uint16_t)(rank + 1);
               ++rank;
             }
@@ -1224,8 +1241,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           int f = count_le(tid > 0 ? excl + run2 : run2);
           if (k == N - 1 && f < N) f = N;
           if (f > f_prev) {
-            usrc[rank] = (uint16_t)k;
-            ucnt[rank] = (uint16_t)(f - f_prev);
+            usc[rank] = (uint32_t)k | ((uint32_t)(f - f_prev) << 16);
             ufill[f_prev] = (uint16_t)(rank + 1);
             ++rank;
           }
@@ -1293,8 +1309,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
       const int h = h0 + g * TB;
-      lo[g] = h < U ? usrc[h] : 0;
-      cnt[g] = h < U ? ucnt[h] : 0;
+      const uint32_t sc = h < U ? usc[h] : 0u;
+      lo[g] = (int)(sc & 0xffffu);
+      cnt[g] = (int)(sc >> 16);
     }
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
@@ -1348,7 +1365,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       for (int j = tid; j < N; j += TB) {
         const int h = max((int)ufill[j], 1) - 1;
         uout[j] = (uint16_t)h;
-        if (a.idx_out) a.idx_out[(size_t)pt * N + j] = usrc[h];
+        if (a.idx_out) a.idx_out[(size_t)pt * N + j] = (int32_t)(usc[h] & 0xffffu);
       }
     }
   }
