@@ -35,7 +35,10 @@ def _run(name, P, N, T, math, fused, imgsz=(640, 640)):
                     idx=np.stack(idx))
 
 
-@pytest.mark.parametrize("name,P,N", [("C2", 12, 2000), ("C3", 6, 5000), ("C5", 6, 3000), ("C4", 3, 10000)])
+@pytest.mark.parametrize("name,P,N", [("C2", 12, 2000), ("C3", 6, 5000), ("C5", 6, 3000), ("C4", 3, 10000),
+                                      # particle counts that leave partial segments / odd segment lengths / no whole
+                                      # 16-byte words: the guarded forms of the vectorised loops
+                                      ("C2", 5, 777), ("C3", 4, 2049), ("C3", 3, 4999), ("C5", 3, 1501), ("C3", 2, 6007)])
 def test_fast_fused_equals_fast_staged_bit_for_bit(name, P, N):
     T = 4
     fused = _run(name, P, N, T, "fast", 1)
