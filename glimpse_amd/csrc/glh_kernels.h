@@ -1599,7 +1599,7 @@ __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
 // the positions, which only the host-RNG parity mode needs).  NaN -> 0.
 __device__ __forceinline__ int count_le_fast(double ck, double scale, double u, int n) {
   const double g = floor(glh_fma(ck, scale, -u)) + 1.0;
-  return g >= 0.0 ? (g > (double)n ? n : (int)g) : 0;
+  return (int)min_nn(max_nn(g, 0.0), (double)n);  // (max returns its number operand: NaN -> 0)
 }
 
 struct ResampleArgs {
