@@ -587,12 +587,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   double* V0 = a.uv + (size_t)pt * N * 2;
   double u0[NREG];
   {
-    double mn[NOBS][2], mx[NOBS][2], nanf[NOBS];
+    double mn[NOBS][2], mx[NOBS][2];
+    bool nanf[NOBS];  // some particle of this thread projects to NaN (a lane mask: no vector registers)
 #pragma unroll
     for (int o = 0; o < NOBS; ++o) {
       mn[o][0] = mn[o][1] = INFINITY;
       mx[o][0] = mx[o][1] = -INFINITY;
-      nanf[o] = 0.0;
+      nanf[o] = false;
     }
     bool bad = false, raster_oob = false;
     uint32_t view_bits = 0u;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           } else
             reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * N + i] = make_double2(u, v);
           if (isnan(u) || isnan(v)) {
-            nanf[o] = 1.0;
+            nanf[o] = true;
           } else {
             mn[o][0] = min_nn(mn[o][0], u); mx[o][0] = max_nn(mx[o][0], u);  // (u, v are not NaN here)
             mn[o][1] = min_nn(mn[o][1], v); mx[o][1] = max_nn(mx[o][1], v);
@@ -689,7 +690,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int o = 0; o < NOBS; ++o) {
       if (!live[o]) continue;
       const double r0 = pt_wave_min63(mn[o][0]), r1 = pt_wave_min63(mn[o][1]);
-      const double r2m = pt_wave_max63(mx[o][0]), r3 = pt_wave_max63(mx[o][1]), r4 = pt_wave_max63(nanf[o]);
+      const double r2m = pt_wave_max63(mx[o][0]), r3 = pt_wave_max63(mx[o][1]);
+      const double r4 = __any(nanf[o]) ? 1.0 : 0.0;
       if (lane == WAVE - 1) {
         double* b = bred[o][wave];
         b[0] = r0; b[1] = r1; b[2] = r2m; b[3] = r3; b[4] = r4;
