@@ -454,7 +454,7 @@ class Context:
 
     def last_variant(self):
         """Diagnostic: (threads, particles in registers, observers, flags) of the fused kernel instantiation that took
-        the last fused step; flags bit 0 = fast arithmetic, bit 1 = the general instantiation."""
+        the last fused step; flags bit 0 = fast arithmetic, bit 1 = the general code, bit 2 = the compile-time contract."""
         out = np.zeros(4, dtype=np.int32)
         check(self.lib.glh_debug_last_variant(self.handle, _ptr(out)))
         return tuple(int(v) for v in out)

@@ -399,7 +399,7 @@ __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
 // surfaces only and carries none of the other code or its registers.
 // FAST: fast arithmetic (GLH_MATH_FAST, glh_math.h): fused multiply-adds, Newton reciprocals, table exp, and a
 // resampling that scans the raw weights and scales the positions instead of normalising (no NumPy-exact sum tree).
-template <int TB, int PPT, int MINW, int NOBS, bool SURF, bool FAST>
+template <int TB, int PPT, int MINW, int NOBS, bool SURF, bool FAST, bool CONTRACT>
 __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   constexpr int PT_WAVES = TB / WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // their first frame -- device Philox draws, every observer on and unmasked, compact input records, plain cameras --
   // so that none of those tests is a branch in its particle loops; the host (fused_step) sends every other case to the
   // general instantiation.
-  constexpr bool COMMON = FAST && !SURF;
+  static_assert(!CONTRACT || FAST, "the compile-time contract belongs to the fast arithmetic");
+  constexpr bool COMMON = CONTRACT;
   const int rng_mode = COMMON ? (int)GLH_RNG_PHILOX : a.rng_mode;
   PT_STAMP(0);
   if (tid == 0) {
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
           double u, v;
-          if constexpr (FAST && !SURF)
+          if constexpr (COMMON)
             project_simple_fast(s_cam[o], x[0], x[1], x[2], u, v);  // (the host sends other cameras to the general instantiation)
           else
             project_m<FAST>(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);

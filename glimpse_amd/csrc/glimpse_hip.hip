@@ -387,13 +387,14 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-#define GLH_PT_VARIANTS(SURF_, FAST_)                                                                             \
-  (const void*)k_point_step<512, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 0, 4, 2, SURF_, FAST_>,     \
-  (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_>,    \
-  (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_>,   \
-  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_>
-    for (const void* f : {GLH_PT_VARIANTS(false, false), GLH_PT_VARIANTS(true, false), GLH_PT_VARIANTS(false, true),
-                          GLH_PT_VARIANTS(true, true)}) {
+#define GLH_PT_VARIANTS(SURF_, FAST_, CON_)                                                                       \
+  (const void*)k_point_step<512, 0, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<512, 0, 4, 2, SURF_, FAST_, CON_>,   \
+  (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_, CON_>,  \
+  (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_, CON_>, \
+  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_, CON_>
+    for (const void* f : {GLH_PT_VARIANTS(false, false, false), GLH_PT_VARIANTS(true, false, false),
+                          GLH_PT_VARIANTS(false, true, true), GLH_PT_VARIANTS(true, true, false),
+                          GLH_PT_VARIANTS(true, true, true)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
@@ -1414,21 +1415,24 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     // ... and, in fast arithmetic, everything the common instantiation is not compiled for (glh_point.h: COMMON): it
     // takes device Philox draws, compact input records, every observer on and unmasked, and cameras within
     // perspective + radial numerator (project_simple_fast)
-    bool common = rng_mode == GLH_RNG_PHILOX && c->compact && !c->have_mask;
+    bool common = fast && rng_mode == GLH_RNG_PHILOX && c->compact && !c->have_mask;
     for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
+    // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
 #define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
   do {                                                                                                         \
     c->last_variant[0] = TB_; c->last_variant[1] = PPT_; c->last_variant[2] = NOBS_;                           \
-    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0);                                                      \
-    if (surf && fast)                                                                                          \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true>), grid, block, lds, c->stream, a);     \
+    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);                                   \
+    if (surf && common)                                                                                        \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true, true>), grid, block, lds, c->stream, a);   \
+    else if (surf && fast)                                                                                     \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true, false>), grid, block, lds, c->stream, a);  \
     else if (surf)                                                                                             \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, false>), grid, block, lds, c->stream, a);    \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, false, false>), grid, block, lds, c->stream, a); \
     else if (fast)                                                                                             \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, true>), grid, block, lds, c->stream, a);    \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, true, true>), grid, block, lds, c->stream, a);  \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, false>), grid, block, lds, c->stream, a);   \
+      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, false, false>), grid, block, lds, c->stream, a);\
   } while (0)
     if (!big) {
       if (O == 1) {

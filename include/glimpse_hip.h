@@ -282,7 +282,8 @@ int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
 /* Diagnostic: which instantiation of the fused kernel took the last fused glh_step / glh_track frame:
  * variant[0..3] = threads per workgroup, particles kept in registers per thread, observers, flags (bit 0: fast
- * arithmetic, bit 1: the general instantiation; flags == 1 is the common one bench.py times).  Zeros before any.  */
+ * arithmetic, bit 1: the general code (gridded surfaces, every motion model), bit 2: the compile-time contract of long
+ * device-RNG runs; flags == 5 is the common instantiation bench.py times).  Zeros before any.                    */
 int glh_debug_last_variant(glh_ctx* ctx, int32_t* variant);
 
 /* ---- results --------------------------------------------------------------------------- */

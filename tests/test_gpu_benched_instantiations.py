@@ -66,7 +66,7 @@ def test_benched_instantiation_matches_the_oracle(name, N):
 @pytest.mark.parametrize("name,P,N,variant", [("C3", 6, 5000, (512, 10, 1)), ("C4", 3, 10000, (1024, 10, 1)),
                                               ("C5", 4, 5000, (512, 0, 2)), ("C2", 8, 2000, (512, 4, 1))])
 def test_which_instantiation_takes_which_step(name, P, N, variant):
-    """bench.py's configurations in fast arithmetic run on the COMMON instantiation (flags == 1) from their second
+    """bench.py's configurations in fast arithmetic run on the COMMON instantiation (flags == 5: fast | contract) from their second
     frame on -- the one the fast parity tests (fused == staged bit for bit, fast vs exact to rounding:
     test_gpu_fast_math.py, test_gpu_fullsize.py) therefore exercise with the same Philox / compact-state runs; the
     first frame (expanded input), host-fed draws and a frame without an image go to the general instantiation, exact
@@ -80,7 +80,7 @@ def test_which_instantiation_takes_which_step(name, P, N, variant):
     with _lib.Context(P, N, wl.O, max_tile=31, max_search_dim=200, max_frames=T) as ctx:
         workloads.setup_context(ctx, wl, frames)
         assert ctx.last_variant() == (0, 0, 0, 0)
-        for math, flags_later in (("fast", 1), ("exact", 0)):
+        for math, flags_later in (("fast", 5), ("exact", 0)):
             ctx.set_math(math)
             ctx.set_frame(0)
             ctx.init_particles(seed=5)
@@ -97,5 +97,5 @@ def test_which_instantiation_takes_which_step(name, P, N, variant):
                 ctx.step(3, 1.0, [3] * wl.O, normals=rng.standard_normal((P, N, 3)), u=rng.random(P))
                 assert ctx.last_variant()[3] == 3  # host-fed draws
                 ctx.step(4, 1.0, [4] + [-1] * (wl.O - 1), seed=5)
-                assert ctx.last_variant()[3] == (3 if wl.O > 1 else 1)  # an observer without an image
+                assert ctx.last_variant()[3] == (3 if wl.O > 1 else 5)  # an observer without an image
         assert (ctx.point_status() == 0).all()
