@@ -232,10 +232,11 @@ class Context:
         self._frame_dtype[obs] = np.dtype(np.uint8)
 
     def observer_set_depth(self, obs, dtype):
-        """Sample type of the observer's frames: uint8 (default) or uint16; before the first upload."""
+        """Sample type of the observer's frames: uint8 (default), uint16, or float64 (one channel); before the first
+        upload."""
         dtype = np.dtype(dtype)
-        if dtype not in (np.dtype(np.uint8), np.dtype(np.uint16)):
-            raise TypeError(f"frames are uint8 or uint16 (got {dtype})")
+        if dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
+            raise TypeError(f"frames are uint8, uint16 or float64 (got {dtype})")
         check(self.lib.glh_observer_set_depth(self.handle, obs, 8 * dtype.itemsize))
         self._frame_dtype[obs] = dtype
 

@@ -27,8 +27,10 @@ struct ObsFrame {
   const uint8_t* frame;  // uint8 [H][W][C], or uint16 [H][W][C] when bits == 16
   int32_t on;            // images[o] >= 0
   int32_t width, height, channels;
-  int32_t bits;          // 8 or 16 (glh_observer_set_depth)
+  int32_t bits;          // 8 or 16 (unsigned integer samples) or 64 (float64 samples, one channel): glh_observer_set_depth
   uint32_t* bins;        // 16-bit frames: [P][bins16_count(channels)] zeroed key histogram workspace (staged kernels)
+  double* fwork;         // float64 frames: [P][fwork_cap] workspace (normalised / matched values of a tile)
+  int64_t fwork_cap;
 };
 
 // Division of small non-negative integers by a divisor that is the same for the whole workgroup: n / d as
@@ -891,6 +893,121 @@ __device__ void search_tile_from_box16(const uint8_t* frame, int width, int chan
 }
 
 // ------------------------------------------------------------------------------------------
+// Float64 frames (one channel): Tracker.extract_tile works on any dtype (tracker.py:522-534).  The values of a
+// tile are arbitrary doubles, so np.unique is not a histogram over keys: what the reference needs from it is, per
+// pixel, the number of pixels at or below its (normalised) value -- cumsum(counts)[inverse] -- and, for a template,
+// the sorted distinct values.  Both come from counting over the tile (every thread runs over all pixels; they all
+// read the same element at a time: a broadcast), O(n^2 / BLK) per thread: a functional path for modest tiles, staged
+// kernels only.  The median high-pass runs on the values themselves (the CDF match is monotone: the median of the
+// matched window is the matched median).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pixel_f64(const uint8_t* frame, int width, int row, int col) {
+  return reinterpret_cast<const double*>(frame)[(size_t)row * width + col];
+}
+// scipy.ndimage.median_filter(size = (2 ry + 1, 2 rx + 1), mode = 'reflect') of a w x h array of doubles at (r, c)
+__device__ __forceinline__ double median_window_f64(const double* a, int w, int h, int r, int c, int rx, int ry) {
+  double v[49];
+  const int nx = 2 * rx + 1, n = nx * (2 * ry + 1);
+  for (int dr = -ry; dr <= ry; ++dr) {
+    const double* row = a + (size_t)reflect_index(r + dr, h) * w;
+    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = row[reflect_index(c + dc, w)];
+  }
+  const int need = (n + 1) / 2;  // the smallest element with at least half the window at or below it
+  double best = INFINITY;
+  for (int i = 0; i < n; ++i) {
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) cnt += v[j] <= v[i];
+    if (cnt >= need && v[i] < best) best = v[i];
+  }
+  return best;
+}
+// normalize (helpers.py:344) of the box into y[n]: (a - a.mean()) * (1 / a.std()); all threads; ends with a barrier
+__device__ __forceinline__ void normalize_box_f64(const uint8_t* frame, int width, const int* box, double* y, double* red,
+                                                  bool* const_tile) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  double sx = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const int r = idx / w, c = idx - r * w;
+    const double x = pixel_f64(frame, width, box[1] + r, box[0] + c);
+    y[idx] = x;
+    sx += x;
+  }
+  const double mean = block_sum(sx, red) / (double)n;
+  double sq = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double d = y[idx] - mean;
+    sq += d * d;
+  }
+  const double var = block_sum(sq, red) / (double)n;
+  const double inv_std = 1.0 / sqrt(var);
+  if (tid == 0 && const_tile) *const_tile = !(var > 0.0);
+  for (int idx = tid; idx < n; idx += BLK) y[idx] = (y[idx] - mean) * inv_std;
+  __syncthreads();
+}
+
+// template: y [n] and cnt [n] (uint32) in shared memory (n = tw * th)
+__device__ void template_from_boxf(const uint8_t* frame, int width, const int* box, double* y, uint32_t* cnt,
+                                   double* red, TemplateOut out, bool* const_tile, int hp_rx, int hp_ry) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  normalize_box_f64(frame, width, box, y, red, const_tile);
+  // pass 1: pixels at or below this one (the cumulative count of its value), and whether an equal one precedes it
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double yi = y[idx];
+    uint32_t leq = 0, eq_before = 0;
+    for (int j = 0; j < n; ++j) {
+      const double yj = y[j];
+      leq += yj <= yi;
+      eq_before += (j < idx) & (yj == yi);
+    }
+    cnt[idx] = (leq << 1) | (eq_before == 0 ? 1u : 0u);  // (n < 2^31)
+  }
+  __syncthreads();
+  // pass 2: the first occurrence of every distinct value takes its place in the sorted unique arrays
+  double firsts = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    if (!(cnt[idx] & 1u)) continue;
+    const double yi = y[idx];
+    uint32_t rank = 0;
+    for (int j = 0; j < n; ++j) rank += (cnt[j] & 1u) & (uint32_t)(y[j] < yi);
+    out.hist_v[rank] = yi;
+    out.hist_q[rank] = (double)(cnt[idx] >> 1) / (double)n;
+    firsts += 1.0;
+  }
+  const double total = block_sum(firsts, red);
+  if (tid == 0) *out.hist_n = (int)total;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const int r = idx / w, c = idx - r * w;
+    const double t = y[idx] - median_window_f64(y, w, h, r, c, hp_rx, hp_ry);
+    out.tile64[idx] = t;
+    out.tile32[idx] = (float)t;
+  }
+}
+
+// search tile: work [2 n] doubles of memory (the normalised values, behind them the matched ones); the template CDF
+__device__ void search_tile_from_boxf(const uint8_t* frame, int width, const int* box, const double* hist_v,
+                                      const double* hist_q, int hist_n, double* work, double* red, float* out, int hp_rx,
+                                      int hp_ry) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  normalize_box_f64(frame, width, box, work, red, nullptr);
+  // helpers.match_cdf: quantile of every pixel = (pixels at or below it) / size, through np.interp of the template CDF
+  double* matched = work + n;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double yi = work[idx];
+    uint32_t leq = 0;
+    for (int j = 0; j < n; ++j) leq += work[j] <= yi;
+    matched[idx] = np_interp((double)leq / (double)n, hist_q, hist_v, hist_n);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += BLK) {
+    const int r = idx / w, c = idx - r * w;
+    out[idx] = (float)(matched[idx] - median_window_f64(matched, w, h, r, c, hp_rx, hp_ry));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2a  Tracker.initialize_template (tracker.py:536-561) for one observer, one block per point
 // ------------------------------------------------------------------------------------------
 struct TemplateArgs {
@@ -949,7 +1066,10 @@ __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
   out.hist_v = a.tmpl_hist_v + slot * a.tile_cap;
   out.hist_q = a.tmpl_hist_q + slot * a.tile_cap;
   out.hist_n = a.tmpl_hist_n + slot;
-  if (a.obs.bits == 16)
+  if (a.obs.bits == 64)
+    template_from_boxf(a.obs.frame, a.obs.width, s_box, reinterpret_cast<double*>(smem),
+                       reinterpret_cast<uint32_t*>(smem + (size_t)a.tw * a.th * 8), red, out, &s_const, a.hp_rx, a.hp_ry);
+  else if (a.obs.bits == 16)
     template_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, reinterpret_cast<uint32_t*>(smem),
                         a.obs.bins + (size_t)pt * bins16_count(a.obs.channels), hist, red, out, &s_const, a.hp_rx,
                         a.hp_ry);
@@ -1164,7 +1284,11 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   }
   __syncthreads();
   if (s_status != GLH_OBS_OK) return;
-  if (a.obs.bits == 16)
+  if (a.obs.bits == 64)
+    search_tile_from_boxf(a.obs.frame, a.obs.width, s_box, a.tmpl_hist_v + slot * a.tile_cap,
+                          a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot], a.obs.fwork + (size_t)pt * a.obs.fwork_cap,
+                          &red[0][0], a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
+  else if (a.obs.bits == 16)
     search_tile_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, a.tmpl_hist_v + slot * a.tile_cap,
                            a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot],
                            a.obs.bins + (size_t)pt * bins16_count(a.obs.channels), reinterpret_cast<uint32_t*>(smem),

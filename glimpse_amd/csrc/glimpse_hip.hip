@@ -135,6 +135,7 @@ struct glh_ctx {
   bool compact = false;  // particles[cur] / weights[cur] are run-length compact (left by the fused step)
   int32_t* resid_draws = nullptr;  // [P] uniforms consumed by the last residual resampling
   uint32_t* bins16 = nullptr;   // [P][65535 * 3 + 1] key histograms of 16-bit frames (staged tile kernels), on first use
+  double* fwork = nullptr;      // [P][2 D^2] tile workspace of float64 frames (staged tile kernels), on first use
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
@@ -265,7 +266,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status_all); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->fwork); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
@@ -468,9 +469,12 @@ extern "C" int glh_observer_init(glh_ctx* c, int o, int n_images, int width, int
 
 extern "C" int glh_observer_set_depth(glh_ctx* c, int o, int bits) {
   CHK(check_obs(c, o));
-  if (bits != 8 && bits != 16) return fail(GLH_E_UNSUPPORTED, "frames are 8 or 16 bits per sample (got %d)", bits);
+  if (bits != 8 && bits != 16 && bits != 64)
+    return fail(GLH_E_UNSUPPORTED, "frames are 8 or 16 bits per sample, or 64 = float64 samples (got %d)", bits);
   Observer& ob = c->obs[o];
   if (ob.n_images <= 0) return fail(GLH_E_STATE, "glh_observer_init first");
+  if (bits == 64 && ob.channels != 1)
+    return fail(GLH_E_UNSUPPORTED, "float64 frames have one channel (observer %d has %d)", o, ob.channels);
   for (auto& p : ob.owned)
     if (p) return fail(GLH_E_STATE, "observer %d: set the depth before uploading frames", o);
   ob.bits = bits;
@@ -917,10 +921,14 @@ static void fill_obs(glh_ctx* c, int o, int image, ObsFrame* f) {
   f->channels = ob.channels;
   f->bits = ob.bits;
   f->bins = c->bins16;
+  f->fwork = c->fwork;
+  f->fwork_cap = 2 * (int64_t)c->cfg.max_search_dim * c->cfg.max_search_dim;
 }
 
 // 16-bit frames: the zeroed per-point key histograms the staged tile kernels of observer `o` count into
 static int prepare_bins16(glh_ctx* c, int o) {
+  if (c->obs[o].bits == 64 && !c->fwork)  // float64 frames: two tile-sized arrays of doubles per point
+    CHK(dalloc(&c->fwork, (size_t)c->cfg.max_points * 2 * c->cfg.max_search_dim * c->cfg.max_search_dim));
   if (c->obs[o].bits != 16) return GLH_OK;
   const size_t per = (size_t)(65535 * 3 + 1);
   if (!c->bins16) CHK(dalloc(&c->bins16, (size_t)c->cfg.max_points * per));
@@ -1043,10 +1051,11 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   a.pt_err_frame = c->pt_err_frame;
   CHK(prepare_bins16(c, o));
   a.obs.bins = c->bins16;
+  a.obs.fwork = c->fwork;
   {
     StageTimer t(c, ST_TEMPLATE);
-    hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK), (size_t)c->tw * c->th * (ob.bits == 16 ? 4 : 2),
-                       c->stream, a);
+    hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK),
+                       (size_t)c->tw * c->th * (ob.bits == 64 ? 12 : (ob.bits == 16 ? 4 : 2)), c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return GLH_OK;
@@ -1087,6 +1096,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.search = c->search;
     CHK(prepare_bins16(c, o));
     tp.obs.bins = c->bins16;
+    tp.obs.fwork = c->fwork;
     {
       StageTimer t(c, ST_TILEPREP);
       size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * (c->obs[o].bits == 16 ? 4 : 2);  // (halo of up to 3 rows)

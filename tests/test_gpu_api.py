@@ -596,3 +596,43 @@ def test_tracker_extract_tile_matches_reference(golden, name):
         np.testing.assert_allclose(search, g[f"{name}_{b}_search"], rtol=0, atol=2e-6)  # float32 search tile
     with pytest.raises(NotImplementedError):
         tracker.extract_tile(0, 1, sbox, histogram=(hv, hq), return_histogram=True)
+
+
+def test_tracking_on_float64_frames_reproduces_reference(golden):
+    """One-channel float64 frames (Tracker.extract_tile works on any dtype, tracker.py:494-534; the distinct values of
+    a tile by counting instead of a key histogram): whole tracks against the reference run with the same np.random
+    seed, and the last track's template (tile, histogram -- one value of the 225 repeats, box)."""
+    from tests.test_oracle_golden import float64_scene
+
+    g = golden("g20_float64.npz")
+    cam_vec, frames = float64_scene()
+    assert frames[0].dtype == np.float64
+    cam = camera_from(cam_vec)
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(frames)]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in g["xy"]]
+    np.random.seed(43)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
+    tpl = tracker._ctx.get_template(0, len(models) - 1)
+    np.testing.assert_array_equal(tpl["box"], g["tpl_box"])
+    assert len(tpl["histogram"][0]) == len(g["tpl_hist_v"]) < tpl["tile"].size  # (a repeated value is merged)
+    np.testing.assert_array_equal(tpl["histogram"][1], g["tpl_hist_q"])
+    np.testing.assert_allclose(tpl["histogram"][0], g["tpl_hist_v"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(tpl["tile"], g["tpl_tile"], rtol=1e-11, atol=1e-12)
+    # the device RNG runs on the same (staged) kernels
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = tracker.track(models, tile_size=(15, 15), rng="philox", seed=3)
+    assert np.isfinite(tr.means).all() and np.all(np.abs(tr.means[:, -1, 3] - 0.15) < 0.06)
+    # RGB float frames are refused (their channel mean has dtype-dependent rounding in the reference)
+    rgb = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=np.stack([f, f, f], axis=2))
+           for i, f in enumerate(frames)]
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(rgb, sigma=0.3)]).track(models, tile_size=(15, 15))

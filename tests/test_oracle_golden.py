@@ -379,3 +379,40 @@ def test_oracle_on_uint16_frames(golden, name, channels):
     res = otracker.track(models, observers, np.arange(5)[:, None], np.ones(4), tile_size=(15, 15))
     np.testing.assert_allclose(res["means"], g[f"{name}_means"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(res["sigmas"], g[f"{name}_sigmas"], rtol=1e-9, atol=1e-10)
+
+
+def float64_scene():
+    """The float64 scene of g20 (tools/make_golden.py: scene64)."""
+    from glimpse_amd import synth
+
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    scene = synth.default_scene(cam, seed=12, velocity=(0.15, 0.0), n_frames=5)
+    frames = [np.power(scene.render(cam, float(t), channels=1, bits=16).astype(np.float64) / 65535.0, 0.8) * 3.5 - 1.25
+              for t in range(5)]
+    return cam, frames
+
+
+def test_oracle_on_float64_frames(golden):
+    """float64 frames (tracker.py:494-534 works on any dtype): the oracle's tiles for explicit boxes and its
+    whole-track loop on np.random against the reference run with the same seed (g20)."""
+    from oracle import motion as omotion
+    from oracle import tiles as otiles
+    from oracle import tracker as otracker
+
+    g = golden("g20_float64.npz")
+    cam, frames = float64_scene()
+    assert abs(sum(float(f.sum()) for f in frames) - float(g["checksum"])) < 1e-6 * abs(float(g["checksum"]))
+    tile, hist = otiles.extract_tile(frames[0], g["tbox"], return_histogram=True)
+    np.testing.assert_allclose(tile, g["tile"], rtol=1e-13, atol=1e-14)
+    np.testing.assert_array_equal(hist[1], g["hist_q"])
+    np.testing.assert_allclose(hist[0], g["hist_v"], rtol=1e-13, atol=1e-14)
+    search = otiles.extract_tile(frames[1], g["sbox"], histogram=hist)
+    np.testing.assert_allclose(search, g["search"], rtol=1e-13, atol=1e-14)
+    observers = [otracker.Observer(frames, np.tile(cam, (5, 1)), 0.3)]
+    models = [omotion.CartesianMotion(xy=xy, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0),
+                                      axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0), dem=0.0, dem_sigma=0.0, n=200)
+              for xy in g["xy"]]
+    np.random.seed(43)
+    res = otracker.track(models, observers, np.arange(5)[:, None], np.ones(4), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g["means"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["sigmas"], g["sigmas"], rtol=1e-9, atol=1e-10)

@@ -953,7 +953,50 @@ def g19_observer_helpers():
     print("g19 splits", out["split_3_1"].tolist(), out["split_4_0"].tolist(), out["split_breaks"].tolist())
 
 
+def scene64():
+    """The float64 scene of g20: the 16-bit gray scene mapped to reflectance-like doubles (a gamma curve: almost every
+    pixel of a tile is a distinct value -- with a few exact repeats from the 16-bit source, which np.unique merges)."""
+    cam, frames16 = scene16(1)
+    frames = [np.power(f.astype(np.float64) / 65535.0, 0.8) * 3.5 - 1.25 for f in frames16]
+    return cam, frames
+
+
+def g20_float64():
+    """float64 frames (Tracker.extract_tile works on any dtype, tracker.py:494-534): whole tracks, the last track's
+    template, and the reference's own tiles for explicit boxes (template + histogram, search tile)."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam, frames = scene64()
+    assert frames[0].dtype == np.float64 and frames[0].ndim == 2
+    pts = synth.grid_points(cam, 3, border_px=70.0, seed=3)
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(len(frames))]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+    models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                      vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                      axyz_sigma=(0.05, 0.05, 0.0)) for xy in pts]
+    np.random.seed(43)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    tpl = tracker.templates[0]
+    out = {"means": tracks.means, "sigmas": tracks.sigmas, "xy": pts,
+           "checksum": np.float64(sum(float(f.sum()) for f in frames)),
+           "tpl_tile": tpl["tile"], "tpl_hist_v": tpl["histogram"][0], "tpl_hist_q": tpl["histogram"][1],
+           "tpl_box": np.asarray(tpl["box"])}
+    bt, bs = np.array((100, 90, 115, 105)), np.array((92, 80, 126, 117))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tile, hist = tracker.extract_tile(obs=0, img=0, box=bt, return_histogram=True)
+        search = tracker.extract_tile(obs=0, img=1, box=bs, histogram=hist)
+    out.update({"tbox": bt, "sbox": bs, "tile": tile, "hist_v": hist[0], "hist_q": hist[1], "search": search})
+    print("g20 vx:", tracks.means[:, -1, 3], "distinct template values:", len(tpl["histogram"][0]), "of", tpl["tile"].size)
+    np.savez_compressed(os.path.join(OUT, "g20_float64.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g20" in sys.argv:
+        g20_float64()
+        sys.exit(0)
     if "--g19" in sys.argv:
         g19_observer_helpers()
         sys.exit(0)
@@ -1006,5 +1049,6 @@ if __name__ == "__main__":
     g17_highpass()
     g18_uint16()
     g19_observer_helpers()
+    g20_float64()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
