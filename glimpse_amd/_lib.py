@@ -100,6 +100,7 @@ SIGNATURES = {
     "glh_set_fused": (_I, [_P, _I]),
     "glh_set_math": (_I, [_P, _I]),
     "glh_set_highpass": (_I, [_P, _I, _I]),
+    "glh_set_interpolation": (_I, [_P, _I, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_debug_last_variant": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
@@ -230,6 +231,10 @@ class Context:
         check(self.lib.glh_observer_init(self.handle, obs, n_images, width, height, channels, float(sigma)))
         self._frame_shape[obs] = (int(height), int(width), int(channels))
         self._frame_dtype[obs] = np.dtype(np.uint8)
+
+    def set_interpolation(self, kx=3, ky=3):
+        """Orders of the surface-sampling spline: (3, 3) (default) or (1, 1)."""
+        check(self.lib.glh_set_interpolation(self.handle, int(kx), int(ky)))
 
     def observer_set_depth(self, obs, dtype):
         """Sample type of the observer's frames: uint8 (default), uint16, or float64 (one channel); before the first

@@ -1217,6 +1217,7 @@ struct TilePrepArgs {
   ObsFrame obs;
   int32_t o, O, P, NB, tw, th, tile_cap, search_cap, max_dim;
   int32_t hp_rx, hp_ry;     // half sizes of the median high-pass window
+  int32_t kcols, krows;     // interpolation orders that set the least surface size (search_box)
   const double* bbox_part;  // [O][P][NB][5]
   const int32_t* tmpl_valid;
   const double* tmpl_hist_v;
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
     }
     int st = GLH_OBS_OK;
     if (search_box(mnu, mnv, mxu, mxv, nanf != 0.0, a.tw, a.th, a.obs.cam->imgsz[0],
-                   a.obs.cam->imgsz[1], s_box))
+                   a.obs.cam->imgsz[1], s_box, a.kcols, a.krows))
       st = GLH_OBS_OUT_OF_BOUNDS;
     else if (s_box[2] > a.obs.width || s_box[3] > a.obs.height)
       st = GLH_OBS_OUT_OF_BOUNDS;
@@ -1499,6 +1500,7 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
 // ------------------------------------------------------------------------------------------
 struct SplineFitArgs {
   int32_t o, P, tw, th, sse_cap, max_n;
+  int32_t linear, reserved;  // linear: interpolation order 1 -- the surface values are the coefficients, nothing to fit
   const int32_t* box;
   const int32_t* obs_status;
   const double* lu;          // packed factors: for n, 5 arrays of n at lu_off[n]
@@ -1571,6 +1573,7 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
     for (int idx = tid; idx < wo * ho; idx += BLK) cp[idx] = z[idx];
     __syncthreads();
   }
+  if (a.linear) return;
   if (spline_dense(ho, wo)) {
     __shared__ double z1[GLH_SPL_DENSE_NINV / 2];  // ho * wo <= (ho^2 + wo^2) / 2
     spline_fit_dense<BLK>(z, z1, wo, ho, a.inv + spline_inverse_off(ho), a.inv + spline_inverse_off(wo));
@@ -1609,6 +1612,7 @@ struct WeightArgs {
   int32_t N, P, O, tw, th, sse_cap, frame;
   int32_t fast;  // GLH_MATH_FAST
   int32_t cell_cap;  // fast: surfaces of up to this many cells are evaluated in per-cell form (the fused kernel's bound)
+  int32_t linear;    // Tracker(interpolation={"kx": 1, "ky": 1}): `coef` is the surface itself, sampled bilinearly
   Surfaces surf;
 };
 
@@ -1667,8 +1671,9 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double* coef = a.coef + slot * (size_t)a.sse_cap;
       // fast arithmetic: surfaces the fused kernel holds in per-cell form are evaluated by that formula here too
-      const bool by_cell = a.fast && spline_cells(ho) * spline_cells(wo) <= a.cell_cap;
-      double val = by_cell  ? spline_eval_cell_direct(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+      const bool by_cell = !a.linear && a.fast && spline_cells(ho) * spline_cells(wo) <= a.cell_cap;
+      double val = a.linear ? spline_eval_linear(coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+                   : by_cell ? spline_eval_cell_direct(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
                    : a.fast ? spline_eval_poly_fast(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
                             : spline_eval_poly(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y);
       if (a.ll_out) a.ll_out[slot * a.N + i] = val * a.inv2s2[o];

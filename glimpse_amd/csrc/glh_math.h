@@ -388,18 +388,20 @@ GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double 
 }
 
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is
-// inside the image (Camera.inframe, camera.py:700-718), 1 otherwise.  kx = ky = 3.
+// inside the image (Camera.inframe, camera.py:700-718), 1 otherwise.  `kcols` / `krows`: the interpolation orders
+// that set the least surface size (tracker.py:585-590: "ky" widens the columns, "kx" the rows); 3 unless
+// Tracker(interpolation=...) says otherwise.
 GLH_HD int search_box(double minu, double minv, double maxu, double maxv, int has_nan, int tw,
-                      int th, double imgw, double imgh, int* box) {
+                      int th, double imgw, double imgh, int* box, int kcols = 3, int krows = 3) {
   if (has_nan) return 1;  // NaN min/max -> garbage ints -> out of bounds (tracker.py:597)
   double lo_u = minu - tw * 0.5, hi_u = maxu + tw * 0.5;
   double lo_v = minv - th * 0.5, hi_v = maxv + th * 0.5;
-  double ncols = 3.0 - ((hi_u - lo_u) - tw);
+  double ncols = (double)kcols - ((hi_u - lo_u) - tw);
   if (ncols > 0.0) {
     lo_u += -ncols * 0.5;
     hi_u += ncols * 0.5;
   }
-  double nrows = 3.0 - ((hi_v - lo_v) - th);
+  double nrows = (double)krows - ((hi_v - lo_v) - th);
   if (nrows > 0.0) {
     lo_v += -nrows * 0.5;
     hi_v += nrows * 0.5;
@@ -717,6 +719,26 @@ GLH_HD double weight_of(double ll, const double* tab32) {
     return exp_fast(x < -746.0 ? -800.0 : x, tab32) + 1e-300;
   }
   return exp(-ll) + 1e-300;
+}
+
+// RectBivariateSpline(kx = ky = 1, s = 0) (Tracker(interpolation={"kx": 1, "ky": 1}), tracker.py:60, :623): the
+// degree-1 B-spline through the surface values, i.e. their bilinear interpolant; arguments clamped like fpbisp's;
+// the two non-zero basis functions on the unit knot interval [i, i + 1] are (i + 1 - x) and (x - i) (fpbspl).
+GLH_HD double spline_eval_linear(const double* z, int ld, int ho, int wo, double cv0, double cu0, double u, double v) {
+  double vl = v - cv0, ul = u - cu0;
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  vl = vl < 0.0 ? 0.0 : (vl > vmax ? vmax : vl);
+  ul = ul < 0.0 ? 0.0 : (ul > umax ? umax : ul);
+  int iv = (int)floor(vl), iu = (int)floor(ul);
+  if (iv > ho - 2) iv = ho - 2;
+  if (iu > wo - 2) iu = wo - 2;
+  const double hv[2] = {(double)(iv + 1) - vl, vl - (double)iv}, hu[2] = {(double)(iu + 1) - ul, ul - (double)iu};
+  double sp = 0.0;
+  for (int i = 0; i < 2; ++i) {
+    const double* row = z + (size_t)(iv + i) * ld + iu;
+    for (int j = 0; j < 2; ++j) sp += row[j] * hv[i] * hu[j];
+  }
+  return sp;
 }
 
 // Evaluate the tensor spline with coefficients coef[ho][wo] (row stride ld) at (u, v);

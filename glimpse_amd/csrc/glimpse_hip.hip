@@ -146,6 +146,7 @@ struct glh_ctx {
   int32_t *leaf_off = nullptr, *leaf_len = nullptr, *sum_ops = nullptr, *level_off = nullptr, *roots = nullptr;
   int nleaves = 0, nnodes = 0, nlevels = 0, nroots = 0;
   int moments_frame = -1;  // history slot already filled by the fused resample kernel
+  int interp_k = 3;  // interpolation order of the surface sampling: 3 (bicubic, the default) or 1 (glh_set_interpolation)
   int32_t last_variant[4] = {0, 0, 0, 0};  // fused kernel instantiation of the last step: TB, PPT, NOBS, fast | general << 1
   size_t normals_cap = 0;
   // profiling
@@ -1086,6 +1087,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.max_dim = c->cfg.max_search_dim;
     tp.hp_rx = c->hp_rx;
     tp.hp_ry = c->hp_ry;
+    tp.kcols = tp.krows = c->interp_k;
     tp.bbox_part = c->bbox_part;
     tp.tmpl_valid = c->tmpl_valid;
     tp.tmpl_hist_v = c->tmpl_hist_v;
@@ -1135,6 +1137,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     sf.inv = c->spl_inv;
     sf.sse = c->sse;
     sf.sse_copy = c->keep_sse ? c->sse_copy : nullptr;
+    sf.linear = c->interp_k == 1;
     {
       StageTimer t(c, ST_SPLINE_FIT);
       hipLaunchKernelGGL(k_spline_fit, dim3(c->P), dim3(BLK), 0, c->stream, sf);
@@ -1180,6 +1183,7 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.frame = c->frame;
   wa.fast = use_fast(c);
   wa.cell_cap = cell_cap(c);
+  wa.linear = c->interp_k == 1;
   wa.surf = surfaces(c);
   {
     StageTimer t(c, ST_WEIGHTS);
@@ -1289,6 +1293,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
   if (c->hp_rx != 2 || c->hp_ry != 2) return false;  // the fused kernel's median network is the 5 x 5 default
+  if (c->interp_k != 3) return false;                // ... and its sampling the bicubic default
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {
@@ -1609,6 +1614,14 @@ extern "C" int glh_set_highpass(glh_ctx* c, int size_x, int size_y) {
     return fail(GLH_E_UNSUPPORTED, "high-pass window %d x %d: sizes must be odd and at most 7", size_x, size_y);
   c->hp_rx = size_x / 2;
   c->hp_ry = size_y / 2;
+  return GLH_OK;
+}
+
+extern "C" int glh_set_interpolation(glh_ctx* c, int kx, int ky) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (!((kx == 3 && ky == 3) || (kx == 1 && ky == 1)))
+    return fail(GLH_E_UNSUPPORTED, "interpolation orders (%d, %d): bicubic (3, 3) or bilinear (1, 1)", kx, ky);
+  c->interp_k = kx;
   return GLH_OK;
 }
 

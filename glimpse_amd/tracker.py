@@ -56,7 +56,8 @@ def _vector24(img):
 def _parallel_worker(job):
     """One worker process of Tracker.track(parallel=N): its own Tracker / context on its GPU, its block of tracks."""
     tracker = Tracker(job["observers"], viewshed=job["viewshed"], resample_method=job["resample_method"],
-                      highpass=job["highpass"], device=job["device"], max_search_dim=job["max_search_dim"])
+                      highpass=job["highpass"], interpolation=job["interpolation"], device=job["device"],
+                      max_search_dim=job["max_search_dim"])
     if job["np_seed"] is not None:
         np.random.seed(int(job["np_seed"]))
     t = tracker.track(job["models"], _catch_errors=job["catch"], **job["kw"])
@@ -88,8 +89,11 @@ class Tracker:
             raise NotImplementedError("the high-pass filter is a median with odd size up to (7, 7): "
                                       f"highpass={highpass!r}")
         self._highpass_size = size
-        if interpolation.get("kx", 3) != 3 or interpolation.get("ky", 3) != 3:
-            raise NotImplementedError("sub-pixel interpolation is the reference default: bicubic (kx = ky = 3)")
+        orders = (int(interpolation.get("kx", 3)), int(interpolation.get("ky", 3)))
+        if orders not in ((3, 3), (1, 1)) or set(interpolation) - {"kx", "ky"}:
+            raise NotImplementedError("sub-pixel interpolation: bicubic (kx = ky = 3, the reference default) or bilinear "
+                                      f"(kx = ky = 1), not {interpolation}")
+        self._orders = orders
         self.viewshed = viewshed
         self.resample_method = resample_method
         self.highpass = highpass
@@ -177,6 +181,7 @@ class Tracker:
             ctx.observer_set_depth(o, first.dtype)
             ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
         ctx.set_highpass(self._highpass_size)
+        ctx.set_interpolation(*self._orders)
         self._ctx, self._ctx_key = ctx, key
         self._uploaded = set()
         return ctx
@@ -488,7 +493,7 @@ class Tracker:
             if a == b:
                 continue
             jobs.append(dict(observers=self.observers, viewshed=self.viewshed, resample_method=self.resample_method,
-                             highpass=self.highpass, device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
+                             highpass=self.highpass, interpolation=self.interpolation, device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
                              np_seed=seeds[w], catch=ntracks >= 2,
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
@@ -675,6 +680,7 @@ class Tracker:
             ctx.begin_sequence(1, n, tile)
             ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
             ctx.set_highpass(self._highpass_size)
+            ctx.set_interpolation(*self._orders)
             self._sctx, self._sctx_key, self._single_tile, self._s_uploaded = ctx, key, tuple(tile), set()
         return self._sctx
 

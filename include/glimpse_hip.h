@@ -277,6 +277,11 @@ int glh_set_math(glh_ctx* ctx, int mode);
  * :530: scipy.ndimage.median_filter): odd sizes up to 7; 5 x 5 (the reference default) unless set.  Other sizes run on
  * the staged kernels.                                                                                           */
 int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
+/* Orders of the spline that samples the SSD surface at the particles (Tracker(interpolation={"kx": .., "ky": ..}),
+ * tracker.py:60, :585-590, :623: scipy RectBivariateSpline(kx, ky), s = 0): (3, 3), the reference default, or (1, 1)
+ * -- bilinear; the order also sets the least size of the surface (the search box is widened to order + 1 cells).
+ * Other orders: GLH_E_UNSUPPORTED.  (1, 1) runs on the staged kernels.                                            */
+int glh_set_interpolation(glh_ctx* ctx, int kx, int ky);
 
 /* Diagnostic: s_memtime stamps [P][20] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */

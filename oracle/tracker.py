@@ -22,8 +22,9 @@ from . import camera, resample, spline, ssd, tiles
 
 
 class Observer(dict):
-    def __init__(self, frames, cams, sigma=0.3):
-        super().__init__(frames=list(frames), cams=np.asarray(cams, dtype=float), sigma=sigma)
+    def __init__(self, frames, cams, sigma=0.3, interp=(3, 3)):
+        """`interp` = (kx, ky) of Tracker(interpolation=...) (tracker.py:60, :585-590, :623)."""
+        super().__init__(frames=list(frames), cams=np.asarray(cams, dtype=float), sigma=sigma, interp=tuple(interp))
 
 
 def observer_log_likelihoods(obs, img, template, particles, trace=None):
@@ -35,7 +36,8 @@ def observer_log_likelihoods(obs, img, template, particles, trace=None):
     size = np.asarray(template["tile"].shape[0:2][::-1])
     uv = camera.xyz_to_uv(cam, particles[:, 0:3])
     halfsize = size * 0.5
-    box = tiles.search_box(uv, size)
+    kx, ky = obs.get("interp", (3, 3))
+    box = tiles.search_box(uv, size, kx=kx, ky=ky)
     if trace is not None:
         trace["uv"] = uv
         trace["box"] = box.ravel().copy()
@@ -51,7 +53,7 @@ def observer_log_likelihoods(obs, img, template, particles, trace=None):
     box_edge = halfsize - 0.5
     sse_box = box + np.concatenate((box_edge, -box_edge))
     sse_box += np.tile(template["duv"], 2)
-    sampled = spline.sample_tile(uv, sse, sse_box)
+    sampled = spline.sample_tile(uv, sse, sse_box, kx=kx, ky=ky)
     if trace is not None:
         trace["search_tile"] = search_tile
         trace["sse"] = sse

@@ -636,3 +636,33 @@ def test_tracking_on_float64_frames_reproduces_reference(golden):
            for i, f in enumerate(frames)]
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(rgb, sigma=0.3)]).track(models, tile_size=(15, 15))
+
+
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_tracking_with_bilinear_interpolation_reproduces_reference(golden, tag):
+    """Tracker(interpolation={"kx": 1, "ky": 1}) (tracker.py:60, :585-590, :623: a degree-1 RectBivariateSpline over
+    the SSD surface, the search box widened to 2 cells only) against the reference run with the same np.random seed."""
+    g = golden("g21_bilinear.npz")
+    scene = golden("g15_ragged.npz")
+    cam = camera_from(scene["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f)
+              for i, f in enumerate(scene["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], interpolation={"kx": 1, "ky": 1},
+                                  max_search_dim=128)
+    wide = tag == "wide"
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200,
+                                          xy_sigma=(0.2, 0.2) if wide else (0.004, 0.004), vxyz=(0.15, 0, 0),
+                                          vxyz_sigma=(0.2, 0.2, 0.0) if wide else (0.002, 0.002, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0) if wide else (0.0005, 0.0005, 0.0))
+              for xy in g["xy"]]
+    np.random.seed(47)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g[f"{tag}_means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"{tag}_sigmas"], rtol=RTOL, atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 1})
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 3, "s": 0.1})

@@ -416,3 +416,24 @@ def test_oracle_on_float64_frames(golden):
     res = otracker.track(models, observers, np.arange(5)[:, None], np.ones(4), tile_size=(15, 15))
     np.testing.assert_allclose(res["means"], g["means"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(res["sigmas"], g["sigmas"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_oracle_with_bilinear_interpolation(golden, tag):
+    """Tracker(interpolation={"kx": 1, "ky": 1}) (tracker.py:60, :585-590, :623): the oracle's whole-track loop against
+    the reference run with the same seed (g21; `tight`: clouds narrower than a pixel, 2 x 2 surfaces)."""
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    g = golden("g21_bilinear.npz")
+    scene = golden("g15_ragged.npz")
+    observers = [otracker.Observer(list(scene["frames"]), np.tile(scene["cam"], (6, 1)), 0.3, interp=(1, 1))]
+    wide = tag == "wide"
+    models = [omotion.CartesianMotion(xy=xy, xy_sigma=(0.2, 0.2) if wide else (0.004, 0.004), vxyz=(0.15, 0, 0),
+                                      vxyz_sigma=(0.2, 0.2, 0.0) if wide else (0.002, 0.002, 0.0), axyz=(0, 0, 0),
+                                      axyz_sigma=(0.05, 0.05, 0.0) if wide else (0.0005, 0.0005, 0.0), dem=0.0,
+                                      dem_sigma=0.0, n=200) for xy in g["xy"]]
+    np.random.seed(47)
+    res = otracker.track(models, observers, np.arange(6)[:, None], np.ones(5), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g[f"{tag}_means"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["sigmas"], g[f"{tag}_sigmas"], rtol=1e-9, atol=1e-10)

@@ -993,7 +993,38 @@ def g20_float64():
     np.savez_compressed(os.path.join(OUT, "g20_float64.npz"), **out)
 
 
+def g21_bilinear():
+    """Tracker(interpolation={"kx": 1, "ky": 1}) (tracker.py:60, :585-590, :623): the SSD surface sampled by a degree-1
+    RectBivariateSpline, the search box widened to 2 cells only -- whole tracks on the g15 scene."""
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    cam2 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    seq, _ = synth.make_sequence(cam2, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam2, 3, border_px=70.0, seed=3)
+    g15 = np.load(os.path.join(OUT, "g15_ragged.npz"))
+    assert np.array_equal(g15["frames"], np.stack(seq)) and np.array_equal(g15["cam"], cam2)
+    imgs = [ref_image(seq[i], cam2, t0 + i * day) for i in range(6)]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)], interpolation={"kx": 1, "ky": 1})
+    out = {"xy": pts}
+    for tag, sig in (("wide", (0.2, 0.2)), ("tight", (0.004, 0.004))):
+        # (tight: a cloud narrower than a pixel, where the least surface size -- 2 x 2 instead of 4 x 4 -- matters)
+        models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=sig,
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0) if tag == "wide" else (0.002, 0.002, 0.0),
+                                          axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0) if tag == "wide" else (0.0005, 0.0005, 0.0))
+                  for xy in pts]
+        np.random.seed(47)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15))
+        out[f"{tag}_means"], out[f"{tag}_sigmas"] = tracks.means, tracks.sigmas
+        print("g21", tag, "vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g21_bilinear.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g21" in sys.argv:
+        g21_bilinear()
+        sys.exit(0)
     if "--g20" in sys.argv:
         g20_float64()
         sys.exit(0)
@@ -1050,5 +1081,6 @@ if __name__ == "__main__":
     g18_uint16()
     g19_observer_helpers()
     g20_float64()
+    g21_bilinear()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
