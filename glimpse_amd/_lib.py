@@ -104,6 +104,7 @@ SIGNATURES = {
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_debug_last_variant": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
+    "glh_get_tracks": (_I, [_P, _I, _I, _P, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
     "glh_get_template": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "glh_get_likelihood_debug": (_I, [_P, _I, _I, _P, _P, _P, _P]),
@@ -478,6 +479,12 @@ class Context:
         out = np.empty((n_frames, self.P, 12))
         check(self.lib.glh_get_moments(self.handle, frame0, n_frames, _ptr(out)))
         return out
+
+    def get_tracks(self, frame0, n_frames):
+        """The posterior history as Tracks holds it: means (P, n_frames, 6), sigmas (P, n_frames, 6)."""
+        means, sigmas = np.empty((self.P, n_frames, 6)), np.empty((self.P, n_frames, 6))
+        check(self.lib.glh_get_tracks(self.handle, frame0, n_frames, _ptr(means), _ptr(sigmas)))
+        return means, sigmas
 
     def moments_device(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -1694,6 +1694,19 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   if (oob) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RASTER_OOB, a.frame);
 }
 
+// The posterior history [T][P][12] (mean | sigma per frame and point) as the two arrays a caller of Tracker.track
+// receives, means [P][T][6] and sigmas [P][T][6] (tracks.py:52-88): one thread per (point, frame, component).
+__global__ __launch_bounds__(BLK) void k_tracks_layout(const double* moments, int T, int P, double* means, double* sigmas) {
+  const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;  // index into [P][T][6]
+  if (i >= (size_t)P * T * 6) return;
+  const int k = (int)(i % 6);
+  const size_t pt = i / 6;
+  const int t = (int)(pt % T), p = (int)(pt / T);
+  const double* m = moments + ((size_t)t * P + p) * 12;
+  means[i] = m[k];
+  sigmas[i] = m[6 + k];
+}
+
 // Test hook: sample a fitted surface (glh_stage_sample); one "point".
 struct SampleArgs {
   const double* coef;

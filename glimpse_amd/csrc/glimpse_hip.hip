@@ -136,6 +136,8 @@ struct glh_ctx {
   int32_t* resid_draws = nullptr;  // [P] uniforms consumed by the last residual resampling
   uint32_t* bins16 = nullptr;   // [P][65535 * 3 + 1] key histograms of 16-bit frames (staged tile kernels), on first use
   double* fwork = nullptr;      // [P][2 D^2] tile workspace of float64 frames (staged tile kernels), on first use
+  double* tracks_tmp = nullptr; // means | sigmas in the caller's layout (glh_get_tracks), on first use
+  size_t tracks_tmp_n = 0;
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
@@ -267,7 +269,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   } dfree(c->obs_mask); dfree(c->active); dfree(c->pt_status);
   dfree(c->pt_err_frame); dfree(c->obs_status_all); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
-  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->fwork); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
+  dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->fwork); dfree(c->tracks_tmp); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
   dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
@@ -1647,6 +1649,27 @@ extern "C" int glh_get_moments(glh_ctx* c, int frame0, int n_frames, double* out
   if (!out || frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames)
     return fail(GLH_E_INVALID, "bad frame range");
   DOWNLOAD(out, c->moments + (size_t)frame0 * c->P * 12, (size_t)n_frames * c->P * 12, double);
+  return GLH_OK;
+}
+
+extern "C" int glh_get_tracks(glh_ctx* c, int frame0, int n_frames, double* means, double* sigmas) {
+  CHK(need_seq(c));
+  if (!means || !sigmas || frame0 < 0 || n_frames <= 0 || frame0 + n_frames > c->cfg.max_frames)
+    return fail(GLH_E_INVALID, "bad frame range or null output");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const size_t n = (size_t)n_frames * c->P * 6;
+  if (c->tracks_tmp_n < 2 * n) {
+    dfree(c->tracks_tmp);
+    c->tracks_tmp = nullptr;
+    c->tracks_tmp_n = 0;
+    CHK(dalloc(&c->tracks_tmp, 2 * n));
+    c->tracks_tmp_n = 2 * n;
+  }
+  hipLaunchKernelGGL(k_tracks_layout, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, c->stream,
+                     c->moments + (size_t)frame0 * c->P * 12, n_frames, c->P, c->tracks_tmp, c->tracks_tmp + n);
+  HIPCHK(hipGetLastError());
+  DOWNLOAD(means, c->tracks_tmp, n, double);
+  DOWNLOAD(sigmas, c->tracks_tmp + n, n, double);
   return GLH_OK;
 }
 

@@ -421,9 +421,7 @@ class Tracker:
                     break
                 stops = new_stops
 
-        moments = ctx.get_moments(0, ntimes)  # (T, P, 12)
-        means = np.ascontiguousarray(np.transpose(moments[:, :, 0:6], (1, 0, 2)))
-        sigmas = np.ascontiguousarray(np.transpose(moments[:, :, 6:12], (1, 0, 2)))
+        means, sigmas = ctx.get_tracks(0, ntimes)  # (P, T, 6) each, laid out on the device
         covariances = None
         if return_covariances:  # tracker.py:307-308, :352: (P, T, 6, 6) instead of sigmas
             covariances = np.ascontiguousarray(np.transpose(ctx.get_covariances(0, ntimes), (1, 0, 2, 3)))

@@ -295,6 +295,9 @@ int glh_debug_last_variant(glh_ctx* ctx, int32_t* variant);
 /* ---- results --------------------------------------------------------------------------- */
 /* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
 int glh_get_moments(glh_ctx* ctx, int frame0, int n_frames, double* out);
+/* The same history in the layout of the reference's Tracks (tracks.py:52-88): means [P][n_frames][6] and sigmas
+ * [P][n_frames][6], rearranged on the device (no host-side transposes of tens of megabytes).                    */
+int glh_get_tracks(glh_ctx* ctx, int frame0, int n_frames, double* means, double* sigmas);
 /* Device pointer + byte size of the moments history [max_frames][P][12] (for an RCCL
  * gather issued by the caller; no copy).                                                    */
 int glh_get_moments_device(glh_ctx* ctx, void** dev_ptr, uint64_t* bytes);
