@@ -24,6 +24,10 @@ the timed region (glh_gather_moments inside the library; no torch anywhere).  `-
 starts the N ranks itself (children are started before anything touches a GPU); under torchrun
 (RANK / WORLD_SIZE set) every process is one rank.
 
+The default run (C3, one GPU) adds short SECONDARY legs after the headline, each over its whole sequence from the prior
+on the frames already in memory: exact arithmetic at C3 (the arithmetic the oracle tests pin bit for bit), one GPU's
+shard of C4 (1 250 x 10 000), C5 (2 048 x 5 000, two observers + DEM term) and C2 -- `secondary` in the JSON line.
+
 Prints ONE JSON line on rank 0 (keys: DESIGN.md "Measurement") and exits non-zero when the run is unhealthy.
 """
 import argparse
@@ -84,6 +88,8 @@ def parse_args(argv=None):
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs of the default run (exact arithmetic at C3, the C4 shard, C5, C2)")
     ap.add_argument("--dump-moments", default=None, help="rank 0 saves the (gathered) posterior history (T, P, 12) here (.npy)")
     return ap.parse_args(argv)
 
@@ -97,23 +103,51 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch(args):
+def launch(args, argv=None, poll=0.05):
     """Start N fresh rank processes (this parent never touches a GPU), relay rank 0's JSON line, fail if any
-    child fails."""
+    child fails.  A rank that dies takes the job down at once: the parent marks the rendezvous directory as aborted
+    (ranks waiting in FileStore.get raise instead of polling until their timeout), stops the others and returns 1."""
+    import tempfile
+    import threading
+
+    from glimpse_amd import sharding
+
     n = args.gpus
     port = _free_port()
+    argv = sys.argv[1:] if argv is None else list(argv)
     procs = []
+    out0 = tempfile.TemporaryFile()
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if rank == 0 else subprocess.DEVNULL))
+    store_path = sharding.FileStore.default_path(f"{port}_{os.getpid()}")  # (Group.from_env: port + launcher's pid)
+    codes = [None] * n
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            os.makedirs(store_path, exist_ok=True)
+            sharding.FileStore(store_path, -1, n).abort(f"ranks failed: {[(r, c) for r, c in enumerate(codes) if c]}")
+            # the survivors see the abort mark at their next rendezvous; ranks stuck elsewhere are stopped after a grace
+            # period (our own children, by pid)
+            killer = threading.Timer(float(os.environ.get("GLH_LAUNCH_GRACE", "10")),
+                                     lambda: [p.kill() for p in procs if p.poll() is None])
+            killer.daemon = True
+            killer.start()
+        time.sleep(poll)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
+        import shutil
+
+        shutil.rmtree(store_path, ignore_errors=True)
         print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
         return 1
     return 0
@@ -366,6 +400,98 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
 
 
 # ------------------------------------------------------------------------------------------------
+# secondary legs of the default run: the other configurations and the parity-grade arithmetic, short
+# ------------------------------------------------------------------------------------------------
+def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
+    """The whole sequence of `wl` from the prior (frame 0 initialises, frames 1 .. n_frames-1 are timed) on a context that
+    already holds its frames: one glh_track call, HIP events around every launch.  Returns the figures of a secondary
+    leg: ms per frame update (wall and kernel), roofline fraction by SURVEY 8(d)'s algorithmic bytes, PMC traffic ratio
+    from the committed counters."""
+    images = lambda i: [i] * wl.O  # noqa: E731
+
+    def initialise():
+        ctx.set_frame(0)
+        ctx.init_particles(seed=seed)
+        for o in range(wl.O):
+            ctx.init_templates(o, 0)
+        ctx.record_moments(0)
+
+    def run(first, count):
+        if count <= 0:
+            return
+        fr = list(range(first, first + count))
+        ctx.track(fr, [1.0] * count, [images(j) for j in fr], seed=seed)
+
+    ctx.set_math(math)
+    initialise()
+    run(1, min(warm, n_frames - 1))
+    ctx.sync()
+    initialise()
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    run(1, n_frames - 1)
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    stage_ms = ctx.profile_get()
+    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+    launch_ms = ctx.profile_launches(dom)
+    ctx.profile_enable(False)
+    status = ctx.observer_status()
+    boxes = ctx.search_boxes()
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
+    dom_ms, dom_n = stage_ms[dom]
+    per_launch = dom_ms / max(dom_n, 1)
+    kern = KERNEL_OF_STAGE.get(dom, dom)
+    traffic = pmc_traffic(wl, kern) if math == "fast" else None
+    moments = ctx.get_moments(0, n_frames)
+    leg = {
+        "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
+        "variant": list(ctx.last_variant()),
+        "ms_per_frame": 1e3 * wall / (n_frames - 1),
+        "kernel_ms_per_launch": per_launch,
+        "value": wl.P * wl.N * (n_frames - 1) / wall,
+        "roofline_frac": abytes / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": abytes,
+        "traffic_ratio": None if traffic is None else traffic / abytes,
+        "observer_ok_fraction": float((status == 0).mean()),
+        "points_with_error_bits": int((ctx.point_status() != 0).sum()),
+        "final_means_finite": bool(np.isfinite(moments[n_frames - 1]).all()),
+    }
+    if len(launch_ms) == dom_n and dom_n == n_frames - 1:
+        tail = launch_ms[-min(20, dom_n):]
+        leg["steady_ms_per_frame"] = float(tail.mean())
+        leg["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:6]]
+    return leg
+
+
+def secondary_legs(args, device, T, frames_c3, frames_c5, seed):
+    """What the headline does not show, each over its whole sequence from the prior on the frames already rendered:
+    exact arithmetic at C3 (the arithmetic the oracle tests pin bit for bit), one GPU's shard of C4, C5 (two observers
+    + DEM term, all 2048 points on one GPU) and C2."""
+    from glimpse_amd import _lib, workloads
+
+    legs = {}
+    plan = [("C3_exact", "C3", None, "exact", T, frames_c3),
+            ("C4_shard", "C4", None, "fast", T, frames_c3),
+            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, frames_c5),
+            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), frames_c3)]
+    for key, name, points, math, n_frames, frames in plan:
+        if frames is None:
+            continue
+        try:
+            wl = workloads.Workload(name, n_frames=T, n_points=points, shard=0, seed=0)
+            with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile),
+                              max_search_dim=args.max_search_dim, max_frames=T) as ctx:
+                workloads.setup_context(ctx, wl, frames)
+                legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
+        except Exception as e:  # noqa: BLE001
+            legs[key] = {"error": repr(e)}
+    return legs
+
+
+# ------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------
 def worker(args):
@@ -375,9 +501,6 @@ def worker(args):
     rank, world = group.rank, group.world
     if "WORLD_SIZE" in os.environ and args.gpus != world and args.gpus != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one GPU per rank (LOCAL_RANK); GLH_BENCH_DEVICE is a test hook (several ranks on one GPU)
-    device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank % max(1, _lib.device_count())))
-
     cfg = workloads.CONFIGS[args.workload]
     W, B = max(0, args.warmup), max(0, args.burn_in)
     if args.steps is None:
@@ -406,10 +529,17 @@ def worker(args):
         point_offset = rank * wl.P
         sizes = [wl.P] * world
 
-    # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files
+    # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files -- by forked helpers,
+    # hence BEFORE anything loads the HIP library (the device count below does)
     cores = usable_cores()
+    secondary = (world == 1 and not args.no_secondary and args.workload == "C3" and args.points is None
+                 and args.particles is None and args.motion == "cartesian" and B == 0)
+    frames_c5 = None
     if world == 1:
         frames = render_frames(wl, cores)
+        if secondary:
+            frames_c5 = render_frames(workloads.Workload("C5", n_frames=T, n_points=workloads.CONFIGS["C5"]["points"],
+                                                         shard=0, seed=0), cores)
     else:
         if rank == 0:
             frames = render_frames(wl, cores)
@@ -418,6 +548,8 @@ def worker(args):
         else:
             frames = [group.store.get_array(f"frames_{o}", mmap=True) for o in range(wl.O)]
 
+    # one GPU per rank (LOCAL_RANK); GLH_BENCH_DEVICE is a test hook (several ranks on one GPU)
+    device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank % max(1, _lib.device_count())))
     ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
                        max_frames=T)
     workloads.setup_context(ctx, wl, frames)
@@ -534,7 +666,7 @@ def worker(args):
             "dtype": "f64",
             "data": "synthetic",
             "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
-                           math=args.math if args.motion == "cartesian" else "exact (general kernel)", parallelism=f"points sharded x{world}",
+                           math=args.math, untimed_launches=W * F + B, parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K * F / elapsed, burn_in_steps=B, frames_per_call=C,
                            frame_updates_per_step=F,
                            step=f"{F} consecutive frame update(s) of all {total_points} points",
@@ -579,8 +711,13 @@ def worker(args):
     ctx_closed = False
     if rank == 0 and world == 1:
         # the side legs must not cost the headline: a failure is reported in the line, the run then exits non-zero
-        if not args.no_api:
+        if secondary:
             ctx.close()
+            ctx_closed = True
+            out["secondary"] = secondary_legs(args, device, T, frames, frames_c5, seed)
+        if not args.no_api:
+            if not ctx_closed:
+                ctx.close()
             ctx_closed = True
             try:
                 out.update(api_leg(wl, frames, T, seed, device, args.max_search_dim))
@@ -599,7 +736,9 @@ def worker(args):
         h = out["health"]
         if h["points_with_error_bits"] or h["observer_ok_fraction"] < 0.99 or not h["final_means_finite"] \
                 or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False \
-                or "api_error" in out or "cpu_baseline_error" in out:
+                or "api_error" in out or "cpu_baseline_error" in out \
+                or any("error" in leg or leg.get("points_with_error_bits") or not leg.get("final_means_finite", True)
+                       or leg.get("observer_ok_fraction", 1.0) < 0.99 for leg in out.get("secondary", {}).values()):
             rc = 3
             out["health"]["verdict"] = "UNHEALTHY"
         print(json.dumps(out), flush=True)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "glh_set_highpass": (_I, [_P, _I, _I]),
     "glh_set_interpolation": (_I, [_P, _I, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
+    "glh_debug_draws": (_I, [_P, _I, _U64, _U64, _P]),
     "glh_debug_last_variant": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_tracks": (_I, [_P, _I, _I, _P, _P]),
@@ -457,6 +458,14 @@ class Context:
         """Diagnostic: s_memtime stamps (P, 20) of the fused kernel's phase boundaries (first call arms)."""
         out = np.zeros((self.P, 20), dtype=np.uint64)
         check(self.lib.glh_debug_phase_stamps(self.handle, _ptr(out)))
+        return out
+
+    def debug_draws(self, kind, seed, step=0):
+        """The device stream's numbers: kind "init" (P, N, 6), "evolve" (P, N, 3) or "u" (P,) of frame `step`."""
+        k = {"init": 0, "evolve": 1, "u": 2}[kind]
+        shape = {0: (self.P, self.N, 6), 1: (self.P, self.N, 3), 2: (self.P,)}[k]
+        out = np.empty(shape, dtype=np.float64)
+        check(self.lib.glh_debug_draws(self.handle, k, int(seed), int(step), _ptr(out)))
         return out
 
     def last_variant(self):

@@ -351,6 +351,7 @@ struct InitArgs {
   Surfaces surf;
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
   const int pt = blockIdx.y;
   if (a.active && !a.active[pt]) return;
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(BLK) void k_init_particles(InitArgs a) {
   for (int k = 0; k < 6; ++k) p[k] = x[k];
   a.weights[(size_t)pt * a.N + i] = 1.0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K1  evolve (motion.py:165-179) + NaN test (tracker.py:118) + project (camera.py:591)
@@ -402,6 +404,7 @@ struct EvolveArgs {
   ObsFrame obs[MAX_OBS];
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
   __shared__ double red[NWAVES][5];
   const int pt = blockIdx.y;
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(BLK) void k_evolve_project(EvolveArgs a) {
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K7  particle_mean / compute_particle_sigma (tracker.py:72-76, :89-104)
@@ -490,6 +494,7 @@ struct MomentsArgs {
   int32_t N, ld, with_sigma;
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_moments(MomentsArgs a) {
   __shared__ double red[NWAVES];
   const int pt = blockIdx.x;
@@ -535,6 +540,7 @@ __global__ __launch_bounds__(BLK) void k_moments(MomentsArgs a) {
     if (tid == 0) out[6 + k] = sqrt(var);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Tracker.particle_covariance (tracker.py:78-82): np.cov(particles.T, aweights=weights, ddof=0)
@@ -548,6 +554,7 @@ struct CovArgs {
   int32_t N;
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_covariance(CovArgs a) {
   __shared__ double red[NWAVES];
   const int pt = blockIdx.x;
@@ -598,6 +605,7 @@ __global__ __launch_bounds__(BLK) void k_covariance(CovArgs a) {
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // pixel keys: gray value, or channel sum for RGB (tile.mean(axis=2) is sum/3, tracker.py:524)
@@ -1029,6 +1037,7 @@ struct TemplateArgs {
   int32_t* pt_err_frame;
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t hist[NBINS];
@@ -1081,6 +1090,7 @@ __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
     if (s_const) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_CONST_TILE, a.frame);
   }
 }
+#endif
 
 // Test hook: template from an explicit box (glh_stage_template).
 struct TemplateBoxArgs {
@@ -1090,6 +1100,7 @@ struct TemplateBoxArgs {
   int32_t hp_rx, hp_ry;
   TemplateOut out;
 };
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t hist[NBINS];
@@ -1101,6 +1112,7 @@ __global__ __launch_bounds__(BLK) void k_template_from_box(TemplateBoxArgs a) {
   template_from_box(a.frame, a.width, a.channels, s_box, reinterpret_cast<uint16_t*>(smem), hist,
                     red, a.out, &s_const, a.hp_rx, a.hp_ry);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Search tile from an integer box: extract_tile(histogram=template CDF) (tracker.py:605-607):
@@ -1228,6 +1240,7 @@ struct TilePrepArgs {
   float* search;        // [O][P][search_cap]
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t hist[NBINS];
@@ -1300,6 +1313,7 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
                          a.tmpl_hist_n[slot], hist, cum, lut, reinterpret_cast<uint16_t*>(smem),
                          scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
 }
+#endif
 
 // Test hook: search tile from an explicit box (glh_stage_search_tile).
 struct SearchBoxArgs {
@@ -1312,6 +1326,7 @@ struct SearchBoxArgs {
   int32_t hp_rx, hp_ry;
   float* out;
 };
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ uint32_t hist[NBINS];
@@ -1324,6 +1339,7 @@ __global__ __launch_bounds__(BLK) void k_search_from_box(SearchBoxArgs a) {
   search_tile_from_box(a.frame, a.width, a.channels, s_box, a.hist_v, a.hist_q, a.hist_n, hist, cum,
                        lut, reinterpret_cast<uint16_t*>(smem), scan_tmp, a.out, a.hp_rx, a.hp_ry);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K3  area-averaged SSD surface (tracker.py:609-614):
@@ -1427,6 +1443,7 @@ __host__ __device__ __forceinline__ int ssd_row_split(int wo, int ho) {
   return G;
 }
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int pt = blockIdx.y, tid = threadIdx.x;
@@ -1493,6 +1510,7 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K4  spline coefficients: two passes of banded (|i-j| <= 2) not-a-knot collocation solves
@@ -1561,6 +1579,7 @@ __device__ __forceinline__ void solve_line(double* x, int stride, int n, const d
   }
 }
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
   const int pt = blockIdx.x, tid = threadIdx.x;
   const size_t slot = (size_t)a.o * a.P + pt;
@@ -1585,6 +1604,7 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
   __syncthreads();
   for (int r = tid; r < ho; r += BLK) solve_line(z + (size_t)r * wo, 1, wo, fw);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K5  sample the spline at every particle (observer.py:178-214), scale by 1/(2 sigma^2)
@@ -1633,6 +1653,7 @@ __device__ __forceinline__ void exp_table_fill(double* tab32) {
   if (threadIdx.x < GLH_EXP_TAB) tab32[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / GLH_EXP_TAB));
 }
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   __shared__ double tab[16 * GLH_NPOLY];
   __shared__ double tab32[GLH_EXP_TAB];
@@ -1693,9 +1714,11 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
   }
   if (oob) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_RASTER_OOB, a.frame);
 }
+#endif
 
 // The posterior history [T][P][12] (mean | sigma per frame and point) as the two arrays a caller of Tracker.track
 // receives, means [P][T][6] and sigmas [P][T][6] (tracks.py:52-88): one thread per (point, frame, component).
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_tracks_layout(const double* moments, int T, int P, double* means, double* sigmas) {
   const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;  // index into [P][T][6]
   if (i >= (size_t)P * T * 6) return;
@@ -1706,6 +1729,7 @@ __global__ __launch_bounds__(BLK) void k_tracks_layout(const double* moments, in
   means[i] = m[k];
   sigmas[i] = m[6 + k];
 }
+#endif
 
 // Test hook: sample a fitted surface (glh_stage_sample); one "point".
 struct SampleArgs {
@@ -1716,6 +1740,7 @@ struct SampleArgs {
   double* values;
   uint8_t* outside;
 };
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= a.n) return;
@@ -1724,6 +1749,7 @@ __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
   double cu0 = cell_origin(a.sb[0], a.sb[2], a.wo), cv0 = cell_origin(a.sb[1], a.sb[3], a.ho);
   a.values[i] = spline_eval(a.coef, a.wo, a.ho, a.wo, cv0, cu0, u, v);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K6  systematic resampling (tracker.py:168-176, :222-223) + posterior moments
@@ -1767,6 +1793,7 @@ struct ResampleArgs {
   int32_t fast;    // GLH_MATH_FAST (systematic resampling only): see the fast branch in k_resample
 };
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double wave_tot[NWAVES];
@@ -2080,11 +2107,13 @@ __global__ __launch_bounds__(BLK) void k_resample(ResampleArgs a) {
     }
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Run-length compact state (written by the fused step, glh_point.h: planar, chunk c of record r at c N + r)
 // -> one record per particle: out[j] = in[uidx[j]] for the particles and the weights.  grid (ceil(N / BLK), P).
 // ------------------------------------------------------------------------------------------
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_expand_state(const double* pin, const double* win, const uint16_t* uidx,
                                                       double* pout, double* wout, int N) {
   const int pt = blockIdx.y, j = blockIdx.x * BLK + threadIdx.x;
@@ -2097,10 +2126,12 @@ __global__ __launch_bounds__(BLK) void k_expand_state(const double* pin, const d
   dst[0] = v0; dst[1] = v1; dst[2] = v2;
   wout[base + j] = win[base + r];
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Test hook: Camera.xyz_to_uv on explicit points
 // ------------------------------------------------------------------------------------------
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const double* xyz, int n,
                                                         double* uv, int directions, double* depth) {
   const int i = blockIdx.x * BLK + threadIdx.x;
@@ -2112,8 +2143,10 @@ __global__ __launch_bounds__(BLK) void k_project_points(const CamDev* cam, const
   uv[2 * i + 1] = v;
   if (depth) depth[i] = d;
 }
+#endif
 
 // Camera.uv_to_xyz on explicit points; depth null = 1, else [n] (or [1], broadcast)
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_unproject_points(const CamDev* cam, const double* uv, int n,
                                                           const double* depth, int n_depth, int directions,
                                                           double* xyz) {
@@ -2126,8 +2159,10 @@ __global__ __launch_bounds__(BLK) void k_unproject_points(const CamDev* cam, con
   xyz[3 * i + 1] = out[1];
   xyz[3 * i + 2] = out[2];
 }
+#endif
 
 // Test hook: Raster.sample at explicit points
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_raster_sample(RasterDev r, const double* xy, int n, int order,
                                                        double* values, uint8_t* oob) {
   const int i = blockIdx.x * BLK + threadIdx.x;
@@ -2136,10 +2171,53 @@ __global__ __launch_bounds__(BLK) void k_raster_sample(RasterDev r, const double
   values[i] = raster_sample(r, xy[2 * i], xy[2 * i + 1], order, &out);
   oob[i] = out;
 }
+#endif
 
+#ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ void k_fill_f64(double* p, size_t n, double v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+#endif
+
+#ifndef GLH_POINT_TU
+// Diagnostic (glh_debug_draws): the numbers of the device streams, written out so that a test can hand the oracle the
+// very draws a GLH_RNG_PHILOX run consumed.  kind 0: the six initialisation normals [P][N][6] (k_init_particles);
+// kind 1: the three evolve normals of frame `step` [P][N][3] (evolve_noise); kind 2: the systematic resampling offset
+// of frame `step` [P] (k_resample / k_point_step).
+struct DrawsArgs {
+  double* out;
+  uint64_t seed, step;
+  int32_t kind, N, P, pt_base;
+};
+__global__ __launch_bounds__(BLK) void k_debug_draws(DrawsArgs a) {
+  const int pt = blockIdx.y;
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  const uint32_t gp = (uint32_t)(pt + a.pt_base);
+  if (a.kind == 2) {
+    if (i == 0) {
+      uint32_t r[4];
+      philox4x32(gp, 0u, (uint32_t)a.step, 0x52455341u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+      a.out[pt] = u01_halfopen(r[0], r[1]);
+    }
+    return;
+  }
+  if (i >= a.N) return;
+  if (a.kind == 0) {
+    double n[6];
+    philox_normals2(a.seed, i, gp, 0u, 0x494e4954u, n[0], n[1]);
+    philox_normals2(a.seed, i, gp, 1u, 0x494e4954u, n[2], n[3]);
+    philox_normals2(a.seed, i, gp, 2u, 0x494e4954u, n[4], n[5]);
+    double* o = a.out + ((size_t)pt * a.N + i) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = n[k];
+  } else {
+    double n[3];
+    evolve_noise(GLH_RNG_PHILOX, nullptr, a.seed, a.step, pt, a.pt_base, i, a.N, n);
+    double* o = a.out + ((size_t)pt * a.N + i) * 3;
+    o[0] = n[0]; o[1] = n[1]; o[2] = n[2];
+  }
+}
+#endif
 
 }  // namespace glh

@@ -16,8 +16,39 @@
 #include "glh_host.h"
 #include "glh_kernels.h"
 #include "glh_point.h"
+#include "glh_point_variants.h"
 
 using namespace glh;
+
+// The fused kernel's instantiations live in their own translation units (glh_point_inst.hip, glh_point_variants.h).
+namespace glh {
+#define GLH_PT_DECL(TB, PPT, NOBS, S, F, C) const void* GLH_PT_NAME(TB, PPT, NOBS, S, F, C)();
+#define GLH_PT_DECL_SHAPE(TB, PPT, NOBS) GLH_PT_CODES(GLH_PT_DECL, TB, PPT, NOBS)
+GLH_PT_SHAPES(GLH_PT_DECL_SHAPE)
+#undef GLH_PT_DECL_SHAPE
+#undef GLH_PT_DECL
+}  // namespace glh
+
+static const void* pt_kernel(int tb, int ppt, int nobs, bool surf, bool fast, bool con) {
+#define GLH_PT_PICK(TB, PPT, NOBS, S, F, C) \
+  if (tb == TB && ppt == PPT && nobs == NOBS && surf == (bool)S && fast == (bool)F && con == (bool)C) \
+    return GLH_PT_NAME(TB, PPT, NOBS, S, F, C)();
+#define GLH_PT_PICK_SHAPE(TB, PPT, NOBS) GLH_PT_CODES(GLH_PT_PICK, TB, PPT, NOBS)
+  GLH_PT_SHAPES(GLH_PT_PICK_SHAPE)
+#undef GLH_PT_PICK_SHAPE
+#undef GLH_PT_PICK
+  return nullptr;
+}
+
+static std::vector<const void*> pt_all_kernels() {
+  std::vector<const void*> v;
+#define GLH_PT_PUSH(TB, PPT, NOBS, S, F, C) v.push_back(GLH_PT_NAME(TB, PPT, NOBS, S, F, C)());
+#define GLH_PT_PUSH_SHAPE(TB, PPT, NOBS) GLH_PT_CODES(GLH_PT_PUSH, TB, PPT, NOBS)
+  GLH_PT_SHAPES(GLH_PT_PUSH_SHAPE)
+#undef GLH_PT_PUSH_SHAPE
+#undef GLH_PT_PUSH
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -391,18 +422,10 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-#define GLH_PT_VARIANTS(SURF_, FAST_, CON_)                                                                       \
-  (const void*)k_point_step<512, 0, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<512, 0, 4, 2, SURF_, FAST_, CON_>,   \
-  (const void*)k_point_step<512, 4, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<512, 10, 4, 1, SURF_, FAST_, CON_>,  \
-  (const void*)k_point_step<1024, 0, 4, 1, SURF_, FAST_, CON_>, (const void*)k_point_step<1024, 0, 4, 2, SURF_, FAST_, CON_>, \
-  (const void*)k_point_step<1024, 10, 4, 1, SURF_, FAST_, CON_>
-    for (const void* f : {GLH_PT_VARIANTS(false, false, false), GLH_PT_VARIANTS(true, false, false),
-                          GLH_PT_VARIANTS(false, true, true), GLH_PT_VARIANTS(true, true, false),
-                          GLH_PT_VARIANTS(true, true, true)}) {
+    for (const void* f : pt_all_kernels()) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
       if (e != hipSuccess) e4 = e;
     }
-#undef GLH_PT_VARIANTS
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       rc = fail(GLH_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   }
@@ -480,6 +503,13 @@ extern "C" int glh_observer_set_depth(glh_ctx* c, int o, int bits) {
     return fail(GLH_E_UNSUPPORTED, "float64 frames have one channel (observer %d has %d)", o, ob.channels);
   for (auto& p : ob.owned)
     if (p) return fail(GLH_E_STATE, "observer %d: set the depth before uploading frames", o);
+  // what the wider tile kernels are sized for (their LDS requests grow with the context's limits)
+  if (bits == 16 && (size_t)(BAND_H + 6) * c->cfg.max_search_dim * 4 > 96 * 1024)
+    return fail(GLH_E_UNSUPPORTED, "16-bit frames: max_search_dim %d exceeds %d (one median band must fit 96 KiB of LDS)",
+                c->cfg.max_search_dim, (int)(96 * 1024 / ((BAND_H + 6) * 4)));
+  if (bits == 64 && (size_t)c->cfg.max_tile * c->cfg.max_tile * 12 > 64 * 1024)
+    return fail(GLH_E_UNSUPPORTED, "float64 frames: max_tile %d exceeds 73 (template workspace of 64 KiB of LDS)",
+                c->cfg.max_tile);
   ob.bits = bits;
   return GLH_OK;
 }
@@ -589,6 +619,8 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
   HIPCHK(hipMemsetAsync(c->pt_status, 0, P * sizeof(uint32_t), c->stream));
   HIPCHK(hipMemsetAsync(c->pt_err_frame, 0x7f, P * sizeof(int32_t), c->stream));
   HIPCHK(hipMemsetAsync(c->tmpl_valid, 0, O * P * sizeof(int32_t), c->stream));
+  // (the fused kernel fetches a template's CDF length before it knows the template is valid: never garbage)
+  HIPCHK(hipMemsetAsync(c->tmpl_hist_n, 0, O * P * sizeof(int32_t), c->stream));
   {
     // GLH_OBS_SKIPPED everywhere, for every frame
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->obs_status_all, GLH_OBS_SKIPPED, (size_t)c->cfg.max_frames * O * P,
@@ -1436,38 +1468,21 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
     // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
-#define GLH_LAUNCH_POINT(TB_, PPT_, NOBS_)                                                                     \
-  do {                                                                                                         \
-    c->last_variant[0] = TB_; c->last_variant[1] = PPT_; c->last_variant[2] = NOBS_;                           \
-    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);                                   \
-    if (surf && common)                                                                                        \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true, true>), grid, block, lds, c->stream, a);   \
-    else if (surf && fast)                                                                                     \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, true, false>), grid, block, lds, c->stream, a);  \
-    else if (surf)                                                                                             \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, true, false, false>), grid, block, lds, c->stream, a); \
-    else if (fast)                                                                                             \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, true, true>), grid, block, lds, c->stream, a);  \
-    else                                                                                                       \
-      hipLaunchKernelGGL((k_point_step<TB_, PPT_, 4, NOBS_, false, false, false>), grid, block, lds, c->stream, a);\
-  } while (0)
+    int tbv = 512, nobsv = O == 2 ? 2 : 1;
     if (!big) {
-      if (O == 1) {
-        if (ppt == 4) GLH_LAUNCH_POINT(512, 4, 1);
-        else if (ppt == 10) GLH_LAUNCH_POINT(512, 10, 1);
-        else GLH_LAUNCH_POINT(512, 0, 1);
-      } else {
-        GLH_LAUNCH_POINT(512, 0, 2);
-      }
+      if (O == 2) ppt = 0;
     } else {
-      if (O == 1) {
-        if (ppt == 10) GLH_LAUNCH_POINT(1024, 10, 1);
-        else GLH_LAUNCH_POINT(1024, 0, 1);
-      } else {
-        GLH_LAUNCH_POINT(1024, 0, 2);
-      }
+      tbv = 1024;
+      if (O == 2 || ppt != 10) ppt = 0;
     }
-#undef GLH_LAUNCH_POINT
+    c->last_variant[0] = tbv; c->last_variant[1] = ppt; c->last_variant[2] = nobsv;
+    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);
+    // codes the library carries (glh_point_variants.h): exact / exact general / fast common / fast general / fast
+    // general under the contract
+    const void* kern = pt_kernel(tbv, ppt, nobsv, surf, fast, surf ? common : fast);
+    if (!kern) return fail(GLH_E_STATE, "no instantiation of the fused kernel for <%d, %d, %d>", tbv, ppt, nobsv);
+    void* kargs[] = {(void*)&a};
+    HIPCHK(hipLaunchKernel(kern, grid, block, kargs, lds, c->stream));
   }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
@@ -1591,6 +1606,31 @@ extern "C" int glh_measure_copy_bandwidth(glh_ctx* c, uint64_t bytes, int iters,
 extern "C" int glh_debug_last_variant(glh_ctx* c, int32_t* variant) {
   if (!c || !variant) return fail(GLH_E_INVALID, "null argument");
   for (int k = 0; k < 4; ++k) variant[k] = c->last_variant[k];
+  return GLH_OK;
+}
+
+extern "C" int glh_debug_draws(glh_ctx* c, int kind, uint64_t seed, uint64_t step, double* out) {
+  CHK(need_seq(c));
+  if (!out || kind < 0 || kind > 2) return fail(GLH_E_INVALID, "kind must be 0 (init), 1 (evolve) or 2 (resample offset)");
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const size_t per = kind == 0 ? 6 : (kind == 1 ? 3 : 0);
+  const size_t count = kind == 2 ? (size_t)c->P : (size_t)c->P * c->N * per;
+  double* buf = nullptr;
+  CHK(dalloc(&buf, count));
+  DrawsArgs a{};
+  a.out = buf;
+  a.seed = seed;
+  a.step = step;
+  a.kind = kind;
+  a.N = c->N;
+  a.P = c->P;
+  a.pt_base = c->pt_base;
+  hipLaunchKernelGGL(k_debug_draws, dim3(kind == 2 ? 1 : (c->N + BLK - 1) / BLK, c->P), dim3(BLK), 0, c->stream, a);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, buf, count * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(buf);
+  if (e != hipSuccess) return fail(GLH_E_HIP, "glh_debug_draws failed: %s", hipGetErrorString(e));
   return GLH_OK;
 }
 

@@ -88,11 +88,28 @@ class FileStore:
             f.write(data)
         os.replace(tmp, os.path.join(self.path, key))
 
+    ABORT = "abort"  # written by a rank (or the launcher) that is giving up: every waiting `get` then raises
+
+    def abort(self, why=""):
+        """Tell every rank that is (or will be) waiting on this store that the job is over."""
+        try:
+            self.put(self.ABORT, str(why).encode())
+        except OSError:
+            pass
+
     def get(self, key):
         target = os.path.join(self.path, key)
+        stop = os.path.join(self.path, self.ABORT)
         deadline = time.monotonic() + self.timeout
         delay = 0.0002
         while not os.path.exists(target):
+            if os.path.exists(stop):
+                try:
+                    with open(stop, "rb") as f:
+                        why = f.read().decode(errors="replace")
+                except OSError:
+                    why = ""
+                raise RuntimeError(f"rank {self.rank}: the job was aborted while waiting for {key!r}: {why}")
             if time.monotonic() > deadline:
                 raise TimeoutError(f"rank {self.rank}: no {key!r} in {self.path} after {self.timeout:.0f} s")
             time.sleep(delay)
@@ -138,6 +155,7 @@ class Group:
         self.transport = "none" if world == 1 else "host"
         self._ctx = None
         self._seq = 0
+        self._attaches = 0  # attach() calls so far: store keys are write-once, every attach has its own
 
     @classmethod
     def from_env(cls, env=None):
@@ -165,6 +183,10 @@ class Group:
 
         want = transport or os.environ.get("GLH_COMM") or None
         ok, why = False, ""
+        # (a second attach on this group -- a new context for the next sequence, a retry after falling back to the
+        # host transport -- must not read the previous communicator's id or votes)
+        k = self._attaches
+        self._attaches += 1
         if want != "host":
             # rank 0 makes the id; an EMPTY id tells the others that it could not (they then skip the collective
             # ncclCommInitRank instead of waiting for a root that never comes)
@@ -175,9 +197,9 @@ class Group:
                 except _lib.GlhError as e:  # librccl missing
                     why = str(e)
                 if self.store is not None:
-                    self.store.put("rccl_id", cid)
+                    self.store.put(f"rccl_id.{k}", cid)
             else:
-                cid = self.store.get("rccl_id")
+                cid = self.store.get(f"rccl_id.{k}")
                 why = "" if cid else "rank 0 could not make an RCCL id"
             if cid:
                 try:
@@ -187,8 +209,8 @@ class Group:
                 except _lib.GlhError as e:  # e.g. several ranks on one GPU
                     why = str(e)
         if self.store is not None:  # all or nothing
-            self.store.put(f"rccl_ok.{self.rank}", b"1" if ok else b"0")
-            every = all(self.store.get(f"rccl_ok.{r}") == b"1" for r in range(self.world))
+            self.store.put(f"rccl_ok.{k}.{self.rank}", b"1" if ok else b"0")
+            every = all(self.store.get(f"rccl_ok.{k}.{r}") == b"1" for r in range(self.world))
         else:
             every = ok
         if ok and not every:

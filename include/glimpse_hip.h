@@ -283,6 +283,12 @@ int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
  * Other orders: GLH_E_UNSUPPORTED.  (1, 1) runs on the staged kernels.                                            */
 int glh_set_interpolation(glh_ctx* ctx, int kx, int ky);
 
+/* Diagnostic: the numbers of the GLH_RNG_PHILOX streams of this context's points (global indices point_offset ..),
+ * so that a parity test can hand the CPU oracle the draws a device-RNG run consumed -- the role np.random plays in
+ * the reference (motion.py:156-162, :176; tracker.py:173).  kind 0: initialisation normals out [P][N][6] in the order
+ * randn(n,2) | randn(n) | randn(n,3); kind 1: the evolve normals of frame `step`, out [P][N][3]; kind 2: the
+ * systematic resampling offset of frame `step`, out [P].  `step` is the frame index passed to glh_step.          */
+int glh_debug_draws(glh_ctx* ctx, int kind, uint64_t seed, uint64_t step, double* out);
 /* Diagnostic: s_memtime stamps [P][20] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);

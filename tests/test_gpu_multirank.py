@@ -89,3 +89,20 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(tmp_path):
     m1, m2 = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert m1.shape == (4, 16, 12)
     np.testing.assert_array_equal(m1, m2)
+
+
+def test_bench_four_ranks_ragged_split_matches_one_rank(tmp_path):
+    """A RAGGED strong split: 14 points over 4 ranks (4, 4, 3, 3), every rank on device 0 over the host transport, equals
+    the single-rank history bit for bit -- block boundaries, global point offsets of the device RNG and the gather's
+    per-rank sizes all differ from rank to rank.  (Four ranks, not eight: the GPU boxes of this pool allow at most six
+    processes on the card at once, and this test process is one of them.)"""
+    common = ["--workload", "C4", "--points", "14", "--particles", "600", "--steps", "3", "--warmup", "1",
+              "--frames-per-step", "1", "--no-cpu-baseline", "--no-api", "--split", "strong"]
+    four = _bench(["--gpus", "4", "--transport", "host", "--dump-moments", str(tmp_path / "four.npy")] + common)
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong"
+    assert four["health"]["gathered_moments_finite"] is True and four["health"]["points_with_error_bits"] == 0
+    assert four["config"]["total_points"] == 14 and four["config"]["points_per_gpu"] == 4
+    one = _bench(["--gpus", "1", "--dump-moments", str(tmp_path / "one.npy")] + common)
+    m1, m4 = np.load(tmp_path / "one.npy"), np.load(tmp_path / "four.npy")
+    assert m1.shape == (4, 14, 12) and np.isfinite(m1[1:]).all()
+    np.testing.assert_array_equal(m1, m4)

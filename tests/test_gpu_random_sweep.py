@@ -77,8 +77,11 @@ def _random_case(seed):
                 matching=matching, taus=taus, sigmas=sigmas, T=T)
 
 
+@pytest.mark.parametrize("math", ["exact", "fast"])
 @pytest.mark.parametrize("seed", range(24))
-def test_fused_step_matches_the_oracle_on_random_configurations(seed):
+def test_fused_step_matches_the_oracle_on_random_configurations(seed, math):
+    """exact: the reference's rounding; fast: the arithmetic of device-RNG runs (GLH_MATH_FAST) on the same host-fed
+    draws -- the general fast instantiation (flags == 3) -- meets the oracle just the same: indices bit for bit."""
     from glimpse_amd import _lib
     from oracle import motion as omotion
     from oracle import tracker as otracker
@@ -97,6 +100,7 @@ def test_fused_step_matches_the_oracle_on_random_configurations(seed):
                 ctx.observer_upload_frame(o, t, cs["frames"][o][t])
         ctx.begin_sequence(P, N, cs["tile"])
         ctx.set_motion_cartesian(cs["params"])
+        ctx.set_math(math)
         ctx.set_frame(0)
         ctx.init_particles(normals=init)
         for o in range(O):
@@ -107,6 +111,7 @@ def test_fused_step_matches_the_oracle_on_random_configurations(seed):
         for i in range(1, T):
             ctx.step(i, cs["taus"][i - 1], cs["matching"][i], normals=ev[i - 1], u=us[i - 1])
             idx.append(ctx.resample_indices())
+            assert ctx.last_variant()[3] == (3 if math == "fast" else 0)
         got = ctx.get_moments(0, T)
         status = ctx.point_status()
         obs_status = ctx.observer_status()

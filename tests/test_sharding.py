@@ -176,3 +176,73 @@ def test_bench_launcher_starts_n_ranks(tmp_path, monkeypatch):
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("seen.")) == ["seen.0", "seen.1", "seen.2"]
     monkeypatch.setenv("STUB_FAIL_RANK", "2")
     assert bench.launch(args) == 1
+
+
+def test_launcher_returns_when_a_rank_dies_before_the_rendezvous(tmp_path, monkeypatch):
+    """Rank 1 dies before it ever reaches the store; rank 0 and rank 2 are waiting in FileStore.get for its barrier
+    file.  The launcher marks the rendezvous directory as aborted, the waiting ranks raise at once (not after the
+    store's 600 s timeout), and launch() returns non-zero within seconds."""
+    import importlib.util
+    import time
+
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "stub_wait.py"
+    stub.write_text("import os, sys\n"
+                    f"sys.path.insert(0, {ROOT!r})\n"
+                    "from glimpse_amd import sharding\n"
+                    "if os.environ['RANK'] == '1':\n"
+                    "    sys.exit(7)\n"
+                    "g = sharding.Group.from_env()\n"
+                    "try:\n"
+                    "    g.store.barrier()\n"
+                    "except RuntimeError as e:\n"
+                    "    assert 'aborted' in str(e), e\n"
+                    "    open(os.path.join(os.path.dirname(__file__), 'aborted.' + os.environ['RANK']), 'w').write(str(e))\n"
+                    "    sys.exit(5)\n"
+                    "sys.exit(0)\n")
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: p)
+    monkeypatch.setenv("GLH_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("GLH_LAUNCH_GRACE", "30")  # the ranks must leave by themselves, not by the kill timer
+    args = bench.parse_args(["--gpus", "3"])
+    t0 = time.monotonic()
+    assert bench.launch(args, argv=["--gpus", "3"]) == 1
+    assert time.monotonic() - t0 < 20
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("aborted.")) == ["aborted.0", "aborted.2"]
+
+
+REATTACH_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+from glimpse_amd import sharding
+
+class FakeCtx:
+    def sync(self): pass
+
+g = sharding.Group.from_env()
+# two attaches on ONE group (a new context for the next sequence): each has its own store keys, so the second never
+# reads the first one's id / votes
+assert g.attach(FakeCtx(), "host") == "host"
+assert g.attach(FakeCtx(), "host") == "host"
+assert g._attaches == 2
+g.barrier()
+g.close()
+print("REATTACH_OK")
+"""
+
+
+def test_group_attach_twice_uses_fresh_keys(tmp_path):
+    script = tmp_path / "reattach_worker.py"
+    script.write_text(REATTACH_WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLH_RENDEZVOUS_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and "REATTACH_OK" in out, err[-2000:]

@@ -26,9 +26,8 @@ def main():
         shutil.copy(bench, os.path.join(prof, f"{tag}_{w}_bench.json"))
         shutil.copy(os.path.join(src, f"{w}_trace", "t_kernel_stats.csv"), os.path.join(prof, f"{tag}_{w}_kernel_stats.csv"))
         line = json.load(open(bench))
-        untimed = 3 + int(line.get("warmup", 0)) * 0  # bench.py: the sequence restarts from the prior; launches before the
-        # timed region = the warm-up sequence(s): take them from the line when it says so
-        warm = int(line["config"].get("untimed_launches", 3)) if isinstance(line.get("config"), dict) else 3
+        # launches of the dominant kernel before the timed region (warm-up steps + burn-in), as the bench line reports them
+        warm = int(line["config"]["untimed_launches"])
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"{tag}_{w}", key,
                         os.path.join(src, f"{w}_trace", "t_kernel_trace.csv"),
                         os.path.join(src, f"{w}_fetch", "f_counter_collection.csv"),
