@@ -22,9 +22,11 @@ from . import camera, resample, spline, ssd, tiles
 
 
 class Observer(dict):
-    def __init__(self, frames, cams, sigma=0.3, interp=(3, 3)):
-        """`interp` = (kx, ky) of Tracker(interpolation=...) (tracker.py:60, :585-590, :623)."""
-        super().__init__(frames=list(frames), cams=np.asarray(cams, dtype=float), sigma=sigma, interp=tuple(interp))
+    def __init__(self, frames, cams, sigma=0.3, interp=(3, 3), ssd="f64"):
+        """`interp` = (kx, ky) of Tracker(interpolation=...) (tracker.py:60, :585-590, :623); `ssd`: which
+        restatement of cv2.matchTemplate's accumulation (oracle/ssd.py) -- "f64" or "row_f32"."""
+        super().__init__(frames=list(frames), cams=np.asarray(cams, dtype=float), sigma=sigma, interp=tuple(interp),
+                         ssd=ssd)
 
 
 def observer_log_likelihoods(obs, img, template, particles, trace=None):
@@ -47,7 +49,7 @@ def observer_log_likelihoods(obs, img, template, particles, trace=None):
     box = box.ravel()
     search_tile = tiles.extract_tile(frame, box, histogram=template["histogram"])
     sse = ssd.match_template_sqdiff(
-        search_tile.astype(np.float32), template["tile"].astype(np.float32)
+        search_tile.astype(np.float32), template["tile"].astype(np.float32), accumulate=obs.get("ssd", "f64")
     )
     sse *= 1 / (size[0] * size[1])
     box_edge = halfsize - 0.5

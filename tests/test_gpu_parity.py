@@ -62,6 +62,13 @@ def test_stage_ssd_matches_oracle(lib):
         got = lib.stage_ssd(s, t)
         assert got.shape == want.shape
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=0)
+        # ... and BIT FOR BIT the restatement with the kernels' own accumulation (float32 fused multiply-adds along a
+        # template row, float64 across rows: oracle/ssd.c oracle_ssd_f32_rows) -- OpenCV leaves the precision of the
+        # accumulation open; the long-sequence index comparisons (test_gpu_pinned.py) are made against this one
+        rows = ossd.match_template_sqdiff(s, t, accumulate="row_f32")
+        rows *= 1 / (np.int64(tw) * np.int64(th))
+        np.testing.assert_array_equal(got, rows)
+        assert np.abs(rows / want - 1).max() < 5e-7
 
 
 def test_stage_sample_matches_reference(lib, golden):

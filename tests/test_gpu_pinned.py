@@ -13,7 +13,17 @@ N = 10 000, two observers + DEM term):
   flipped index would propagate to every later frame -- in both arithmetics (exact with host-fed draws, fast with the
   device streams);
 * at FULL size (C3: 4 096 x 5 000 x 100 frames) fast and exact arithmetic on one Philox stream: the posterior history
-  to 1e-9 and the number of differing record indices of the final state, reported and bounded."""
+  to 1e-9 and the number of differing record indices of the final state, reported and bounded.
+
+The SSD boundary.  cv2.matchTemplate is absent from the reference tree and from this image (parity
+unpinned there); OpenCV's formula does not fix the precision of the accumulation.  The oracle restates it twice
+(oracle/ssd.c): with a float64 accumulator (what the golden fixtures' stand-in does; the default of every other test)
+and with the kernels' float32-along-a-row accumulation.  The two surfaces agree to a few float32 ulps -- and that alone
+moves one resampling index every ~10-100 steps of a 5 000-particle filter (measured with the oracle against itself),
+after which the two runs are different random realisations.  Index-for-index equality over 100 frames is therefore
+asserted against the second restatement, which the kernels' surface equals bit for bit (tests/test_gpu_parity.py:
+test_stage_ssd_matches_oracle): what these tests pin is everything around the SSD -- draws, evolve, projection, search
+box, tile preparation, spline fit and sampling, weights, resampling, moments -- in the arithmetic bench.py times."""
 import functools
 
 import numpy as np
@@ -38,7 +48,11 @@ def _oracle_tracks(wl, frames, T, init, ev, us):
     from oracle import motion as omotion
     from oracle import tracker as otracker
 
-    observers = [otracker.Observer(list(frames[o][:T]), np.tile(wl.cams[o], (T, 1)), wl.sigmas[o]) for o in range(wl.O)]
+    # cv2.matchTemplate restated with the kernels' accumulation (float32 along a template row, float64 across rows:
+    # bit for bit the kernels' surface, tests/test_gpu_parity.py): OpenCV does not specify the accumulation, and one
+    # unit in the last place of a float32 surface value is enough to move an index once in ~10-100 steps
+    observers = [otracker.Observer(list(frames[o][:T]), np.tile(wl.cams[o], (T, 1)), wl.sigmas[o], ssd="row_f32")
+                 for o in range(wl.O)]
     matching = np.tile(np.arange(T)[:, None], (1, wl.O))
     means, sigmas, idx = [], [], []
     for p in range(wl.P):

@@ -9,6 +9,7 @@ cat > $OUT/one.hip <<EOT
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cmath>
+#define GLH_POINT_TU 1
 #include "$(cd "$(dirname "$0")/.." && pwd)/glimpse_amd/csrc/glh_point.h"
 template __global__ void glh::k_point_step<$TB, $PPT, 4, $NOBS, $SURF, $FAST, $CON>(glh::PointArgs);
 EOT
