@@ -836,25 +836,47 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
             }
           }
         } else {
+          // (the next particle's v is on its way from the scratch while this one is sampled)
+          double vn = V0[tid < N ? tid : 0];
 #pragma unroll 1
           for (int r = 0; r < rounds; ++r) {
             const int i = r * TB + tid;
-            if (i < N) c[i] = sample_one(make_double2(c[i], V0[i]));
+            const double v = vn;
+            vn = V0[i + TB < N ? i + TB : 0];
+            if (i < N) c[i] = sample_one(make_double2(c[i], v));
           }
         }
         c_ready = true;
         w_done = w_here;
-      } else {
+      } else if constexpr (NOBS > 1) {
         if (!c_ready) {  // observer 0 was skipped: c[] still holds its parked coordinates
           for (int i = tid; i < N; i += TB) c[i] = 0.0;
           c_ready = true;
         }
         // (the next particle's uv is on its way from the scratch while this one is sampled)
         double2 qn = uvp[tid < N ? tid : 0];
-        for (int i = tid; i < N; i += TB) {
-          const double2 q = qn;
-          qn = uvp[i + TB < N ? i + TB : 0];
-          c[i] += eval(q.x, q.y) * scale;
+        if (o == NOBS - 1) {
+          // the last observer: the motion model's term is appended and the weight taken in the same pass (same
+          // operations in the same order as the separate loop below, which then has nothing left to do)
+          const bool mterm = a.has_dem && motion_term;  // uniform
+          double wn = mterm ? W[tid < N ? tid : 0] : 0.0;
+          for (int i = tid; i < N; i += TB) {
+            const double2 q = qn;
+            const double wi = wn;
+            qn = uvp[i + TB < N ? i + TB : 0];
+            if (mterm) wn = W[i + TB < N ? i + TB : 0];
+            double ll = c[i];
+            ll += eval(q.x, q.y) * scale;
+            if (mterm) ll += wi;  // (tracker.py:143: appended last)
+            c[i] = weight_of<FAST>(ll, tab32);
+          }
+          w_done = true;
+        } else {
+          for (int i = tid; i < N; i += TB) {
+            const double2 q = qn;
+            qn = uvp[i + TB < N ? i + TB : 0];
+            c[i] += eval(q.x, q.y) * scale;
+          }
         }
       }
     };

@@ -28,6 +28,42 @@ def _sample(surface, xy):
     return np.full(len(xy), surface)
 
 
+def _columns(values, width):
+    """(len(values), width) float64 from per-model parameters (sequences of `width` numbers, or scalars that broadcast)."""
+    try:
+        a = np.concatenate(values)
+        if a.size == len(values) * width:
+            return a.reshape(len(values), width).astype(np.float64, copy=False)
+    except (ValueError, TypeError):
+        pass
+    return np.array([np.broadcast_to(np.asarray(v, dtype=np.float64), (width,)) for v in values])
+
+
+def params_table(models):
+    """[P][GLH_MOTION_FULL_LEN] table of glh_set_motion for a list of motion models: `fill_params` of every model,
+    column by column when all of them are Cartesian / Cylindrical models (thousands of rows per run: one NumPy
+    concatenation per parameter instead of a dozen slice assignments per model)."""
+    P = len(models)
+    table = np.zeros((P, 24))
+    if P and all(type(m) in (CartesianMotion, CylindricalMotion) for m in models):
+        rates = [m._rates() for m in models]
+        table[:, 0:2] = _columns([m.xy for m in models], 2)
+        table[:, 2:4] = _columns([m.xy_sigma for m in models], 2)
+        for k, (a, b) in enumerate(((4, 7), (7, 10), (10, 13), (13, 16))):
+            table[:, a:b] = _columns([r[k] for r in rates], 3)
+        dem, dem_sigma = [m.dem for m in models], [m.dem_sigma for m in models]
+        rd = np.fromiter((isinstance(d, Raster) for d in dem), dtype=bool, count=P)
+        rs = np.fromiter((isinstance(d, Raster) for d in dem_sigma), dtype=bool, count=P)
+        table[:, 16] = [0.0 if r else d for d, r in zip(dem, rd)]
+        table[:, 17] = [0.0 if r else d for d, r in zip(dem_sigma, rs)]
+        table[:, 18] = [m.KIND for m in models]
+        table[:, 20], table[:, 21] = rd, rs
+        return table
+    for row, model in zip(table, models):
+        model.fill_params(row)
+    return table
+
+
 class Motion:
     """Interface illustration (motion.py:13-89)."""
 

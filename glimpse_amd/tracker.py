@@ -20,7 +20,8 @@ import warnings as _warnings
 import numpy as np
 
 from . import _lib
-from .motion import CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion
+from .motion import (CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion,
+                     params_table)
 from .raster import Raster
 from .timeutil import _US, _offsets_us, nearest_in_sorted  # noqa: F401  (re-exported)
 from .tracks import Tracks
@@ -307,10 +308,7 @@ class Tracker:
             """The frame loop (tracker.py:326-357) for all tracks at once."""
             ctx.begin_sequence(ntracks, n, tile_size)
             self._upload_surfaces(ctx, motion_models)
-            table = np.zeros((ntracks, _lib.MOTION_FULL_LEN))
-            for row, model in zip(table, motion_models):
-                model.fill_params(row)
-            ctx.set_motion(table)
+            ctx.set_motion(params_table(motion_models))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
             ctx.set_point_offset(point_offset)
             # device-RNG runs have no reference stream to be bit-exact with: fast arithmetic (GLH_MATH_FAST)
