@@ -49,6 +49,24 @@ def _on_device(model):
     return type(model) in _DEVICE_MODELS
 
 
+def _batches(models):
+    """First index of every run of consecutive motion models that one device batch can hold: device models (`_on_device`)
+    with the same particle count and at most ONE gridded dem and ONE gridded dem_sigma among them (constant surfaces are
+    parameters of the point and mix freely); a user-defined model is a run of its own."""
+    starts, n, dem, sigma, device = [], None, None, None, False
+    for i, m in enumerate(models):
+        d = m.dem if isinstance(getattr(m, "dem", None), Raster) else None
+        s = m.dem_sigma if isinstance(getattr(m, "dem_sigma", None), Raster) else None
+        fits = (i > 0 and device and _on_device(m) and m.n == n
+                and (d is None or dem is None or d is dem) and (s is None or sigma is None or s is sigma))
+        if fits:
+            dem, sigma = dem if d is None else d, sigma if s is None else s
+        else:
+            starts.append(i)
+            n, dem, sigma, device = m.n, d, s, _on_device(m)
+    return starts
+
+
 def _vector24(img):
     """Camera vector of an Observer image: an Image's camera, or a Raster's own grid (observer.py:26)."""
     return img.cam.vector24 if hasattr(img, "cam") else img.vector24
@@ -215,12 +233,12 @@ class Tracker:
                 self._uploaded.add(job)
 
     def _upload_surfaces(self, ctx, motion_models):
-        """One gridded dem, one dem_sigma (shared by every model that uses a raster) and the viewshed."""
+        """One gridded dem, one dem_sigma (shared by every model of the batch that uses a raster: `_batches` splits the
+        tracks accordingly) and the viewshed."""
         for which, attr in ((_lib.RASTER_DEM, "dem"), (_lib.RASTER_DEM_SIGMA, "dem_sigma")):
             rasters = {id(getattr(m, attr)): getattr(m, attr) for m in motion_models
                        if isinstance(getattr(m, attr), Raster)}
-            if len(rasters) > 1:
-                raise NotImplementedError(f"all motion models must share one {attr} raster")
+            assert len(rasters) <= 1, "a batch shares one raster per surface"
             ctx.set_raster(which, next(iter(rasters.values())) if rasters else None)
         ctx.set_raster(_lib.RASTER_VIEWSHED, self.viewshed)
 
@@ -252,14 +270,22 @@ class Tracker:
                                         return_covariances=return_covariances, return_particles=return_particles,
                                         reduce_particles=reduce_particles, rng=rng, seed=seed, point_offset=point_offset)
         n = motion_models[0].n
-        if any(m.n != n for m in motion_models) or not all(_on_device(m) for m in motion_models):
-            # Motion models with different particle counts (each track of the reference has its own n,
-            # tracker.py:305-314): consecutive models with equal n form one batch, the batches run in order -- so
-            # the legacy np.random stream is consumed track after track like the reference -- and are merged.
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        # tracker.py:199-201 draws n - sum(repetitions) uniforms: how far the legacy global stream advances at every
+        # frame of a track depends on that track's weights, so the stream cannot be staged ahead for a batch of tracks
+        # -- with np.random the tracks then run one after another, like the reference runs them (the device RNG has no
+        # such coupling and keeps the batch)
+        serial = self.resample_method == "residual" and rng == "numpy"
+        if serial or len(_batches(motion_models)) > 1 or not _on_device(motion_models[0]):
+            # Motion models that cannot share one batch -- different particle counts (each track of the reference has
+            # its own n, tracker.py:305-314), their own dem / dem_sigma rasters (motion.py:136-141), user-defined
+            # models: consecutive compatible models form one batch, the batches run in order -- so the legacy
+            # np.random stream is consumed track after track like the reference -- and are merged.
             return self._track_runs(motion_models, params, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
                                     observer_mask=observer_mask, return_covariances=return_covariances,
                                     return_particles=return_particles, reduce_particles=reduce_particles, rng=rng,
-                                    seed=seed, point_offset=point_offset)
+                                    seed=seed, point_offset=point_offset, serial=serial)
         if datetimes is None:
             datetimes = self.datetimes
         else:
@@ -285,15 +311,6 @@ class Tracker:
         self._upload_images(ctx, matching)
         uniform = bool(observer_mask.all()) and bool((first == first[0]).all()) and bool((last == last[0]).all())
 
-        if rng not in ("numpy", "philox"):
-            raise ValueError("rng must be 'numpy' or 'philox'")
-        if self.resample_method == "residual" and rng == "numpy":
-            # tracker.py:199-201 draws n - sum(repetitions) uniforms: how far the legacy global stream advances at
-            # every frame of every track depends on that track's weights, so the stream cannot be staged ahead
-            # for a batch of tracks.  The device RNG has no such coupling; resample_particles("residual") (one
-            # track, one step) does follow np.random exactly.
-            raise NotImplementedError("resample_method='residual' with rng='numpy': use rng='philox', or the step "
-                                      "methods (resample_particles) for np.random parity")
         warn_log = [[] for _ in range(ntracks)]
         images_of = lambda i: [m if m is not None else -1 for m in matching[i]]  # noqa: E731
 
@@ -512,23 +529,20 @@ class Tracker:
             tracks.reduced = [r for part in parts for r in part["reduced"]]
         return tracks
 
-    def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0, **kw):
-        """Tracks that cannot share one batch: consecutive device models of equal n form a batch, every user-defined
-        model is a run of its own (`_track_custom`); the runs go in track order, so np.random is consumed like the
-        reference consumes it (one track after another), and are merged."""
+    def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0,
+                    serial=False, **kw):
+        """Tracks that cannot share one batch (`_batches`): consecutive compatible device models form a batch, every
+        user-defined model is a run of its own (`_track_custom`); the runs go in track order, so np.random is consumed
+        like the reference consumes it (one track after another), and are merged.  `serial`: every track is a run of
+        its own through the per-track loop (residual resampling on the np.random stream)."""
         ntracks = len(motion_models)
         if observer_mask is not None:
             observer_mask = np.asarray(observer_mask, dtype=bool)
-
-        def splits(i):
-            a, b = motion_models[i - 1], motion_models[i]
-            return a.n != b.n or not _on_device(a) or not _on_device(b)
-
-        bounds = [0] + [i for i in range(1, ntracks) if splits(i)] + [ntracks]
+        bounds = list(range(ntracks + 1)) if serial else _batches(motion_models) + [ntracks]
         parts = []
         for a, b in zip(bounds[:-1], bounds[1:]):
             mask = None if observer_mask is None else observer_mask[a:b]
-            if not _on_device(motion_models[a]):
+            if serial or not _on_device(motion_models[a]):
                 parts.append(self._track_custom(motion_models[a], None if mask is None else mask[0],
                                                 reduce_particles=reduce_particles, catch_errors=ntracks >= 2, **kw))
             else:

@@ -53,7 +53,7 @@ def choice(weights, u):
     return np.searchsorted(cdf, np.asarray(u, dtype=float), side="right")
 
 
-METHODS = {"systematic": systematic, "stratified": stratified, "choice": choice}
+METHODS = {"systematic": systematic, "stratified": stratified, "residual": residual, "choice": choice}
 
 
 def particle_mean(particles, weights):

@@ -186,7 +186,12 @@ def track_one(
                 else:
                     # one uniform (systematic) or n of them (stratified; np.random.choice draws its n
                     # uniforms from the same global stream)
-                    u = np.random.random() if resample_method == "systematic" else np.random.random(n)
+                    if resample_method == "systematic":
+                        u = np.random.random()
+                    elif resample_method == "residual":
+                        u = np.random.random  # tracker.py:199-201 draws n - sum(repetitions) uniforms: known inside
+                    else:
+                        u = np.random.random(n)
                     if draws is not None:
                         draws["u"].append(u)
                 idx = resample.METHODS[resample_method](weights, u)

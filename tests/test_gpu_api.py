@@ -119,8 +119,8 @@ def test_philox_tracking_recovers_velocity(golden):
 
 @pytest.mark.parametrize("method", ["stratified", "residual", "choice"])
 def test_philox_tracking_with_the_other_resampling_methods(golden, method):
-    """Every resampling method of tracker.py:151-223 drives a whole run on the device RNG; residual resampling
-    with the np.random stream is refused for batches (its draw count per frame depends on the weights)."""
+    """Every resampling method of tracker.py:151-223 drives a whole run on the device RNG (residual resampling on
+    the np.random stream: test_tracker_api_variants_reproduce_reference)."""
     g = golden("g8_c2mini.npz")
     tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128, resample_method=method)
     models = models_from(g)[:3]
@@ -131,19 +131,19 @@ def test_philox_tracking_with_the_other_resampling_methods(golden, method):
     v = tracks.vxyz[:, -1]
     assert np.all(np.abs(v[:, 0] - 0.15) < 0.06), v
     assert np.all(np.abs(v[:, 1]) < 0.06), v
-    if method == "residual":
-        with pytest.raises(NotImplementedError, match="philox"):
-            tracker.track(models, tile_size=(15, 15))
 
 
 @pytest.mark.parametrize("name,tracker_kw,track_kw", [
     ("g9_cov.npz", {}, dict(return_covariances=True)),
     ("g9_stratified.npz", dict(resample_method="stratified"), {}),
     ("g9_choice.npz", dict(resample_method="choice"), {}),
+    # residual resampling on the legacy stream (tracker.py:188-203): every step of every track draws a weight-dependent
+    # number of uniforms, so the tracks run one after another through the per-track loop, like the reference's
+    ("g22_residual.npz", dict(resample_method="residual"), {}),
 ])
 def test_tracker_api_variants_reproduce_reference(golden, name, tracker_kw, track_kw):
-    """return_covariances (tracker.py:307-308, :352) and resample_method='stratified' / 'choice'
-    (tracker.py:178-186, :205-209) against reference runs with the same seed."""
+    """return_covariances (tracker.py:307-308, :352) and resample_method='stratified' / 'choice' / 'residual'
+    (tracker.py:178-209) against reference runs with the same seed."""
     g = golden(name)
     tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128, **tracker_kw)
     np.random.seed(int(g["seed"]))
@@ -324,6 +324,38 @@ def test_gridded_surfaces_end_to_end(golden):
         np.testing.assert_allclose(tracks.sigmas[ok], g[f"{name}_sigmas"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.particles[ok], g[f"{name}_particles"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.weights[ok], g[f"{name}_weights"][ok], rtol=RTOL, atol=1e-290)
+
+
+def test_motion_models_with_their_own_rasters(golden):
+    """Every motion model may carry its OWN dem / dem_sigma rasters (motion.py:136-141).  A device context holds one
+    raster per surface, so consecutive models that share theirs form a batch (constant surfaces mix freely) and the
+    batches run in track order -- np.random is consumed like the reference consumes it: same seed, same tracks."""
+    import datetime
+
+    from glimpse_amd.tracker import _batches
+    from tests.helpers_api import camera_from
+
+    g = golden("g22_rasters.npz")
+    t0, day = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    images = [glimpse_amd.Image("synthetic", cam=camera_from(g["cam"]), datetime=t0 + i * day, array=g["frames"][i])
+              for i in range(len(g["frames"]))]
+    R = lambda key: glimpse_amd.Raster(g[key], x=g["xlim"], y=g["ylim"])  # noqa: E731
+    dem, sig = {"a": R("dem_a"), "b": R("dem_b")}, {"a": R("sigma_a"), "b": R("sigma_b")}
+    cart = dict(time_unit=day, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02),
+                axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01))
+    models = [glimpse_amd.CartesianMotion(xy=xy, dem=0.1 if k == "s" else dem[k], dem_sigma=0.25 if k == "s" else sig[k],
+                                          **cart) for xy, k in zip(g["xy"], g["kinds"])]
+    assert list(g["kinds"]) == ["a", "a", "b", "s", "a"] and _batches(models) == [0, 2, 4]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    np.random.seed(int(g["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.particles, g["particles"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.weights, g["weights"], rtol=RTOL, atol=1e-290)
 
 
 def test_orthophoto_observer_on_the_device(golden):

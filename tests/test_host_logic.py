@@ -309,3 +309,27 @@ def test_observer_image_cache_helpers(tmp_path):
     np.testing.assert_array_equal(images[1].array, frames[1])
     obs.clear_images(slice(1, None))
     assert images[0].array is not None and images[1].array is None and images[2].array is None
+
+
+def test_batches_of_motion_models():
+    """Which consecutive motion models one device batch can hold (glimpse_amd.tracker._batches): equal particle counts, at
+    most one gridded dem and one gridded dem_sigma (constant surfaces mix freely), user-defined models alone."""
+    import datetime
+
+    import glimpse_amd as g
+    from glimpse_amd.tracker import _batches
+    from tests.custom_motion import DriftMotion
+
+    day = datetime.timedelta(days=1)
+    A, B = g.Raster(np.zeros((4, 4)), x=(0, 4), y=(4, 0)), g.Raster(np.ones((4, 4)), x=(0, 4), y=(4, 0))
+
+    def cart(dem=0.0, sigma=0.1, n=100):
+        return g.CartesianMotion(xy=(1, 1), time_unit=day, dem=dem, dem_sigma=sigma, n=n)
+
+    assert _batches([cart(), cart(), cart()]) == [0]
+    assert _batches([cart(n=100), cart(n=200), cart(n=200)]) == [0, 1]
+    assert _batches([cart(A), cart(), cart(A), cart(B), cart(B, A), cart(sigma=B)]) == [0, 3, 5]
+    assert _batches([cart(), cart(A), cart(sigma=A), cart(A, A), cart(sigma=B)]) == [0, 4]
+    custom = DriftMotion.__new__(DriftMotion)
+    custom.n = 100
+    assert _batches([cart(), custom, cart(), cart()]) == [0, 1, 2]

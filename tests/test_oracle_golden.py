@@ -197,10 +197,12 @@ def test_ssd_c_matches_numpy():
 
 @pytest.mark.parametrize("name,kw", [("g9_cov.npz", dict(return_covariances=True)),
                                      ("g9_stratified.npz", dict(resample_method="stratified")),
-                                     ("g9_choice.npz", dict(resample_method="choice"))])
+                                     ("g9_choice.npz", dict(resample_method="choice")),
+                                     ("g22_residual.npz", dict(resample_method="residual"))])
 def test_api_variants_match_reference(golden, name, kw):
-    """Covariance output and the stratified / choice resampling methods, end to end with the oracle
-    consuming the legacy global stream from the reference's seed."""
+    """Covariance output and the stratified / choice / residual resampling methods, end to end with the oracle
+    consuming the legacy global stream from the reference's seed (residual: a weight-dependent number of uniforms per
+    step, tracker.py:199-201)."""
 
     g = golden(name)
     np.random.seed(int(g["seed"]))
@@ -313,6 +315,26 @@ def test_gridded_surfaces_end_to_end_match_reference(golden):
         np.testing.assert_allclose(res["means"][ok], g[f"{name}_means"][ok], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(res["sigmas"][ok], g[f"{name}_sigmas"][ok], rtol=1e-9, atol=1e-14)
         assert np.isnan(res["means"][errors]).all()
+
+
+def test_motion_models_with_their_own_rasters_match_reference(golden):
+    """Five tracks whose motion models carry different dem / dem_sigma rasters (motion.py:136-141)."""
+    from oracle import raster as oraster
+
+    g = golden("g22_rasters.npz")
+    T = len(g["frames"])
+    R = lambda key: oraster.Raster(g[key], x=g["xlim"], y=g["ylim"])  # noqa: E731
+    dem, sig = {"a": R("dem_a"), "b": R("dem_b")}, {"a": R("sigma_a"), "b": R("sigma_b")}
+    cart = dict(n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02), axyz=(0, 0, 0),
+                axyz_sigma=(0.05, 0.05, 0.01))
+    models = [motion.CartesianMotion(xy=xy, dem=0.1 if k == "s" else dem[k], dem_sigma=0.25 if k == "s" else sig[k], **cart)
+              for xy, k in zip(g["xy"], g["kinds"])]
+    observers = [tracker.Observer(list(g["frames"]), np.tile(g["cam"], (T, 1)), 0.3)]
+    np.random.seed(int(g["seed"]))
+    res = tracker.track(models, observers, np.arange(T)[:, None], np.ones(T - 1), tile_size=(15, 15))
+    assert all(e is None for e in res["errors"])
+    np.testing.assert_allclose(res["means"], g["means"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["sigmas"], g["sigmas"], rtol=1e-9, atol=1e-14)
 
 
 def test_orthophoto_observer_matches_reference(golden):

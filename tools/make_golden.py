@@ -407,8 +407,11 @@ def run_e2e(name, cams_per_obs, frames_per_obs, sigmas, models_kw, tile_size, se
         out[f"randn{i}"] = r
     if all(np.size(r) == 1 for r in rec.random):
         out["random"] = np.array([float(r) for r in rec.random])
-    else:  # stratified resampling draws random(n) per step
+    elif len({np.size(r) for r in rec.random}) == 1:  # stratified resampling draws random(n) per step
         out["random_n"] = np.stack([np.asarray(r, dtype=float) for r in rec.random])
+    else:  # residual resampling draws n - sum(repetitions) uniforms per step
+        out["random_counts"] = np.array([np.size(r) for r in rec.random])
+        out["random_flat"] = np.concatenate([np.ravel(np.asarray(r, dtype=float)) for r in rec.random])
     out["resample_method"] = resample_method
     # per-step traces; steps are grouped per track in order
     out["track_starts"] = np.array(rec.track_starts)
@@ -650,6 +653,48 @@ def g12_rasters():
     run("view", [glimpse.CartesianMotion(xy=xy, dem=0.0, dem_sigma=0.3, **cart) for xy in [(0.5, -0.5), (3.5, 1.0)]],
         1303, viewshed=viewshed)
     np.savez_compressed(os.path.join(OUT, "g12_raster_e2e.npz"), **e)
+
+
+def g22_variants():
+    """Two inputs the reference accepts that need their own batching on the device: (a) resample_method='residual'
+    with the legacy np.random stream for several tracks (tracker.py:188-203: every step of every track draws
+    n - sum(repetitions) uniforms, so the stream position of a track depends on the weights of the tracks before it);
+    (b) motion models that each carry their OWN dem / dem_sigma rasters (motion.py:136-141)."""
+    cam = synth.nadir_camera((192, 192), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    frames, _ = synth.make_sequence(cam, 5, seed=21, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam, 3, border_px=70.0, seed=4)
+    kws = [dict(xy=tuple(p), dem=0.0, dem_sigma=0.3, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0),
+                vxyz_sigma=(0.2, 0.2, 0.02), axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01)) for p in pts]
+    tr = run_e2e("g22_residual.npz", [[cam] * 5], [frames], [0.3], kws, (15, 15), seed=2201, resample_method="residual")
+    print("g22_residual vx:", tr.means[:, -1, 3])
+
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(5)]
+    xlim, ylim = (-6.0, 6.0), (6.0, -6.0)
+    Za, Zb = 0.1 * _dem_field(24, 24, xlim, ylim, 17), 0.3 + 0.1 * _dem_field(16, 20, xlim, ylim, 18)
+    Sa, Sb = 0.2 + 0.05 * np.abs(_dem_field(24, 24, xlim, ylim, 19)), 0.4 + 0.02 * np.abs(_dem_field(12, 12, xlim, ylim, 20))
+    R = lambda Z: glimpse.Raster(Z, x=xlim, y=ylim)  # noqa: E731
+    cart = dict(time_unit=day, n=150, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.02),
+                axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.01))
+    # five tracks: rasters A, A, B (both surfaces differ), scalar surfaces, A again
+    spec = [((0.5, -0.5), "a"), ((-2.0, 1.5), "a"), ((1.0, 1.0), "b"), ((-1.0, -1.5), "s"), ((2.0, -1.0), "a")]
+    dem = {"a": R(Za), "b": R(Zb)}
+    sig = {"a": R(Sa), "b": R(Sb)}
+    models = [glimpse.CartesianMotion(xy=xy, dem=0.1 if k == "s" else dem[k], dem_sigma=0.25 if k == "s" else sig[k], **cart)
+              for xy, k in spec]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+    np.random.seed(2202)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert all(e is None for e in tracks.errors)
+    e = {"frames": np.stack(frames), "cam": cam, "xlim": np.array(xlim), "ylim": np.array(ylim), "dem_a": Za, "dem_b": Zb,
+         "sigma_a": Sa, "sigma_b": Sb, "xy": np.array([xy for xy, _ in spec]), "kinds": np.array([k for _, k in spec]),
+         "seed": 2202, "means": tracks.means, "sigmas": tracks.sigmas, "particles": tracks.particles,
+         "weights": tracks.weights}
+    print("g22_rasters vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g22_rasters.npz"), **e)
 
 
 def g13_ortho():
@@ -1022,6 +1067,9 @@ def g21_bilinear():
 
 
 if __name__ == "__main__":
+    if "--g22" in sys.argv:
+        g22_variants()
+        sys.exit(0)
     if "--g21" in sys.argv:
         g21_bilinear()
         sys.exit(0)
