@@ -79,23 +79,28 @@ def up_to_date():
     return not _newer(LIB, DEPS)
 
 
-def _jobs(extra):
+def _jobs(extra, objdir=OBJDIR):
     """[(object, command, dependencies)]"""
     cc = hipcc()
-    jobs = [(os.path.join(OBJDIR, "glimpse_hip.o"), [cc, *FLAGS, *extra, "-c", SRC], [SRC, *HEADERS, *HOST_HEADERS])]
+    jobs = [(os.path.join(objdir, "glimpse_hip.o"), [cc, *FLAGS, *extra, "-c", SRC], [SRC, *HEADERS, *HOST_HEADERS])]
     for tb, ppt, nobs, s, f, c in variants():
-        obj = os.path.join(OBJDIR, f"pt_{tb}_{ppt}_{nobs}_{s}{f}{c}.o")
+        obj = os.path.join(objdir, f"pt_{tb}_{ppt}_{nobs}_{s}{f}{c}.o")
         defs = [f"-DPT_TB={tb}", f"-DPT_PPT={ppt}", f"-DPT_NOBS={nobs}", f"-DPT_SURF={s}", f"-DPT_FAST={f}",
                 f"-DPT_CON={c}"]
         jobs.append((obj, [cc, *FLAGS, *extra, *defs, "-c", INST], [INST, *HEADERS]))
     return jobs
 
 
-def build(force=False, verbose=True, extra=(), workers=None):
+def build(force=False, verbose=True, extra=(), workers=None, out=None):
+    """`out`: build an experimental variant (extra compiler flags) under another name, glimpse_amd/lib/<out>.so, with its
+    own object directory -- tools/ab.sh runs such libraries side by side (GLH_LIB)."""
+    lib, objdir = LIB, OBJDIR
+    if out:
+        lib, objdir, force = os.path.join(LIBDIR, out + ".so"), os.path.join(LIBDIR, "obj_" + out), True
     if not force and up_to_date():
         return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
-    jobs = _jobs(list(extra))
+    os.makedirs(objdir, exist_ok=True)
+    jobs = _jobs(list(extra), objdir)
     todo = [(obj, cmd) for obj, cmd, deps in jobs if force or _newer(obj, deps)]
     if workers is None:
         workers = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("GLH_BUILD_JOBS", "8"))))
@@ -114,11 +119,11 @@ def build(force=False, verbose=True, extra=(), workers=None):
                 raise RuntimeError(f"hipcc failed for {os.path.basename(obj)}")
             if verbose and r.stderr.strip():
                 sys.stderr.write(r.stderr)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *[obj for obj, _, _ in jobs]]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *[obj for obj, _, _ in jobs]]
     if verbose:
         print(" ".join(cmd[:6]) + f" ... ({len(jobs)} objects)", flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) K[k] = s_K[k];
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-  constexpr int GU = 2;
+  constexpr int GU = TB >= 1024 ? 3 : 2;  // records in flight per thread (a 16-wave workgroup has its CU to itself: nothing else hides the gather latency; 4 spill)
   for (int h0 = tid; h0 < U; h0 += GU * TB) {
     int lo[GU], cnt[GU];
     double x[GU][6], w[GU];
