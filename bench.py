@@ -382,7 +382,7 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
         q = wl.params[p]
         models.append(g.CartesianMotion(xy=q[0:2], time_unit=unit, dem=q[16], dem_sigma=q[17], n=wl.N, xy_sigma=q[2:4],
                                         vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13], axyz_sigma=q[13:16]))
-    tracker = g.Tracker(observers, device=device, max_search_dim=max_search_dim)
+    tracker = g.Tracker(observers, device=device)  # (workspaces sized from the prior: the API's default)
     t_setup = time.perf_counter() - t00
     t0 = time.perf_counter()
     tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)

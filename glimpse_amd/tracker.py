@@ -93,8 +93,10 @@ def _parallel_worker(job):
 
 class Tracker:
     def __init__(self, observers, viewshed=None, resample_method="systematic", highpass={"size": (5, 5)},  # noqa: B006
-                 interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=320):  # noqa: B006
-        """tracker.py:52-70 (+ `device`, `max_search_dim`: GPU ordinal and search-tile workspace)."""
+                 interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=None):  # noqa: B006
+        """tracker.py:52-70 (+ `device`: GPU ordinal; `max_search_dim`: side of the per-point search-tile workspaces in
+        pixels -- None sizes them from the prior's projected spread and re-runs the sequence with larger ones if a
+        search tile outgrows them, so the result never depends on the guess)."""
         self.observers = list(observers)
         if viewshed is not None and not isinstance(viewshed, Raster):
             raise TypeError("viewshed must be a glimpse_amd.Raster")
@@ -180,15 +182,15 @@ class Tracker:
         return matches
 
     # ---- device context ---------------------------------------------------------------------
-    def _context(self, n_points, n_particles, n_frames, tile_size):
+    def _context(self, n_points, n_particles, n_frames, tile_size, search_dim):
         O = len(self.observers)
-        key = (n_points, n_particles, n_frames, max(tile_size))
+        key = (n_points, n_particles, n_frames, max(tile_size), search_dim)
         if self._ctx is not None and self._ctx_key == key:
             return self._ctx
         if self._ctx is not None:
             self._ctx.close()
         ctx = _lib.Context(n_points, n_particles, O, device_id=self.device, max_tile=max(31, max(tile_size)),
-                           max_search_dim=self.max_search_dim, max_frames=n_frames)
+                           max_search_dim=search_dim, max_frames=n_frames)
         for o, obs in enumerate(self.observers):
             first = obs.images[0].read()
             if first.dtype not in (np.uint8, np.uint16, np.float64) or (first.dtype == np.float64 and first.ndim != 2):
@@ -204,6 +206,44 @@ class Tracker:
         self._ctx, self._ctx_key = ctx, key
         self._uploaded = set()
         return ctx
+
+    def _estimate_search_dim(self, motion_models, matching, taus, tile_size):
+        """Side (pixels) of the search-tile workspaces a run is likely to need: the template plus five standard
+        deviations on either side of the particle cloud at its widest -- the prior, widened by a few frames of free
+        drift (the filter needs a few updates to pin the velocity down) -- projected through every observer's camera.
+        A guess, not a bound: `track` re-runs with larger workspaces when a search tile outgrows it."""
+        free = 4.0 * (float(np.max(np.abs(taus))) if len(taus) else 1.0)  # time units of unconstrained drift
+        t = params_table(motion_models)
+        v, vs, a, as_, kind = t[:, 4:7], t[:, 7:10], t[:, 10:13], t[:, 13:16], t[:, 18]
+        polar = (kind == CylindricalMotion.KIND) | (kind == TangentCylindricalMotion.KIND)
+        sv = np.where(polar, np.hypot(vs[:, 0], np.abs(v[:, 0]) * vs[:, 1]), np.maximum(vs[:, 0], vs[:, 1]))
+        sa = np.where(polar, np.hypot(as_[:, 0], np.abs(a[:, 0]) * as_[:, 1]), np.maximum(as_[:, 0], as_[:, 1]))
+        s_h = np.sqrt(np.max(t[:, 2:4], axis=1) ** 2 + (free * sv) ** 2 + (0.5 * free ** 2 * sa) ** 2)
+        s_z = np.sqrt(t[:, 17] ** 2 + (free * (vs[:, 2] + t[:, 19] * sv)) ** 2 + (0.5 * free ** 2 * as_[:, 2]) ** 2)
+        z0 = t[:, 16].copy()
+        for p, m in enumerate(motion_models):
+            if isinstance(m.dem, Raster):
+                z = m.dem.sample(np.atleast_2d(np.asarray(m.xy, dtype=float)), bounds_error=False)[0]
+                z0[p] = z if np.isfinite(z) else 0.0
+            if isinstance(m.dem_sigma, Raster):
+                z = m.dem_sigma.sample(np.atleast_2d(np.asarray(m.xy, dtype=float)), bounds_error=False)[0]
+                s_z[p] = np.hypot(s_z[p], z if np.isfinite(z) else 0.0)
+        P = len(motion_models)
+        base = np.column_stack((t[:, 0:2], z0))
+        pts = np.concatenate((base, base + np.column_stack((s_h, np.zeros(P), np.zeros(P))),
+                              base + np.column_stack((np.zeros(P), s_h, np.zeros(P))),
+                              base + np.column_stack((np.zeros(P), np.zeros(P), s_z))))
+        spread = 0.0
+        for o, obs in enumerate(self.observers):
+            imgs = [m for m in matching[:, o] if m is not None]
+            if not imgs:
+                continue
+            uv = _lib.stage_project(_vector24(obs.images[int(imgs[0])]), pts, device_id=self.device).reshape(4, P, 2)
+            sigma_px = np.sqrt(((uv[1:] - uv[0]) ** 2).sum(axis=0))  # (P, 2)
+            if np.isfinite(sigma_px).any():
+                spread = max(spread, float(np.nanmax(sigma_px)))
+        dim = max(tile_size) + 2 * 5.0 * spread + 8
+        return int(min(2000, max(max(tile_size) + 16, 16 * np.ceil(dim / 16))))
 
     def _upload_images(self, ctx, matching):
         """Frames the run will touch -> HBM, once.  Images that still live in files are decoded by a thread pool
@@ -307,8 +347,13 @@ class Tracker:
         empty = ~observed.any(axis=1)
         first[empty], last[empty] = 0, -1
 
-        ctx = self._context(ntracks, n, ntimes, tile_size)
+        # search-tile workspaces: the caller's size, or a guess from the prior that grows (and re-runs) on demand
+        dim = self.max_search_dim
+        if dim is None:
+            dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), getattr(self, "_grown_dim", 0))
+        ctx = self._context(ntracks, n, ntimes, tile_size, dim)
         self._upload_images(ctx, matching)
+        outgrown = [False]  # a search tile did not fit the workspaces (this attempt)
         uniform = bool(observer_mask.all()) and bool((first == first[0]).all()) and bool((last == last[0]).all())
 
         warn_log = [[] for _ in range(ntracks)]
@@ -339,8 +384,9 @@ class Tracker:
                     for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
                         warn_log[p].append(UserWarning(_OOB_WARNING))
                     for p in np.nonzero(running & (status[o] == _lib.OBS_TILE_TOO_LARGE))[0]:
+                        outgrown[0] = True
                         warn_log[p].append(RuntimeWarning(
-                            f"search tile exceeds max_search_dim={self.max_search_dim}; observer {o} skipped"))
+                            f"search tile exceeds max_search_dim={dim}; observer {o} skipped"))
 
             def common(i):
                 """Every track is running and no template starts at frame i: ONE fused launch does evolve +
@@ -410,31 +456,19 @@ class Tracker:
                 i += 1
             return out_p, out_w, ctx.point_status(), ctx.point_error_frame()
 
-        if rng == "philox":
-            out_particles, out_weights, status, err_frame = run(None)
-        else:
-            # The reference stops drawing for a track at the frame where it fails, which shifts
-            # the stream of the tracks after it: replay until the assumed consumption is consistent.
-            state0 = np.random.get_state()
-            stops = np.stack((last, last, last), axis=1)
-            for _ in range(ntracks + 1):
-                np.random.set_state(state0)
-                draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic,
-                                         models=motion_models)
-                out_particles, out_weights, status, err_frame = run(draws)
-                new_stops = np.stack((last, last, last), axis=1)
-                for p in np.nonzero(status)[0]:
-                    e = int(err_frame[p])
-                    # a dem / dem_sigma raster that does not cover the initial positions raises inside
-                    # initialize_particles right after randn(n, 2) (motion.py:158): nothing else is drawn
-                    gridded = isinstance(motion_models[p].dem, Raster) or isinstance(motion_models[p].dem_sigma, Raster)
-                    if e == first[p] and status[p] & _lib.PT_RASTER_OOB and gridded:
-                        new_stops[p, 2] = -1
-                    new_stops[p, 0] = e
-                    new_stops[p, 1] = e if (status[p] & _lib.PT_RESAMPLE_CLAMP and not status[p] & 0x77) else e - 1
-                if (new_stops == stops).all():
-                    break
-                stops = new_stops
+        state0 = np.random.get_state() if rng == "numpy" else None
+        while True:
+            outgrown[0] = False
+            out_particles, out_weights, status, err_frame = self._attempt(run, rng, state0, ntracks, n, first, last,
+                                                                          systematic, motion_models)
+            if not outgrown[0] or self.max_search_dim is not None or dim >= 2000:
+                break
+            # an automatic workspace was too small for some search tile (that observer was skipped on that frame):
+            # nothing of this attempt is kept -- same draws, larger workspaces
+            dim = min(2000, 2 * dim)
+            self._grown_dim = dim
+            ctx = self._context(ntracks, n, ntimes, tile_size, dim)
+            self._upload_images(ctx, matching)
 
         means, sigmas = ctx.get_tracks(0, ntimes)  # (P, T, 6) each, laid out on the device
         covariances = None
@@ -469,6 +503,34 @@ class Tracker:
         if reduce_particles:
             tracks.reduced = [reduce_particles(out_particles[p], out_weights[p]) for p in range(ntracks)]
         return tracks
+
+    def _attempt(self, run, rng, state0, ntracks, n, first, last, systematic, motion_models):
+        """One pass over the sequence: `run(None)` on the device RNG, or the replay loop on the np.random stream."""
+        if rng == "philox":
+            return run(None)
+        # The reference stops drawing for a track at the frame where it fails, which shifts
+        # the stream of the tracks after it: replay until the assumed consumption is consistent.
+        stops = np.stack((last, last, last), axis=1)
+        for _ in range(ntracks + 1):
+            np.random.set_state(state0)
+            draws = self._draw_numpy(ntracks, n, first, last, stops, per_particle_u=not systematic,
+                                     models=motion_models)
+            out = run(draws)
+            status, err_frame = out[2], out[3]
+            new_stops = np.stack((last, last, last), axis=1)
+            for p in np.nonzero(status)[0]:
+                e = int(err_frame[p])
+                # a dem / dem_sigma raster that does not cover the initial positions raises inside
+                # initialize_particles right after randn(n, 2) (motion.py:158): nothing else is drawn
+                gridded = isinstance(motion_models[p].dem, Raster) or isinstance(motion_models[p].dem_sigma, Raster)
+                if e == first[p] and status[p] & _lib.PT_RASTER_OOB and gridded:
+                    new_stops[p, 2] = -1
+                new_stops[p, 0] = e
+                new_stops[p, 1] = e if (status[p] & _lib.PT_RESAMPLE_CLAMP and not status[p] & 0x77) else e - 1
+            if (new_stops == stops).all():
+                break
+            stops = new_stops
+        return out
 
     # ---- parallel=N: N worker processes, one GPU each (the reference's process pool, tracker.py:381-387) ----------
     @staticmethod
@@ -677,7 +739,7 @@ class Tracker:
                 self._sctx.close()
             O = len(self.observers)
             ctx = _lib.Context(1, n, O, device_id=self.device, max_tile=max(31, max(tile)),
-                               max_search_dim=self.max_search_dim, max_frames=2)
+                               max_search_dim=self.max_search_dim or 320, max_frames=2)
             for o, obs in enumerate(self.observers):
                 a0 = obs.images[0].read()
                 if a0.dtype not in (np.uint8, np.uint16, np.float64) or (a0.dtype == np.float64 and a0.ndim != 2):

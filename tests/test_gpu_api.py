@@ -698,3 +698,32 @@ def test_tracking_with_bilinear_interpolation_reproduces_reference(golden, tag):
         glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 1})
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 3, "s": 0.1})
+
+
+def test_search_workspaces_size_themselves(golden, monkeypatch):
+    """Tracker(max_search_dim=None), the default: the per-point search-tile workspaces are sized from the prior's
+    projected spread, and a run whose search tiles outgrow them is repeated with larger ones (same draws) -- the tracks
+    never depend on the guess.  Forced here by a guess that is far too small."""
+    g = golden("g8_c2mini.npz")
+    tile = tuple(int(v) for v in g["tile_size"])
+
+    def run(**kw):
+        tracker = glimpse_amd.Tracker(observers_from(g), **kw)
+        np.random.seed(int(g["seed"]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models_from(g), tile_size=tile, return_particles=True)
+        return tracker, tracks
+
+    _, explicit = run(max_search_dim=128)
+    tracker, auto = run()
+    assert tracker._ctx_key[-1] % 16 == 0 and tile[0] + 16 <= tracker._ctx_key[-1] <= 128
+    monkeypatch.setattr(glimpse_amd.Tracker, "_estimate_search_dim", lambda self, *a: max(tile) + 16)
+    tracker, grown = run()
+    assert tracker._ctx_key[-1] > max(tile) + 16  # the first attempt overflowed and was repeated
+    for tracks in (auto, grown):
+        assert [e is None for e in tracks.errors] == [e is None for e in explicit.errors]
+        np.testing.assert_array_equal(tracks.means, explicit.means)
+        np.testing.assert_array_equal(tracks.particles, explicit.particles)
+        assert all(w is None or not any("max_search_dim" in str(x) for x in w) for w in tracks.warnings)
+    np.testing.assert_allclose(auto.means[:3], g["means"][:3], rtol=RTOL, atol=1e-8)
