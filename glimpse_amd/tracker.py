@@ -238,10 +238,13 @@ class Tracker:
             imgs = [m for m in matching[:, o] if m is not None]
             if not imgs:
                 continue
-            uv = _lib.stage_project(_vector24(obs.images[int(imgs[0])]), pts, device_id=self.device).reshape(4, P, 2)
+            cam = _vector24(obs.images[int(imgs[0])])
+            uv = _lib.stage_project(cam, pts, device_id=self.device).reshape(4, P, 2)
             sigma_px = np.sqrt(((uv[1:] - uv[0]) ** 2).sum(axis=0))  # (P, 2)
-            if np.isfinite(sigma_px).any():
-                spread = max(spread, float(np.nanmax(sigma_px)))
+            # (a point that starts outside the image has no template: its track fails whatever the workspaces)
+            seen = (uv[0] >= 0).all(axis=1) & (uv[0] <= cam[6:8]).all(axis=1) & np.isfinite(sigma_px).all(axis=1)
+            if seen.any():
+                spread = max(spread, float(sigma_px[seen].max()))
         dim = max(tile_size) + 2 * 5.0 * spread + 8
         return int(min(2000, max(max(tile_size) + 16, 16 * np.ceil(dim / 16))))
 
