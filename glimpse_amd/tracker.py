@@ -353,7 +353,8 @@ class Tracker:
         # search-tile workspaces: the caller's size, or a guess from the prior that grows (and re-runs) on demand
         dim = self.max_search_dim
         if dim is None:
-            dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), getattr(self, "_grown_dim", 0))
+            dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), getattr(self, "_grown_dim", 0),
+                      max(31, max(tile_size)) + 16)
         ctx = self._context(ntracks, n, ntimes, tile_size, dim)
         self._upload_images(ctx, matching)
         outgrown = [False]  # a search tile did not fit the workspaces (this attempt)

@@ -26,11 +26,11 @@ for o in range(wl.O):
     observers.append(g.Observer(images, sigma=wl.sigmas[o]))
 models = [g.CartesianMotion(xy=q[0:2], time_unit=unit, dem=q[16], dem_sigma=q[17], n=wl.N, xy_sigma=q[2:4], vxyz=q[4:7],
                             vxyz_sigma=q[7:10], axyz=q[10:13], axyz_sigma=q[13:16]) for q in wl.params]
-tracker = g.Tracker(observers, max_search_dim=320)
+tracker = g.Tracker(observers)
 tracker.track(models, tile_size=wl.tile, rng="philox", seed=1)
 t0 = time.perf_counter()
 tracker.track(models, tile_size=wl.tile, rng="philox", seed=1)
-print("warm call", time.perf_counter() - t0)
+print("warm call", time.perf_counter() - t0, "workspace side", tracker._ctx_key[-1], "grown", getattr(tracker, "_grown_dim", None))
 pr = cProfile.Profile()
 pr.enable()
 tracker.track(models, tile_size=wl.tile, rng="philox", seed=1)
