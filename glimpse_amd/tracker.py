@@ -352,7 +352,9 @@ class Tracker:
 
         # search-tile workspaces: the caller's size, or a guess from the prior that grows (and re-runs) on demand
         dim = self.max_search_dim
-        if dim is None:
+        if dim is None and self._ctx is not None and self._ctx_key[:4] == (ntracks, n, ntimes, max(tile_size)):
+            dim = self._ctx_key[4]  # the workspaces that served the last run of this shape
+        elif dim is None:
             dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), getattr(self, "_grown_dim", 0),
                       max(31, max(tile_size)) + 16)
         ctx = self._context(ntracks, n, ntimes, tile_size, dim)
