@@ -233,3 +233,19 @@ def test_highpass_window_sizes_match_reference(lib, golden):
         lib.stage_template(frames["gray"][0], tbox, highpass=(4, 4))
     with pytest.raises(lib.GlhError):
         lib.stage_template(frames["gray"][0], tbox, highpass=(9, 9))
+
+
+def test_depth_limits_are_refused_up_front(lib):
+    """glh_observer_set_depth refuses the combinations its tile kernels cannot serve (their LDS requests grow with the
+    context's limits) instead of failing every launch later: 16-bit frames beyond a 1117-pixel search workspace, float64
+    frames with templates beyond 73 pixels."""
+    with lib.Context(2, 64, 1, max_tile=31, max_search_dim=1500, max_frames=2) as ctx:
+        ctx.observer_init(0, 2, 64, 64, 1, 0.3)
+        with pytest.raises(lib.GlhError, match="16-bit frames"):
+            ctx.observer_set_depth(0, np.uint16)
+        ctx.observer_set_depth(0, np.float64)  # (a 31-pixel template is fine)
+    with lib.Context(2, 64, 1, max_tile=90, max_search_dim=300, max_frames=2) as ctx:
+        ctx.observer_init(0, 2, 64, 64, 1, 0.3)
+        with pytest.raises(lib.GlhError, match="float64 frames"):
+            ctx.observer_set_depth(0, np.float64)
+        ctx.observer_set_depth(0, np.uint16)
