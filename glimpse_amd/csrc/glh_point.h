@@ -31,7 +31,7 @@ constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two 
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
 constexpr int PT_NSTAMP = 20;
-constexpr int PT_MAX_OBS = 2;    // observers per point in the fused kernel (more: staged path)
+constexpr int PT_MAX_OBS = 4;    // observers per point in the fused kernel (= MAX_OBS of the library)
 
 template <int TB>
 __device__ __forceinline__ double pt_block_sum(double v, double* red) {

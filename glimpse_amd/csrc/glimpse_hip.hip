@@ -1458,7 +1458,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const dim3 block(tb);
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
     if (big && ppt == 4) ppt = 10;
-    if (getenv("GLH_PT_UVLDS") || O == 2) ppt = 0;
+    if (getenv("GLH_PT_UVLDS") || O >= 2) ppt = 0;
     // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
     const bool fast = use_fast(c);
     // ... and, in fast arithmetic, everything the common instantiation is not compiled for (glh_point.h: COMMON): it
@@ -1468,12 +1468,12 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
     // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
-    int tbv = 512, nobsv = O == 2 ? 2 : 1;
+    int tbv = 512, nobsv = O;
     if (!big) {
-      if (O == 2) ppt = 0;
+      if (O >= 2) ppt = 0;
     } else {
       tbv = 1024;
-      if (O == 2 || ppt != 10) ppt = 0;
+      if (O >= 2 || ppt != 10) ppt = 0;
     }
     c->last_variant[0] = tbv; c->last_variant[1] = ppt; c->last_variant[2] = nobsv;
     c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);

@@ -362,3 +362,103 @@ def test_fused_step_evolves_every_motion_model_like_the_staged_kernels(gridded, 
         # tangent models leave vz = 0 and follow the surface
         tangent = params[:, 18] >= 2
         assert (fused["p"][tangent][..., 5] == 0).all()
+
+
+def _multi_observer_case(O, T=4, P=3, N=1500, seed=5):
+    """O stations around one scene (a nadir camera with k1-k3, the oblique station of C5, a second nadir station off to
+    the side with another focal length, a second oblique station), points every one of them sees."""
+    from glimpse_amd import synth
+
+    imgsz = (512, 512)
+    cams = [synth.nadir_camera(imgsz, f=1000.0, height=100.0, k=(0.05, -0.01, 0.002, 0, 0, 0)),
+            synth.pack_camera(imgsz=imgsz, f=1200.0, k=(0.03, 0, 0), xyz=(40, -30, 90), viewdir=(-53.13, -60.9, 0)),
+            synth.nadir_camera(imgsz, f=850.0, height=110.0, k=(0.02, 0, 0, 0, 0, 0), xyz_offset=(4.0, -3.0)),
+            synth.pack_camera(imgsz=imgsz, f=1100.0, k=(0, 0, 0), xyz=(-35, 25, 95), viewdir=(125.5, -65.6, 0))][:O]
+    scene = synth.default_scene(cams[0], seed=seed, velocity=(0.15, 0.0), n_frames=T, margin=60.0)
+    frames = [[scene.render(cam, float(t)) for t in range(T)] for cam in cams]
+    rng = np.random.default_rng(seed)
+    xy = []
+    while len(xy) < P:
+        cand = rng.uniform(-6, 6, 2)
+        uv = [synth.project(cam, np.array([[cand[0], cand[1], 0.0]]))[0] for cam in cams]
+        if all(90 < u[0] < imgsz[0] - 90 and 90 < u[1] < imgsz[1] - 90 for u in uv):
+            xy.append(cand)
+    params = np.zeros((P, 18))
+    params[:, 0:2] = xy
+    params[:, 2:4] = 0.15
+    params[:, 4:7] = (0.15, 0.0, 0.0)
+    params[:, 7:10] = (0.1, 0.1, 0.03)
+    params[:, 13:16] = (0.04, 0.04, 0.01)
+    params[:, 17] = 0.4
+    return dict(cams=cams, frames=frames, params=params, imgsz=imgsz, T=T, P=P, N=N, sigmas=[0.3, 0.45, 0.35, 0.5][:O])
+
+
+@pytest.mark.parametrize("O", [3, 4])
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_three_and_four_observers_on_the_fused_kernel(lib, O, math):
+    """Up to MAX_OBS = 4 observers per point run on the fused kernel (k_point_step<.., 0, O, ..>): the log likelihoods of
+    all stations add up (tracker.py:139-146).  Bit for bit the staged kernels (also with every tile forced through the
+    HBM workspaces), and the oracle's indices and posteriors on the same host-fed draws."""
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    cs = _multi_observer_case(O)
+    P, N, T = cs["P"], cs["N"], cs["T"]
+    rng = np.random.default_rng(O)
+    init = rng.standard_normal((P, N, 6))
+    ev = rng.standard_normal((T - 1, P, N, 3))
+    us = rng.random((T - 1, P))
+    res = {}
+    # (mode 2 -- every tile through the HBM workspaces -- has its own LDS plan and with it its own bound on the surfaces
+    # the fast arithmetic samples in per-cell form: comparable bit for bit in exact arithmetic only)
+    modes = (1, 0, 2) if math == "exact" else (1, 0)
+    for mode in modes:
+        with lib.Context(P, N, O, max_tile=31, max_search_dim=160, max_frames=T) as ctx:
+            for o in range(O):
+                ctx.observer_init(o, T, cs["imgsz"][0], cs["imgsz"][1], 1, cs["sigmas"][o])
+                ctx.observer_set_cameras(o, np.tile(cs["cams"][o], (T, 1)))
+                for t in range(T):
+                    ctx.observer_upload_frame(o, t, cs["frames"][o][t])
+            ctx.begin_sequence(P, N, (21, 21))
+            ctx.set_motion_cartesian(cs["params"])
+            ctx.set_math(math)
+            ctx.set_fused(mode)
+            ctx.set_debug(2)
+            ctx.set_frame(0)
+            ctx.init_particles(normals=init)
+            for o in range(O):
+                ctx.init_templates(o, 0)
+            ctx.record_moments(0)
+            idx = []
+            for i in range(1, T):
+                # (frame 2: the last station has no image)
+                images = [i] * O if i != 2 else [i] * (O - 1) + [-1]
+                ctx.step(i, 1.0, images, normals=ev[i - 1], u=us[i - 1])
+                idx.append(ctx.resample_indices())
+                if mode:
+                    assert ctx.last_variant()[:3] == (512, 0, O)
+            assert (ctx.point_status() == 0).all()
+            res[mode] = dict(particles=ctx.get_particles(), weights=ctx.get_weights(), moments=ctx.get_moments(0, T),
+                             idx=np.stack(idx))
+    for other in modes[1:]:
+        np.testing.assert_array_equal(res[1]["idx"], res[other]["idx"])
+        np.testing.assert_array_equal(res[1]["particles"], res[other]["particles"])
+        np.testing.assert_array_equal(res[1]["weights"], res[other]["weights"])
+        np.testing.assert_allclose(res[1]["moments"], res[other]["moments"], rtol=1e-12, atol=1e-13)
+    # (the SSD restated with the kernels' accumulation: index-for-index comparisons are made against that one, DESIGN §2)
+    observers = [otracker.Observer(cs["frames"][o], np.tile(cs["cams"][o], (T, 1)), cs["sigmas"][o], ssd="row_f32")
+                 for o in range(O)]
+    matching = np.tile(np.arange(T)[:, None], (1, O))
+    matching[2, O - 1] = -1
+    for p in range(P):
+        q = cs["params"][p]
+        model = omotion.CartesianMotion(xy=q[0:2], xy_sigma=q[2:4], vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13],
+                                        axyz_sigma=q[13:16], dem=q[16], dem_sigma=q[17], n=N)
+        draws = {"init": init[p], "evolve": [ev[s, p] for s in range(T - 1)], "u": [us[s, p] for s in range(T - 1)]}
+        trace = []
+        ref = otracker.track_one(model, observers, matching, np.ones(T - 1), tile_size=(21, 21), draws=draws, trace=trace)
+        np.testing.assert_allclose(res[1]["moments"][:, p, 0:6], ref["means"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(res[1]["moments"][:, p, 6:12], ref["sigmas"], rtol=1e-7, atol=1e-8)
+        steps = [tr["idx"] for tr in trace if "idx" in tr]
+        for s in range(T - 1):
+            np.testing.assert_array_equal(res[1]["idx"][s][p], steps[s])
