@@ -26,7 +26,8 @@ starts the N ranks itself (children are started before anything touches a GPU); 
 
 The default run (C3, one GPU) adds short SECONDARY legs after the headline, each over its whole sequence from the prior
 on the frames already in memory: exact arithmetic at C3 (the arithmetic the oracle tests pin bit for bit), one GPU's
-shard of C4 (1 250 x 10 000), C5 (2 048 x 5 000, two observers + DEM term) and C2 -- `secondary` in the JSON line.
+shard of C4 (1 250 x 10 000), C5 (2 048 x 5 000, two observers + DEM term), C2, and C3 on RGB frames -- `secondary` in
+the JSON line.
 
 Prints ONE JSON line on rank 0 (keys: DESIGN.md "Measurement") and exits non-zero when the run is unhealthy.
 """
@@ -88,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
+    ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
+                    help="frame channels: 1 (gray, BASELINE's configurations) or 3 (RGB uint8: what time-lapse JPEGs decode to)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs of the default run (exact arithmetic at C3, the C4 shard, C5, C2)")
     ap.add_argument("--dump-moments", default=None, help="rank 0 saves the (gathered) posterior history (T, P, 12) here (.npy)")
@@ -192,15 +195,15 @@ def pmc_traffic(wl, kernel):
     return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
-def algorithmic_bytes_per_step(P, N, O, tile, boxes, status):
-    """P*(96 N) state + per observer (Ws*Hs + 20*tw*th + 96) per point."""
+def algorithmic_bytes_per_step(P, N, O, tile, boxes, status, channels=1):
+    """P*(96 N) state + per observer (Ws*Hs*s_img + 20*tw*th + 96) per point (s_img = bytes per pixel)."""
     tw, th = tile
     total = 96.0 * N * P
     for o in range(O):
         ok = status[o] == 0
         ws = (boxes[o, :, 2] - boxes[o, :, 0])[ok].astype(np.float64)
         hs = (boxes[o, :, 3] - boxes[o, :, 1])[ok].astype(np.float64)
-        total += float((ws * hs).sum()) + ok.sum() * (20.0 * tw * th + 96.0)
+        total += channels * float((ws * hs).sum()) + ok.sum() * (20.0 * tw * th + 96.0)
     return total
 
 
@@ -227,7 +230,7 @@ def render_frames(wl, workers):
     cache = os.environ.get("GLH_FRAME_CACHE")  # (A/B tooling: repeated runs of one workload on one box)
     key = None
     if cache:
-        key = os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}")
+        key = os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}_{wl.channels}")
         if all(os.path.exists(f"{key}_{o}.npy") for o in range(wl.O)):
             return [np.load(f"{key}_{o}.npy", mmap_mode="r") for o in range(wl.O)]
     for o in range(wl.O):
@@ -440,11 +443,11 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     ctx.profile_enable(False)
     status = ctx.observer_status()
     boxes = ctx.search_boxes()
-    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels)
     dom_ms, dom_n = stage_ms[dom]
     per_launch = dom_ms / max(dom_n, 1)
     kern = KERNEL_OF_STAGE.get(dom, dom)
-    traffic = pmc_traffic(wl, kern) if math == "fast" else None
+    traffic = pmc_traffic(wl, kern) if math == "fast" and wl.channels == 1 else None
     moments = ctx.get_moments(0, n_frames)
     leg = {
         "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
@@ -466,22 +469,25 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     return leg
 
 
-def secondary_legs(args, device, T, frames_c3, frames_c5, seed):
+def secondary_legs(args, device, T, frames_c3, frames_c5, frames_rgb, seed):
     """What the headline does not show, each over its whole sequence from the prior on the frames already rendered:
     exact arithmetic at C3 (the arithmetic the oracle tests pin bit for bit), one GPU's shard of C4, C5 (two observers
-    + DEM term, all 2048 points on one GPU) and C2."""
+    + DEM term, all 2048 points on one GPU), C2, and C3 on RGB frames (what time-lapse JPEGs decode to: 766 key bins
+    instead of 256)."""
     from glimpse_amd import _lib, workloads
 
     legs = {}
-    plan = [("C3_exact", "C3", None, "exact", T, frames_c3),
-            ("C4_shard", "C4", None, "fast", T, frames_c3),
-            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, frames_c5),
-            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), frames_c3)]
-    for key, name, points, math, n_frames, frames in plan:
+    plan = [("C3_exact", "C3", None, "exact", T, frames_c3, 1),
+            ("C4_shard", "C4", None, "fast", T, frames_c3, 1),
+            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, frames_c5, 1),
+            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), frames_c3, 1),
+            ("C3_rgb", "C3", None, "fast", T, frames_rgb, 3)]
+    for key, name, points, math, n_frames, frames, channels in plan:
         if frames is None:
             continue
         try:
             wl = workloads.Workload(name, n_frames=T, n_points=points, shard=0, seed=0)
+            wl.channels = channels
             with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile),
                               max_search_dim=args.max_search_dim, max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
@@ -529,17 +535,21 @@ def worker(args):
         point_offset = rank * wl.P
         sizes = [wl.P] * world
 
+    wl.channels = args.channels
     # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files -- by forked helpers,
     # hence BEFORE anything loads the HIP library (the device count below does)
     cores = usable_cores()
     secondary = (world == 1 and not args.no_secondary and args.workload == "C3" and args.points is None
-                 and args.particles is None and args.motion == "cartesian" and B == 0)
-    frames_c5 = None
+                 and args.particles is None and args.motion == "cartesian" and B == 0 and args.channels == 1)
+    frames_c5 = frames_rgb = None
     if world == 1:
         frames = render_frames(wl, cores)
         if secondary:
             frames_c5 = render_frames(workloads.Workload("C5", n_frames=T, n_points=workloads.CONFIGS["C5"]["points"],
                                                          shard=0, seed=0), cores)
+            rgb = workloads.Workload("C3", n_frames=T, shard=0, seed=0)
+            rgb.channels = 3
+            frames_rgb = render_frames(rgb, cores)
     else:
         if rank == 0:
             frames = render_frames(wl, cores)
@@ -633,7 +643,7 @@ def worker(args):
     # algorithmic bytes / SSD flops of one step, from the search boxes of the last timed step (the smallest tiles
     # of the sequence: the tile term, ~4 % of the bytes, is if anything understated for the first frames)
     boxes = ctx.search_boxes()
-    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status)
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels)
     flops = ssd_flops_per_step(wl.O, wl.tile, boxes, status)
     moments_local = ctx.get_moments(0, T)
 
@@ -690,7 +700,7 @@ def worker(args):
         ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         kern = KERNEL_OF_STAGE.get(dom, dom)
         roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern),
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern) if wl.channels == 1 else None,
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": abytes / launches_per_frame,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
@@ -714,7 +724,7 @@ def worker(args):
         if secondary:
             ctx.close()
             ctx_closed = True
-            out["secondary"] = secondary_legs(args, device, T, frames, frames_c5, seed)
+            out["secondary"] = secondary_legs(args, device, T, frames, frames_c5, frames_rgb, seed)
         if not args.no_api:
             if not ctx_closed:
                 ctx.close()

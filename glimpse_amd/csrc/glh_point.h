@@ -121,9 +121,15 @@ __host__ __device__ __forceinline__ int pt_align16(int x) { return (x + 15) & ~1
 // LDS row stride (floats) of the search tile: >= ws + 11 readable columns and == 8 (mod 32), so the
 // row-split lanes of a strip (rows g = 0..7) start in distinct 16-byte bank slots
 __host__ __device__ __forceinline__ int pt_search_ld(int ws) { return ((ws + 3 + 31) / 32) * 32 + 8; }
+// histogram | cumulative counts | LUT of nb bins.  The 766 bins of RGB frames keep their cumulative counts IN the
+// histogram (each thread scans the two bins it owns): 3 KB that keep typical RGB tiles in LDS at two workgroups per CU.
+__host__ __device__ __forceinline__ bool pt_cum_in_place(int nb) { return nb > 256; }
+__host__ __device__ __forceinline__ int pt_hcl_bytes(int nb) {
+  return pt_align16(nb * 4) * (pt_cum_in_place(nb) ? 1 : 2) + pt_align16(nb * 8);
+}
 // bytes of the arrays that always live in LDS: template tile + histogram / cumulative counts / LUT
 __host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
-  return pt_align16(th * ssd_twp(tw) * 4) + pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
+  return pt_align16(th * ssd_twp(tw) * 4) + pt_hcl_bytes(nb);
 }
 
 // The raw-key tile of a w x h crop is stored with its 'reflect' border already in place (2 rows above and below,
@@ -214,6 +220,12 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     const uint32_t excl = base + incl - local;
     if (b0 < nb) ws.cum[b0] = excl + h0;
     if (b1 < nb) ws.cum[b1] = excl + local;
+    if (ws.cum == ws.hist) {
+      // cumulative counts in place (pt_cum_in_place): the counts of the own bins are still in registers, so their
+      // LUT entries are made here, from the template CDF -- same operations as the loop below
+      if (h0) ws.lut[b0] = np_interp((double)(excl + h0) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
+      if (h1) ws.lut[b1] = np_interp((double)(excl + local) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
+    }
   }
   __syncthreads();
   // ... then whole padded rows: -1 <- 0, -2 <- 1, h <- h - 1, h + 1 <- h - 2 (the column borders are in place)
@@ -223,10 +235,12 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     const int src = k < 2 ? k : h - 1 - (k - 2);
     keys[r * wp + c] = keys[src * wp + c];
   }
-  for (int b = tid; b < nb; b += TB) {
-    if (ws.hist[b]) {
-      const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
-      ws.lut[b] = np_interp(q, ws.cdf_q, ws.cdf_v, hist_n);
+  if (ws.cum != ws.hist) {
+    for (int b = tid; b < nb; b += TB) {
+      if (ws.hist[b]) {
+        const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
+        ws.lut[b] = np_interp(q, ws.cdf_q, ws.cdf_v, hist_n);
+      }
     }
   }
   __syncthreads();
@@ -756,14 +770,16 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
     const int hist_n = o == 0 ? hist_n0 : a.tmpl_hist_n[slot];
     const int twp = ssd_twp(tw);
-    // ---- LDS carve: [T | cq | cv | S | X] with X = max(hist + cum + lut + keys, Z + LU)
+    // ---- LDS carve: [T | S | X] with X = max(hist + cum + lut + keys, Z + LU).  The template CDF (cq | cv) lies at the
+    //      head of S: it is read while the LUT is made, the search tile is written after that -- 4 KB that decide whether
+    //      a gray tile fits, 12 KB for the 766 bins of RGB frames (which used to send every RGB tile to the workspaces).
     TileWs ws;
     const int offT = pt_align16(th * twp * 4), cdfb = pt_align16(hist_n * 8);
     ws.T = reinterpret_cast<float*>(r2);
-    const int off = offT + 2 * cdfb;
+    const int off = offT;
     const int ld_lds = pt_search_ld(ws_);
-    const int s_bytes = pt_align16(hs * ld_lds * 4);
-    const int hcl = pt_align16(nb * 4) * 2 + pt_align16(nb * 8);
+    const int s_bytes = max(pt_align16(hs * ld_lds * 4), 2 * cdfb);
+    const int hcl = pt_hcl_bytes(nb), hb = pt_cum_in_place(nb) ? 0 : pt_align16(nb * 4);  // (hb: offset of cum behind hist)
     const int l1 = hcl + pt_align16(pt_keys_count(ws_, hs) * 2);
     const bool dense = spline_dense(ho, wo);  // spline fit by explicit inverses
     const int zb = pt_align16(ho * wo * 8);
@@ -917,8 +933,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.S = reinterpret_cast<float*>(r2 + off);
       unsigned char* X = r2 + off + s_bytes;
       ws.hist = reinterpret_cast<uint32_t*>(X);
-      ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
-      ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
+      ws.cum = reinterpret_cast<uint32_t*>(X + hb);
+      ws.lut = reinterpret_cast<double*>(X + hb + pt_align16(nb * 4));
       ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
       ws.cdf_q = reinterpret_cast<const double*>(r2 + offT);
       ws.cdf_v = ws.cdf_q + cdfb / 8;
@@ -967,8 +983,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       unsigned char* X = r2 + offT;
       __syncthreads();  // the CDF copy has landed before the histogram is zeroed over it
       ws.hist = reinterpret_cast<uint32_t*>(X);
-      ws.cum = reinterpret_cast<uint32_t*>(X + pt_align16(nb * 4));
-      ws.lut = reinterpret_cast<double*>(X + 2 * pt_align16(nb * 4));
+      ws.cum = reinterpret_cast<uint32_t*>(X + hb);
+      ws.lut = reinterpret_cast<double*>(X + hb + pt_align16(nb * 4));
       ws.ld = (ws_ + 14) & ~3;
       ws.S = a.ws_search + slot * (size_t)a.search_cap;
       ws.keys = a.ws_keys + slot * (size_t)a.keys_cap;

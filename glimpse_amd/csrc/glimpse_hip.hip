@@ -1342,7 +1342,8 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
   const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_NINV / 2 * 8);
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
-  const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2 + 4096;
+  // (the template CDF lies over the search tile while the LUT is made: no bytes of its own)
+  const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2;
   int r2;
   if (cN + std::max(r2_min, typical) <= PT_LDS_HALF)
     r2 = PT_LDS_HALF - cN;

@@ -111,8 +111,10 @@ class Workload:
         sub.params = self.params[lo:hi]
         return sub
 
+    channels = 1  # 3: RGB frames (what a time-lapse JPEG decodes to)
+
     def frame(self, obs, t):
-        return self.scene.render(self.cams[obs], float(t))
+        return self.scene.render(self.cams[obs], float(t), channels=self.channels)
 
     def frames(self, obs):
         return [self.frame(obs, t) for t in range(self.T)]
@@ -122,7 +124,7 @@ class Workload:
                 "tangent_cartesian": "TangentCartesianMotion", "tangent_cylindrical": "TangentCylindricalMotion"}[motion]
         return {
             "workload": f"{self.name}: {self.P} points x {self.N} particles x {self.T} frames "
-                        f"{self.imgsz[0]}x{self.imgsz[1]} uint8, tile {self.tile[0]}x{self.tile[1]}, "
+                        f"{self.imgsz[0]}x{self.imgsz[1]} uint8{' RGB' if self.channels == 3 else ''}, tile {self.tile[0]}x{self.tile[1]}, "
                         f"{self.O} observer(s), {name}, radial k={tuple(self.cfg['k'])}",
             "points_per_gpu": self.P,
             "particles": self.N,
@@ -132,8 +134,9 @@ class Workload:
         }
 
 
-def setup_context(ctx, wl, frames=None, channels=1):
+def setup_context(ctx, wl, frames=None, channels=None):
     """Upload cameras + frames of a workload into a glimpse_amd._lib.Context and start a sequence."""
+    channels = wl.channels if channels is None else channels
     for o in range(wl.O):
         ctx.observer_init(o, wl.T, wl.imgsz[0], wl.imgsz[1], channels, wl.sigmas[o])
         ctx.observer_set_cameras(o, np.tile(wl.cams[o], (wl.T, 1)))
