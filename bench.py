@@ -390,9 +390,12 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
     t0 = time.perf_counter()
     tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
     wall_cold = time.perf_counter() - t0  # creates the context (device allocations) and uploads every frame
-    t0 = time.perf_counter()
-    tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
-    wall = time.perf_counter() - t0       # context and frames resident: the frame loop + results
+    wall = None
+    for _ in range(2):  # context and frames resident: the frame loop + results (the faster of two calls)
+        t0 = time.perf_counter()
+        tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
+        dt = time.perf_counter() - t0
+        wall = dt if wall is None else min(wall, dt)
     ok = sum(e is None for e in tracks.errors)
     finite = bool(np.isfinite(tracks.means[:, -1]).all())
     if tracker._ctx is not None:

@@ -111,6 +111,8 @@ struct PointArgs {
   Surfaces surf;           // gridded dem / dem_sigma / viewshed (null pointers when absent)
   uint32_t cam_flags[PT_MAX_OBS];  // cam_flags(cam[o]): scalar, so the optional projection terms branch uniformly
   int32_t N, P, O, tw, th, tile_cap, search_cap, keys_cap, sse_cap, max_dim, frame, rng_mode, has_dem;
+  int32_t hp_rx, hp_ry;  // half sizes of the median high-pass window (2, 2 = the 5 x 5 default; others: general code only)
+  int32_t interp_k;      // order of the surface sampling: 3 (bicubic spline) or 1 (bilinear; general code only)
   int32_t cell_cap;  // fast arithmetic: surfaces of up to this many cells are sampled in per-cell form (0: never)
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
@@ -163,9 +165,12 @@ struct TileWs {
 };
 
 // extract_tile(histogram=template CDF) (tracker.py:605-607) into ws.S; see search_tile_from_box.
-template <int TB>
+// GEN (the general instantiations): any odd median window up to 7 x 7 (`hp_rx`, `hp_ry` half sizes; Tracker(highpass=
+// {"size": ...}), tracker.py:59, :530) -- the 5 x 5 default keeps its packed network everywhere.
+template <int TB, bool GEN = false>
 __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box, int nb, int hist_n, const TileWs& ws,
-                                             uint32_t* scan_tmp, unsigned long long* stp = nullptr) {
+                                             uint32_t* scan_tmp, unsigned long long* stp = nullptr, int hp_rx = 2,
+                                             int hp_ry = 2) {
   // diagnostic s_memtime stamps 13 / 14 inside this stage (tools/phase_probe.py), when armed
 #define TP_STAMP(k)                                                                                      \
   do {                                                                                                   \
@@ -256,6 +261,19 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   // is columns c0 - 2 .. c0 + 3 of rows r - 2 .. r + 2 of the bordered tile: three aligned 32-bit words per row
   // (c0 and the row stride are even), i.e. the pairs (k0 k1) (k2 k3) (k4 k5) directly and (k1 k2) (k3 k4) by a
   // funnel shift.
+  if (GEN && (hp_rx != 2 || hp_ry != 2)) {
+    // another window: the median by bisection over the key range, one pixel per thread, on the same key tile
+    // (`reflect` by index arithmetic: the tile's own border is the 5 x 5 window's) -- what k_tileprep does
+    const UDiv by_w2 = udiv_make(w);
+    for (int idx = tid; idx < n; idx += TB) {
+      const int r = udiv(by_w2, idx), c = idx - r * w;
+      const int key = keys[r * wp + c];
+      const int med = median_window(keys, wp, 0, w, h, r, c, hp_rx, hp_ry, nb - 1);
+      ws.S[r * ld + c] = (float)(ws.lut[key] - ws.lut[med]);
+    }
+    __syncthreads();
+    return;
+  }
   const int npc = (w + 1) >> 1;
   const UDiv by_npc = udiv_make(npc);
   for (int idx = tid; idx < h * npc; idx += TB) {
@@ -733,7 +751,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         st = GLH_OBS_OK;
         s_uvbb[o][0] = mnu; s_uvbb[o][1] = mnv; s_uvbb[o][2] = mxu; s_uvbb[o][3] = mxv;
         const ObsFrame& ob = a.obs[o];
-        if (search_box(mnu, mnv, mxu, mxv, nf != 0.0, a.tw, a.th, a.cam[o].imgsz[0], a.cam[o].imgsz[1], s_box[o]))
+        const int korder = SURF ? a.interp_k : 3;  // (the order also sets the least size of the surface, tracker.py:585-590)
+        if (search_box(mnu, mnv, mxu, mxv, nf != 0.0, a.tw, a.th, a.cam[o].imgsz[0], a.cam[o].imgsz[1], s_box[o], korder,
+                       korder))
           st = GLH_OBS_OUT_OF_BOUNDS;
         else if (s_box[o][2] > ob.width || s_box[o][3] > ob.height)
           st = GLH_OBS_OUT_OF_BOUNDS;
@@ -781,7 +801,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int s_bytes = max(pt_align16(hs * ld_lds * 4), 2 * cdfb);
     const int hcl = pt_hcl_bytes(nb), hb = pt_cum_in_place(nb) ? 0 : pt_align16(nb * 4);  // (hb: offset of cum behind hist)
     const int l1 = hcl + pt_align16(pt_keys_count(ws_, hs) * 2);
-    const bool dense = spline_dense(ho, wo);  // spline fit by explicit inverses
+    // Tracker(interpolation={"kx": 1, "ky": 1}) (general code): the surface values are the coefficients -- no fit -- and
+    // the sampling is their bilinear interpolant
+    const bool linear = SURF && a.interp_k == 1;          // uniform
+    const bool dense = !linear && spline_dense(ho, wo);  // spline fit by explicit inverses
     const int zb = pt_align16(ho * wo * 8);
     // small inverses (one entry per thread) are fetched before the SSD and parked in LDS after it, like the LU
     // factors of the larger surfaces: no memory latency inside the fit
@@ -809,7 +832,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
       auto eval = [&](double u, double v) -> double {
         if constexpr (CELLS) return spline_eval_cell(Z, ho, wo, cv0, cu0, u, v);
-        else return spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, u, v);
+        else {
+          if constexpr (SURF)
+            if (linear) return spline_eval_linear(Z, wo, ho, wo, cv0, cu0, u, v);
+          return spline_eval_poly_m<FAST>(tab, Z, wo, ho, wo, cv0, cu0, u, v);
+        }
       };
       // "Some sampling points are outside box" (observer.py:201-202): some particle's uv is outside the box exactly
       // when the bounding box of all of them is (NaNs never get here: they skip the observer) -- one test per
@@ -903,7 +930,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     bool cells = false;  // uniform
     auto to_cells = [&](const double* Z) -> bool {
       const int ncu = spline_cells(wo), nrows = 4 * spline_cells(ho) * ncu;
-      if (!FAST || nrows > 4 * a.cell_cap) return false;
+      if (!FAST || linear || nrows > 4 * a.cell_cap) return false;
       double row[2][4];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -938,7 +965,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
       ws.cdf_q = reinterpret_cast<const double*>(r2 + offT);
       ws.cdf_v = ws.cdf_q + cdfb / 8;
-      pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);  // starts with a barrier: T, cdf visible
+      pt_tile_prep<TB, SURF>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps, a.hp_rx, a.hp_ry);  // starts with a barrier: T, cdf visible
       PT_STAMP(2);
       ws.Z = reinterpret_cast<double*>(X);
       ws.Z1 = ws.Z + zb / 8;
@@ -971,9 +998,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       if (inv_lds) {  // (its own call: the inverses' address space stays known)
         ws.ih = invl;
         ws.iw = invl + ho * ho;
-        pt_spline_fit<TB>(ws, wo, ho);
+        if (!linear) pt_spline_fit<TB>(ws, wo, ho);
       } else {
-        pt_spline_fit<TB>(ws, wo, ho);
+        if (!linear) pt_spline_fit<TB>(ws, wo, ho);
       }
       PT_STAMP(4);
       if (!to_cells(ws.Z)) sample_all(ws.Z, std::false_type{});
@@ -1000,9 +1027,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         // only the float32 search tile is too large: the key tile stays in LDS (its own call, so that the
         // median's window loads keep their address space)
         ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
-        pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
+        pt_tile_prep<TB, SURF>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps, a.hp_rx, a.hp_ry);
       } else {
-        pt_tile_prep<TB>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps);
+        pt_tile_prep<TB, SURF>(ob, box, nb, hist_n, ws, scan_tmp, (unsigned long long*)a.stamps, a.hp_rx, a.hp_ry);
       }
       PT_STAMP(2);
       if (offT + pt_align16(hs * ws.ld * 4) <= a.r2_bytes) {
@@ -1035,11 +1062,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         __syncthreads();
         ws.Z = Zl;
         ws.Z1 = fl;
-        pt_spline_fit<TB>(ws, wo, ho);
+        if (!linear) pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
         if (!to_cells(Zl)) sample_all(Zl, std::false_type{});
       } else {
-        pt_spline_fit<TB>(ws, wo, ho);
+        if (!linear) pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
         sample_all(ws.Z, std::false_type{});  // (a surface this large is beyond the cell form as well)
       }

@@ -1326,8 +1326,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   if (mode < 0) mode = c->fused;
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
-  if (c->hp_rx != 2 || c->hp_ry != 2) return false;  // the fused kernel's median network is the 5 x 5 default
-  if (c->interp_k != 3) return false;                // ... and its sampling the bicubic default
+  // (other median windows and bilinear sampling run on the general instantiations: fused_step)
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {
@@ -1440,6 +1439,9 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.has_dem = c->has_dem;
   a.r2_bytes = r2_bytes;
   a.cell_cap = cell_cap(c);
+  a.hp_rx = c->hp_rx;
+  a.hp_ry = c->hp_ry;
+  a.interp_k = c->interp_k;
   a.pt_base = c->pt_base;
   a.surf = surfaces(c);
   a.nleaves = c->nleaves;
@@ -1468,7 +1470,9 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     bool common = fast && rng_mode == GLH_RNG_PHILOX && c->compact && !c->have_mask;
     for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
     // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
-    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common);
+    const bool plain = c->hp_rx == 2 && c->hp_ry == 2 && c->interp_k == 3;  // the 5 x 5 median, bicubic sampling
+    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common) ||
+                      !plain;
     int tbv = 512, nobsv = O;
     if (!big) {
       if (O >= 2) ppt = 0;

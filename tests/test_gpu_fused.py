@@ -462,3 +462,55 @@ def test_three_and_four_observers_on_the_fused_kernel(lib, O, math):
         steps = [tr["idx"] for tr in trace if "idx" in tr]
         for s in range(T - 1):
             np.testing.assert_array_equal(res[1]["idx"][s][p], steps[s])
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+@pytest.mark.parametrize("variant", [dict(highpass=(3, 3)), dict(highpass=(7, 5)), dict(highpass=(1, 3)),
+                                     dict(interpolation=(1, 1)), dict(highpass=(3, 3), interpolation=(1, 1))])
+def test_other_median_windows_and_bilinear_sampling_on_the_fused_kernel(lib, variant, math):
+    """Tracker(highpass={"size": ...}) other than 5 x 5 and Tracker(interpolation={"kx": 1, "ky": 1}) run on the
+    general instantiations of the fused kernel (rounds 1-2: staged kernels only): bit for bit the staged kernels, on
+    gray and RGB frames, host-fed and device draws."""
+    from glimpse_amd import workloads
+
+    T = 5
+    for name, P, N, channels in (("C2", 6, 1500, 1), ("C5", 3, 2000, 3)):
+        wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+        wl.channels = channels
+        frames = [wl.frames(o) for o in range(wl.O)]
+        rng = np.random.default_rng(7)
+        ev, us = rng.standard_normal((P, N, 3)), rng.random(P)
+        res = []
+        for mode in (1, 0):
+            with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
+                workloads.setup_context(ctx, wl, frames)
+                if "highpass" in variant:
+                    ctx.set_highpass(variant["highpass"])
+                if "interpolation" in variant:
+                    ctx.set_interpolation(*variant["interpolation"])
+                ctx.set_math(math)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=11)
+                for o in range(wl.O):
+                    ctx.init_templates(o, 0)
+                ctx.record_moments(0)
+                idx = []
+                for i in range(1, T):
+                    if i == 2:
+                        ctx.step(i, 1.0, [i] * wl.O, normals=ev, u=us)  # (one step on host-fed draws)
+                    else:
+                        ctx.step(i, 1.0, [i] * wl.O, seed=11)
+                    idx.append(ctx.resample_indices())
+                    if mode:
+                        assert ctx.last_variant()[3] & 2  # the general code
+                assert (ctx.observer_status() == lib.OBS_OK).all() and (ctx.point_status() == 0).all()
+                stages = {k for k, v in ctx.profile_get().items() if v[1] > 0}
+                assert ("point_step" in stages) == bool(mode)
+                res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T), np.stack(idx)))
+        np.testing.assert_array_equal(res[0][3], res[1][3])
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
+        assert abs(np.median(res[0][2][-1, :, 3]) - 0.15) < 0.06
