@@ -136,6 +136,7 @@ SIGNATURES = {
     "glh_stage_search_tile_highpass": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
     "glh_stage_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "glh_stage_sample_orders": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "glh_stage_resample": (_I, [_I, _P, _I, _D, _P]),
     "glh_stage_raster_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _I, _D, _D, _D, _D, _P, _I, _I, _P, _P]),
 }
@@ -235,7 +236,7 @@ class Context:
         self._frame_dtype[obs] = np.dtype(np.uint8)
 
     def set_interpolation(self, kx=3, ky=3):
-        """Orders of the surface-sampling spline: (3, 3) (default) or (1, 1)."""
+        """Orders of the surface-sampling spline (rows axis, columns axis), each 1 .. 5; (3, 3) by default."""
         check(self.lib.glh_set_interpolation(self.handle, int(kx), int(ky)))
 
     def observer_set_depth(self, obs, dtype):
@@ -692,15 +693,21 @@ def stage_ssd(search, templ, device_id=0):
     return out
 
 
-def stage_sample(sse, box, uv, device_id=0):
+def stage_sample(sse, box, uv, device_id=0, orders=None):
+    """Observer.sample_tile (observer.py:178-214) on the device: (values, outside).  `orders` = (kx, ky) of
+    RectBivariateSpline (rows axis, columns axis); None: the bicubic default."""
     sse = _arr(sse, np.float32)
     box = _arr(box, np.float64, (4,))
     uv = _arr(uv, np.float64)
-    vals = np.empty(len(uv))
+    values = np.empty(len(uv))
     outside = np.empty(len(uv), dtype=np.uint8)
-    check(load().glh_stage_sample(device_id, _ptr(sse), sse.shape[0], sse.shape[1], _ptr(box), _ptr(uv), len(uv),
-                                  _ptr(vals), _ptr(outside)))
-    return vals, outside.astype(bool)
+    if orders is None:
+        check(load().glh_stage_sample(device_id, _ptr(sse), sse.shape[0], sse.shape[1], _ptr(box), _ptr(uv), len(uv),
+                                      _ptr(values), _ptr(outside)))
+    else:
+        check(load().glh_stage_sample_orders(device_id, _ptr(sse), sse.shape[0], sse.shape[1], int(orders[0]),
+                                             int(orders[1]), _ptr(box), _ptr(uv), len(uv), _ptr(values), _ptr(outside)))
+    return values, outside.astype(bool)
 
 
 def stage_resample(weights, u, device_id=0):

@@ -162,6 +162,36 @@ inline void spline_lu(int n, double* out) {
   }
 }
 
+// Degree-k collocation matrix (glh_math.h: gspl_*) factored without pivoting (it is totally positive), bandwidth k on
+// either side: out = [L: k arrays of n, L_d[i] at (i, i - d)] [u0inv: n] [U: k arrays of n, U_d[i] at (i, i + d)],
+// (2 k + 1) n doubles.  Same elimination as oracle/spline.py: lu_general.
+inline void spline_lu_general(int n, int k, double* out) {
+  std::vector<double> a((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    const int l = gspl_interval((double)i, n, k);
+    double h[GLH_SPL_KMAX + 1];
+    gspl_basis((double)i, l, n, k, h);
+    for (int m = 0; m <= k; ++m) a[(size_t)i * n + (l - k + m)] = h[m];
+  }
+  double* L = out;
+  double* u0inv = out + (size_t)k * n;
+  double* U = u0inv + n;
+  for (size_t q = 0; q < (size_t)(2 * k + 1) * n; ++q) out[q] = 0.0;
+  for (int c = 0; c < n; ++c) {
+    for (int i = c + 1; i < std::min(c + k + 1, n); ++i) {
+      const double m = a[(size_t)i * n + c] / a[(size_t)c * n + c];
+      L[(size_t)(i - c - 1) * n + i] = m;
+      for (int j = c; j < std::min(c + k + 1, n); ++j) a[(size_t)i * n + j] -= m * a[(size_t)c * n + j];
+      a[(size_t)i * n + c] = 0.0;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    u0inv[i] = 1.0 / a[(size_t)i * n + i];
+    for (int d = 1; d <= k; ++d)
+      if (i + d < n) U[(size_t)(d - 1) * n + i] = a[(size_t)i * n + i + d];
+  }
+}
+
 // The same collocation matrix inverted explicitly (row-major n x n): for small surfaces the fit is two
 // dense products, Ih . Z . Iw^T, in which every coefficient is an independent dot product (the banded solves
 // above are two serial chains of n steps per line).  Gauss-Jordan with partial pivoting in long double, rounded

@@ -1519,6 +1519,11 @@ __global__ __launch_bounds__(BLK) void k_ssd(SsdArgs a) {
 struct SplineFitArgs {
   int32_t o, P, tw, th, sse_cap, max_n;
   int32_t linear, reserved;  // linear: interpolation order 1 -- the surface values are the coefficients, nothing to fit
+  int32_t kx, ky;            // orders along the rows / columns axis (3, 3 unless Tracker(interpolation=...) says otherwise)
+  const double* glu_v;       // general orders: factors of spline_lu_general for degree kx, by size at glu_v_off[n]
+  const int64_t* glu_v_off;
+  const double* glu_u;       // ... and for degree ky
+  const int64_t* glu_u_off;
   const int32_t* box;
   const int32_t* obs_status;
   const double* lu;          // packed factors: for n, 5 arrays of n at lu_off[n]
@@ -1579,6 +1584,22 @@ __device__ __forceinline__ void solve_line(double* x, int stride, int n, const d
   }
 }
 
+// one line of the degree-k fit: forward / backward substitution with the factors of spline_lu_general (glh_host.h)
+__device__ __forceinline__ void solve_line_general(double* x, int stride, int n, int k, const double* f) {
+  const double *L = f, *u0inv = f + (size_t)k * n, *U = u0inv + n;
+  for (int i = 1; i < n; ++i) {
+    double y = x[(size_t)i * stride];
+    for (int d = 1; d <= k && d <= i; ++d) y = y - L[(size_t)(d - 1) * n + i] * x[(size_t)(i - d) * stride];
+    x[(size_t)i * stride] = y;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double acc = x[(size_t)i * stride];
+    for (int d = 1; d <= k; ++d)
+      if (i + d < n) acc = acc - U[(size_t)(d - 1) * n + i] * x[(size_t)(i + d) * stride];
+    x[(size_t)i * stride] = acc * u0inv[i];
+  }
+}
+
 #ifndef GLH_POINT_TU  // (the fused kernel's own translation units carry none of the staged kernels)
 __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
   const int pt = blockIdx.x, tid = threadIdx.x;
@@ -1593,6 +1614,14 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
     __syncthreads();
   }
   if (a.linear) return;
+  if (a.glu_v) {  // any other orders than (3, 3) and (1, 1): banded solves of bandwidth k, columns then rows
+    const double* fv = a.glu_v + a.glu_v_off[ho];
+    const double* fu = a.glu_u + a.glu_u_off[wo];
+    for (int c = tid; c < wo; c += BLK) solve_line_general(z + c, wo, ho, a.kx, fv);
+    __syncthreads();
+    for (int r = tid; r < ho; r += BLK) solve_line_general(z + (size_t)r * wo, 1, wo, a.ky, fu);
+    return;
+  }
   if (spline_dense(ho, wo)) {
     __shared__ double z1[GLH_SPL_DENSE_NINV / 2];  // ho * wo <= (ho^2 + wo^2) / 2
     spline_fit_dense<BLK>(z, z1, wo, ho, a.inv + spline_inverse_off(ho), a.inv + spline_inverse_off(wo));
@@ -1633,6 +1662,8 @@ struct WeightArgs {
   int32_t fast;  // GLH_MATH_FAST
   int32_t cell_cap;  // fast: surfaces of up to this many cells are evaluated in per-cell form (the fused kernel's bound)
   int32_t linear;    // Tracker(interpolation={"kx": 1, "ky": 1}): `coef` is the surface itself, sampled bilinearly
+  int32_t kx, ky;    // other orders than (3, 3) / (1, 1) when general != 0 (rows axis, columns axis)
+  int32_t general;
   Surfaces surf;
 };
 
@@ -1692,8 +1723,9 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
       double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double* coef = a.coef + slot * (size_t)a.sse_cap;
       // fast arithmetic: surfaces the fused kernel holds in per-cell form are evaluated by that formula here too
-      const bool by_cell = !a.linear && a.fast && spline_cells(ho) * spline_cells(wo) <= a.cell_cap;
-      double val = a.linear ? spline_eval_linear(coef, wo, ho, wo, cv0, cu0, q.x, q.y)
+      const bool by_cell = !a.linear && !a.general && a.fast && spline_cells(ho) * spline_cells(wo) <= a.cell_cap;
+      double val = a.general ? spline_eval_general(coef, wo, ho, wo, a.kx, a.ky, cv0, cu0, q.x, q.y)
+                   : a.linear ? spline_eval_linear(coef, wo, ho, wo, cv0, cu0, q.x, q.y)
                    : by_cell ? spline_eval_cell_direct(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
                    : a.fast ? spline_eval_poly_fast(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y)
                             : spline_eval_poly(tab, coef, wo, ho, wo, cv0, cu0, q.x, q.y);
@@ -1735,6 +1767,7 @@ __global__ __launch_bounds__(BLK) void k_tracks_layout(const double* moments, in
 struct SampleArgs {
   const double* coef;
   int32_t ho, wo, n;
+  int32_t kx, ky;  // 0, 0: the bicubic default (spline_eval); else spline_eval_general
   double sb[4];
   const double* uv;
   double* values;
@@ -1747,7 +1780,8 @@ __global__ __launch_bounds__(BLK) void k_sample(SampleArgs a) {
   double u = a.uv[2 * i], v = a.uv[2 * i + 1];
   a.outside[i] = !(u >= a.sb[0] && u <= a.sb[2] && v >= a.sb[1] && v <= a.sb[3]);
   double cu0 = cell_origin(a.sb[0], a.sb[2], a.wo), cv0 = cell_origin(a.sb[1], a.sb[3], a.ho);
-  a.values[i] = spline_eval(a.coef, a.wo, a.ho, a.wo, cv0, cu0, u, v);
+  a.values[i] = a.kx ? spline_eval_general(a.coef, a.wo, a.ho, a.wo, a.kx, a.ky, cv0, cu0, u, v)
+                     : spline_eval(a.coef, a.wo, a.ho, a.wo, cv0, cu0, u, v);
 }
 #endif
 

@@ -741,6 +741,58 @@ GLH_HD double spline_eval_linear(const double* z, int ld, int ho, int wo, double
   return sp;
 }
 
+// ---- any order 1 .. 5 of RectBivariateSpline(kx, ky), s = 0 (Tracker(interpolation=...), tracker.py:60, :623) ----
+// FITPACK (fpgrre, interpolation case) puts the interior knots at the data sites for odd degrees and midway between
+// them for even degrees; on unit-spaced sites 0 .. n-1 both read t[i] = i - (k + 1) / 2 for i = k+1 .. n-1, between
+// k + 1 knots at 0 and k + 1 at n - 1.  Restated in oracle/spline.py (knot_general ... eval_general) and pinned to the
+// reference by tests/golden/g23_orders.npz.
+constexpr int GLH_SPL_KMAX = 5;
+GLH_HD double gspl_knot(int i, int n, int k) {
+  return i <= k ? 0.0 : (i >= n ? (double)(n - 1) : (double)i - 0.5 * (double)(k + 1));
+}
+// l with t[l] <= xl < t[l+1], clamped to [k, n-1] (fpbisp)
+GLH_HD int gspl_interval(double xl, int n, int k) {
+  int l = (int)floor(xl + 0.5 * (double)(k + 1));
+  if (l < k) l = k;
+  if (l > n - 1) l = n - 1;
+  return l;
+}
+// the k + 1 non-zero B-splines B_{l-k} .. B_l at x (FITPACK fpbspl); h [GLH_SPL_KMAX + 1]
+GLH_HD void gspl_basis(double x, int l, int n, int k, double* h) {
+  double hh[GLH_SPL_KMAX + 1];
+  h[0] = 1.0;
+  for (int j = 1; j <= k; ++j) {
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.0;
+    for (int i = 0; i < j; ++i) {
+      const int li = l + i + 1, lj = li - j;
+      const double tli = gspl_knot(li, n, k), tlj = gspl_knot(lj, n, k);
+      const double f = hh[i] / (tli - tlj);
+      h[i] = h[i] + f * (tli - x);
+      h[i + 1] = f * (x - tlj);
+    }
+  }
+}
+// the tensor spline of degree kv along the rows axis and ku along the columns axis, arguments clamped to the outermost
+// sites (fpbisp); coef [ho][wo], row stride ld
+GLH_HD double spline_eval_general(const double* coef, int ld, int ho, int wo, int kv, int ku, double cv0, double cu0,
+                                  double u, double v) {
+  double vl = v - cv0, ul = u - cu0;
+  const double vmax = (double)(ho - 1), umax = (double)(wo - 1);
+  vl = vl < 0.0 ? 0.0 : (vl > vmax ? vmax : vl);
+  ul = ul < 0.0 ? 0.0 : (ul > umax ? umax : ul);
+  const int lv = gspl_interval(vl, ho, kv), lu = gspl_interval(ul, wo, ku);
+  double hv[GLH_SPL_KMAX + 1], hu[GLH_SPL_KMAX + 1];
+  gspl_basis(vl, lv, ho, kv, hv);
+  gspl_basis(ul, lu, wo, ku, hu);
+  double sp = 0.0;
+  for (int i = 0; i <= kv; ++i) {
+    const double* row = coef + (size_t)(lv - kv + i) * ld + (lu - ku);
+    for (int j = 0; j <= ku; ++j) sp += row[j] * hv[i] * hu[j];
+  }
+  return sp;
+}
+
 // Evaluate the tensor spline with coefficients coef[ho][wo] (row stride ld) at (u, v);
 // arguments are clamped to the outermost cell centres (FITPACK fpbisp).
 GLH_HD double spline_eval(const double* coef, int ld, int ho, int wo, double cv0, double cu0,

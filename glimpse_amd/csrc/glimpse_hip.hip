@@ -179,7 +179,11 @@ struct glh_ctx {
   int32_t *leaf_off = nullptr, *leaf_len = nullptr, *sum_ops = nullptr, *level_off = nullptr, *roots = nullptr;
   int nleaves = 0, nnodes = 0, nlevels = 0, nroots = 0;
   int moments_frame = -1;  // history slot already filled by the fused resample kernel
-  int interp_k = 3;  // interpolation order of the surface sampling: 3 (bicubic, the default) or 1 (glh_set_interpolation)
+  int interp_k = 3;  // interpolation order of the surface sampling: 3 (bicubic, the default), 1 (bilinear), or 0: the
+                     // general orders interp_kx (rows axis) / interp_ky (columns axis) (glh_set_interpolation)
+  int interp_kx = 3, interp_ky = 3;
+  double* glu[2] = {nullptr, nullptr};       // general orders: spline_lu_general factors for degree kx / ky by size
+  int64_t* glu_off[2] = {nullptr, nullptr};  // [max_search_dim + 1]
   int32_t last_variant[4] = {0, 0, 0, 0};  // fused kernel instantiation of the last step: TB, PPT, NOBS, fast | general << 1
   size_t normals_cap = 0;
   // profiling
@@ -301,7 +305,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   dfree(c->pt_err_frame); dfree(c->obs_status_all); dfree(c->box); dfree(c->idx); dfree(c->tmpl_box);
   dfree(c->tmpl_hist_n); dfree(c->tmpl_valid); dfree(c->tmpl_duv); dfree(c->tmpl_tile64);
   dfree(c->tmpl_hist_v); dfree(c->tmpl_hist_q); dfree(c->tmpl_tile32); dfree(c->search); dfree(c->ws_keys); dfree(c->bins16); dfree(c->fwork); dfree(c->tracks_tmp); dfree(c->resid_draws); dfree(c->uidx[0]); dfree(c->uidx[1]); dfree(c->stamps);
-  dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->leaf_off);
+  dfree(c->sse); dfree(c->sse_copy); dfree(c->ll_dbg); dfree(c->lu); dfree(c->poly); dfree(c->lu_off); dfree(c->spl_inv); dfree(c->glu[0]); dfree(c->glu[1]); dfree(c->glu_off[0]); dfree(c->glu_off[1]); dfree(c->leaf_off);
   dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
@@ -1121,7 +1125,8 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.max_dim = c->cfg.max_search_dim;
     tp.hp_rx = c->hp_rx;
     tp.hp_ry = c->hp_ry;
-    tp.kcols = tp.krows = c->interp_k;
+    tp.kcols = c->interp_ky;  // ("ky" widens the columns, "kx" the rows: tracker.py:585-590)
+    tp.krows = c->interp_kx;
     tp.bbox_part = c->bbox_part;
     tp.tmpl_valid = c->tmpl_valid;
     tp.tmpl_hist_v = c->tmpl_hist_v;
@@ -1172,6 +1177,14 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     sf.sse = c->sse;
     sf.sse_copy = c->keep_sse ? c->sse_copy : nullptr;
     sf.linear = c->interp_k == 1;
+    sf.kx = c->interp_kx;
+    sf.ky = c->interp_ky;
+    if (c->interp_k == 0) {
+      sf.glu_v = c->glu[0];
+      sf.glu_v_off = c->glu_off[0];
+      sf.glu_u = c->glu[1];
+      sf.glu_u_off = c->glu_off[1];
+    }
     {
       StageTimer t(c, ST_SPLINE_FIT);
       hipLaunchKernelGGL(k_spline_fit, dim3(c->P), dim3(BLK), 0, c->stream, sf);
@@ -1218,6 +1231,9 @@ static int update_weights_impl(glh_ctx* c, const int32_t* images, bool projected
   wa.fast = use_fast(c);
   wa.cell_cap = cell_cap(c);
   wa.linear = c->interp_k == 1;
+  wa.general = c->interp_k == 0;
+  wa.kx = c->interp_kx;
+  wa.ky = c->interp_ky;
   wa.surf = surfaces(c);
   {
     StageTimer t(c, ST_WEIGHTS);
@@ -1327,6 +1343,7 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   const int O = c->cfg.n_observers;
   if (O > PT_MAX_OBS || c->tw > PT_MAX_TILE || c->th > PT_MAX_TILE) return false;
   // (other median windows and bilinear sampling run on the general instantiations: fused_step)
+  if (c->interp_k == 0) return false;  // orders other than (3, 3) / (1, 1): staged kernels
 
   int nb = 256;
   for (int o = 0; o < O; ++o) {
@@ -1666,9 +1683,36 @@ extern "C" int glh_set_highpass(glh_ctx* c, int size_x, int size_y) {
 
 extern "C" int glh_set_interpolation(glh_ctx* c, int kx, int ky) {
   if (!c) return fail(GLH_E_INVALID, "null context");
-  if (!((kx == 3 && ky == 3) || (kx == 1 && ky == 1)))
-    return fail(GLH_E_UNSUPPORTED, "interpolation orders (%d, %d): bicubic (3, 3) or bilinear (1, 1)", kx, ky);
-  c->interp_k = kx;
+  if (kx < 1 || kx > GLH_SPL_KMAX || ky < 1 || ky > GLH_SPL_KMAX)
+    return fail(GLH_E_UNSUPPORTED, "interpolation orders (%d, %d): each of 1 .. %d (RectBivariateSpline)", kx, ky,
+                GLH_SPL_KMAX);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  for (int q = 0; q < 2; ++q) {
+    dfree(c->glu[q]);
+    dfree(c->glu_off[q]);
+  }
+  c->interp_kx = kx;
+  c->interp_ky = ky;
+  c->interp_k = (kx == 3 && ky == 3) ? 3 : ((kx == 1 && ky == 1) ? 1 : 0);
+  if (c->interp_k == 0) {
+    // any other orders: banded factors of the degree-k collocation matrices for every surface side up to the workspace's
+    const int maxn = c->cfg.max_search_dim;
+    for (int q = 0; q < 2; ++q) {
+      const int k = q == 0 ? kx : ky;
+      std::vector<int64_t> off(maxn + 1, 0);
+      int64_t total = 0;
+      for (int n = k + 1; n <= maxn; ++n) {
+        off[n] = total;
+        total += (int64_t)(2 * k + 1) * n;
+      }
+      std::vector<double> lu((size_t)total);
+      for (int n = k + 1; n <= maxn; ++n) spline_lu_general(n, k, lu.data() + off[n]);
+      CHK(dalloc(&c->glu[q], (size_t)total));
+      CHK(dalloc(&c->glu_off[q], (size_t)maxn + 1));
+      HIPCHK(hipMemcpy(c->glu[q], lu.data(), (size_t)total * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(c->glu_off[q], off.data(), (size_t)(maxn + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+  }
   return GLH_OK;
 }
 
@@ -2197,10 +2241,69 @@ extern "C" int glh_stage_ssd(int dev, const float* search, int hs, int ws, const
   return GLH_OK;
 }
 
+static int stage_sample_impl(int dev, const float* sse, int ho, int wo, int kx, int ky, const double* box,
+                             const double* uv, int n, double* values, uint8_t* outside);
+
 extern "C" int glh_stage_sample(int dev, const float* sse, int ho, int wo, const double* box, const double* uv, int n,
                                 double* values, uint8_t* outside) {
-  if (!sse || !box || !uv || !values || !outside || ho < 4 || wo < 4 || n <= 0) return fail(GLH_E_INVALID, "bad argument");
+  return stage_sample_impl(dev, sse, ho, wo, 0, 0, box, uv, n, values, outside);
+}
+
+extern "C" int glh_stage_sample_orders(int dev, const float* sse, int ho, int wo, int kx, int ky, const double* box,
+                                       const double* uv, int n, double* values, uint8_t* outside) {
+  if (kx < 1 || kx > GLH_SPL_KMAX || ky < 1 || ky > GLH_SPL_KMAX)
+    return fail(GLH_E_UNSUPPORTED, "interpolation orders (%d, %d): each of 1 .. %d", kx, ky, GLH_SPL_KMAX);
+  return stage_sample_impl(dev, sse, ho, wo, kx, ky, box, uv, n, values, outside);
+}
+
+// kx = ky = 0: the bicubic default (k_spline_fit's own path + spline_eval); else the general orders
+static int stage_sample_impl(int dev, const float* sse, int ho, int wo, int kx, int ky, const double* box,
+                             const double* uv, int n, double* values, uint8_t* outside) {
+  const int need_h = kx ? kx + 1 : 4, need_w = ky ? ky + 1 : 4;
+  if (!sse || !box || !uv || !values || !outside || ho < need_h || wo < need_w || n <= 0)
+    return fail(GLH_E_INVALID, "bad argument");
   HIPCHK(hipSetDevice(dev));
+  if (kx) {
+    std::vector<double> z((size_t)ho * wo);
+    for (size_t i = 0; i < z.size(); ++i) z[i] = (double)sse[i];
+    std::vector<double> fv((size_t)(2 * kx + 1) * ho), fu((size_t)(2 * ky + 1) * wo);
+    spline_lu_general(ho, kx, fv.data());
+    spline_lu_general(wo, ky, fu.data());
+    const int maxn = ho > wo ? ho : wo;
+    std::vector<int64_t> zero(maxn + 1, 0);
+    DevBuf dz, dfv, dfu, doff, dbox, dst, duv, dval, dout;
+    CHK(dz.up(z.data(), z.size() * 8));
+    CHK(dfv.up(fv.data(), fv.size() * 8));
+    CHK(dfu.up(fu.data(), fu.size() * 8));
+    CHK(doff.up(zero.data(), zero.size() * 8));
+    int32_t ibox[4] = {0, 0, wo, ho};
+    int32_t st = GLH_OBS_OK;
+    CHK(dbox.up(ibox, sizeof ibox));
+    CHK(dst.up(&st, sizeof st));
+    SplineFitArgs sf{};
+    sf.o = 0; sf.P = 1; sf.tw = 1; sf.th = 1; sf.sse_cap = ho * wo; sf.max_n = maxn;
+    sf.box = dbox.as<int32_t>();
+    sf.obs_status = dst.as<int32_t>();
+    sf.sse = dz.as<double>();
+    sf.kx = kx; sf.ky = ky;
+    sf.glu_v = dfv.as<double>(); sf.glu_v_off = doff.as<int64_t>();
+    sf.glu_u = dfu.as<double>(); sf.glu_u_off = doff.as<int64_t>();
+    hipLaunchKernelGGL(k_spline_fit, dim3(1), dim3(BLK), 0, 0, sf);
+    CHK(duv.up(uv, (size_t)n * 16));
+    CHK(dval.alloc((size_t)n * 8));
+    CHK(dout.alloc((size_t)n));
+    SampleArgs sa{};
+    sa.coef = dz.as<double>();
+    sa.ho = ho; sa.wo = wo; sa.n = n; sa.kx = kx; sa.ky = ky;
+    for (int k = 0; k < 4; ++k) sa.sb[k] = box[k];
+    sa.uv = duv.as<double>();
+    sa.values = dval.as<double>();
+    sa.outside = dout.as<uint8_t>();
+    hipLaunchKernelGGL(k_sample, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, sa);
+    CHK(finish());
+    CHK(dval.down(values, (size_t)n * 8));
+    return dout.down(outside, (size_t)n);
+  }
   const int maxn = ho > wo ? ho : wo;
   std::vector<int64_t> off(maxn + 1, 0);
   std::vector<double> lu;

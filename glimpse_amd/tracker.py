@@ -111,9 +111,11 @@ class Tracker:
                                       f"highpass={highpass!r}")
         self._highpass_size = size
         orders = (int(interpolation.get("kx", 3)), int(interpolation.get("ky", 3)))
-        if orders not in ((3, 3), (1, 1)) or set(interpolation) - {"kx", "ky"}:
-            raise NotImplementedError("sub-pixel interpolation: bicubic (kx = ky = 3, the reference default) or bilinear "
-                                      f"(kx = ky = 1), not {interpolation}")
+        if not all(1 <= k <= 5 for k in orders) or set(interpolation) - {"kx", "ky"}:
+            # (tracker.py:60, :623: the dict goes to scipy RectBivariateSpline; its orders kx, ky are what the device
+            # implements -- a smoothing factor `s` or a `bbox` would be another spline)
+            raise NotImplementedError("sub-pixel interpolation: interpolating splines of orders kx, ky in 1 .. 5 "
+                                      f"(the reference default is 3, 3), not {interpolation}")
         self._orders = orders
         self.viewshed = viewshed
         self.resample_method = resample_method

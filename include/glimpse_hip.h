@@ -274,13 +274,13 @@ int glh_set_fused(glh_ctx* ctx, int on);
  * the same arithmetic in either mode, so they stay bit-identical to each other).                                */
 int glh_set_math(glh_ctx* ctx, int mode);
 /* Window of the median high-pass filter of every tile (Tracker(highpass={"size": (size_y, size_x)}), tracker.py:59,
- * :530: scipy.ndimage.median_filter): odd sizes up to 7; 5 x 5 (the reference default) unless set.  Other sizes run on
- * the staged kernels.                                                                                           */
+ * :530: scipy.ndimage.median_filter): odd sizes up to 7; 5 x 5 (the reference default) unless set.                                                                                           */
 int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
 /* Orders of the spline that samples the SSD surface at the particles (Tracker(interpolation={"kx": .., "ky": ..}),
  * tracker.py:60, :585-590, :623: scipy RectBivariateSpline(kx, ky), s = 0): (3, 3), the reference default, or (1, 1)
- * -- bilinear; the order also sets the least size of the surface (the search box is widened to order + 1 cells).
- * Other orders: GLH_E_UNSUPPORTED.  (1, 1) runs on the staged kernels.                                            */
+ * -- bilinear; any other orders 1 .. 5 (kx: rows axis, ky: columns axis): the interpolating spline of those degrees with
+ * FITPACK's knots, banded solves of bandwidth k, on the staged kernels.  The orders also set the least size of the
+ * surface (the search box is widened to ky + 1 columns and kx + 1 rows, tracker.py:585-590).                        */
 int glh_set_interpolation(glh_ctx* ctx, int kx, int ky);
 
 /* Diagnostic: the numbers of the GLH_RNG_PHILOX streams of this context's points (global indices point_offset ..),
@@ -406,6 +406,10 @@ int glh_stage_ssd(int device_id, const float* search, int hs, int ws, const floa
  * uv [n][2] -> values [n]; outside [n] flags points outside the box.                         */
 int glh_stage_sample(int device_id, const float* sse, int ho, int wo, const double* box,
                      const double* uv, int n, double* values, uint8_t* outside);
+/* The same for any orders of RectBivariateSpline (kx: rows axis, ky: columns axis, each 1 .. 5; Tracker(interpolation=
+ * {"kx": ..., "ky": ...}), tracker.py:60, :623): ho >= kx + 1, wo >= ky + 1.                                          */
+int glh_stage_sample_orders(int dev, const float* sse, int ho, int wo, int kx, int ky, const double* box,
+                            const double* uv, int n, double* values, uint8_t* outside);
 /* Raster.sample(xy, order) (raster.py:913-1027) at n points: values [n], oob [n] = 1 where the
  * reference would raise (outside the outer limits).                                            */
 int glh_stage_raster_sample(int device_id, const double* z, int nx, int ny, const double* gx,

@@ -175,3 +175,109 @@ def eval_notaknot(coef, cv0, cu0, v, u):
                 sp += coef[qv + i, qu + j] * hv[i] * hu[j]
         out[k] = sp
     return out
+
+
+# ---- any order 1 .. 5 (RectBivariateSpline(kx, ky), s = 0): closed form of what the general kernels do ----
+# FITPACK (fpgrre, interpolation case) puts the interior knots at the data sites for odd degrees and midway between them
+# for even degrees; with unit-spaced sites j = 0 .. n-1 both read  t[i] = i - (k + 1) / 2  for i = k+1 .. n-1, between
+# k + 1 knots at 0 and k + 1 knots at n - 1.
+
+
+def knot_general(i, n, k):
+    """i-th knot (0 <= i < n + k + 1) of the degree-k interpolating spline on sites 0 .. n-1."""
+    if i <= k:
+        return 0.0
+    if i >= n:
+        return float(n - 1)
+    return i - 0.5 * (k + 1)
+
+
+def interval_general(xl, n, k):
+    """l with t[l] <= xl < t[l+1], clamped to [k, n-1] (fpbisp)."""
+    return int(min(max(np.floor(xl + 0.5 * (k + 1)), k), n - 1))
+
+
+def basis_general(x, l, n, k):
+    """The k + 1 non-zero B-splines B_{l-k} .. B_l at x (FITPACK fpbspl)."""
+    h = np.zeros(k + 1)
+    hh = np.zeros(k + 1)
+    h[0] = 1.0
+    for j in range(1, k + 1):
+        hh[:j] = h[:j]
+        h[0] = 0.0
+        for i in range(j):
+            li, lj = l + i + 1, l + i + 1 - j
+            f = hh[i] / (knot_general(li, n, k) - knot_general(lj, n, k))
+            h[i] = h[i] + f * (knot_general(li, n, k) - x)
+            h[i + 1] = f * (x - knot_general(lj, n, k))
+    return h
+
+
+def collocation_general(n, k):
+    """Dense n x n collocation matrix A[i, j] = B_j(site i); banded with |i - j| <= k."""
+    a = np.zeros((n, n))
+    for i in range(n):
+        l = interval_general(float(i), n, k)
+        a[i, l - k : l + 1] = basis_general(float(i), l, n, k)
+    return a
+
+
+def lu_general(n, k):
+    """LU without pivoting of the collocation matrix (totally positive), bandwidth k on either side:
+    (L [n][k]: L[i][d-1] at (i, i-d); u0inv [n]; U [n][k]: U[i][d-1] at (i, i+d))."""
+    a = collocation_general(n, k)
+    L = np.zeros((n, k))
+    for c in range(n):
+        for i in range(c + 1, min(c + k + 1, n)):
+            m = a[i, c] / a[c, c]
+            L[i, i - c - 1] = m
+            a[i, c : min(c + k + 1, n)] -= m * a[c, c : min(c + k + 1, n)]
+            a[i, c] = 0.0
+    U = np.zeros((n, k))
+    for i in range(n):
+        for d in range(1, k + 1):
+            if i + d < n:
+                U[i, d - 1] = a[i, i + d]
+    return L, 1.0 / np.diag(a), U
+
+
+def solve_general(lu, b):
+    """Solve A x = b along axis 0 of b (n, m) with the factors from `lu_general`."""
+    L, u0inv, U = lu
+    n, k = L.shape
+    y = np.array(b, dtype=float)
+    for i in range(1, n):
+        for d in range(1, min(k, i) + 1):
+            y[i] = y[i] - L[i, d - 1] * y[i - d]
+    x = y
+    for i in range(n - 1, -1, -1):
+        acc = x[i]
+        for d in range(1, k + 1):
+            if i + d < n:
+                acc = acc - U[i, d - 1] * x[i + d]
+        x[i] = acc * u0inv[i]
+    return x
+
+
+def fit_general(z, kx, ky):
+    """Coefficients of the interpolating spline of degree kx along the rows axis and ky along the columns axis."""
+    ho, wo = z.shape
+    c = solve_general(lu_general(ho, kx), np.asarray(z, dtype=float))
+    return solve_general(lu_general(wo, ky), c.T).T
+
+
+def eval_general(coef, kx, ky, cv0, cu0, v, u):
+    """Evaluate at points (v, u), arguments clamped to the outermost sites (fpbisp)."""
+    ho, wo = coef.shape
+    out = np.empty(len(u))
+    for p in range(len(u)):
+        vl = min(max(v[p] - cv0, 0.0), ho - 1.0)
+        ul = min(max(u[p] - cu0, 0.0), wo - 1.0)
+        lv, lu_ = interval_general(vl, ho, kx), interval_general(ul, wo, ky)
+        hv, hu = basis_general(vl, lv, ho, kx), basis_general(ul, lu_, wo, ky)
+        sp = 0.0
+        for i in range(kx + 1):
+            for j in range(ky + 1):
+                sp += coef[lv - kx + i, lu_ - ky + j] * hv[i] * hu[j]
+        out[p] = sp
+    return out

@@ -695,9 +695,37 @@ def test_tracking_with_bilinear_interpolation_reproduces_reference(golden, tag):
     np.testing.assert_allclose(tracks.means, g[f"{tag}_means"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(tracks.sigmas, g[f"{tag}_sigmas"], rtol=RTOL, atol=1e-8)
     with pytest.raises(NotImplementedError):
-        glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 1})
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 6, "ky": 1})
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(images)], interpolation={"kx": 3, "ky": 3, "s": 0.1})
+
+
+@pytest.mark.parametrize("orders", [(2, 2), (5, 5), (3, 1), (4, 2)])
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_tracking_with_other_interpolation_orders_reproduces_reference(golden, orders, tag):
+    """Tracker(interpolation={"kx": .., "ky": ..}) with any orders RectBivariateSpline takes (tracker.py:60, :585-590,
+    :623; kx along the rows, ky along the columns -- the orders also set the least size of the surface) against reference
+    runs with the same np.random seed (g23)."""
+    g = golden("g23_orders.npz")
+    scene = golden("g15_ragged.npz")
+    kx, ky = orders
+    cam = camera_from(scene["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f)
+              for i, f in enumerate(scene["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], interpolation={"kx": kx, "ky": ky})
+    wide = tag == "wide"
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200,
+                                          xy_sigma=(0.2, 0.2) if wide else (0.004, 0.004), vxyz=(0.15, 0, 0),
+                                          vxyz_sigma=(0.2, 0.2, 0.0) if wide else (0.002, 0.002, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0) if wide else (0.0005, 0.0005, 0.0))
+              for xy in g["xy"]]
+    np.random.seed(4700 + 10 * kx + ky)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g[f"k{kx}{ky}_{tag}_means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"k{kx}{ky}_{tag}_sigmas"], rtol=RTOL, atol=1e-8)
 
 
 def test_search_workspaces_size_themselves(golden, monkeypatch):

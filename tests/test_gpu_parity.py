@@ -249,3 +249,18 @@ def test_depth_limits_are_refused_up_front(lib):
         with pytest.raises(lib.GlhError, match="float64 frames"):
             ctx.observer_set_depth(0, np.float64)
         ctx.observer_set_depth(0, np.uint16)
+
+
+def test_stage_sample_orders_match_reference(lib, golden):
+    """Observer.sample_tile for every order of RectBivariateSpline (1 .. 5, mixed; g23): the general kernels (banded
+    fit of bandwidth k + evaluation with FITPACK's knots) against the reference's values."""
+    g = golden("g23_orders.npz")
+    for c in range(int(g["n_cases"])):
+        kx, ky = (int(v) for v in g[f"c{c}_k"])
+        got, outside = lib.stage_sample(g[f"c{c}_sse"], g[f"c{c}_box"], g[f"c{c}_uv"], orders=(kx, ky))
+        assert not outside.any()
+        np.testing.assert_allclose(got, g[f"c{c}_val"], rtol=0, atol=5e-12)
+    with pytest.raises(lib.GlhError):
+        lib.stage_sample(g["c0_sse"], g["c0_box"], g["c0_uv"], orders=(6, 3))
+    with pytest.raises(lib.GlhError):
+        lib.stage_sample(np.zeros((2, 9), np.float32), g["c0_box"], g["c0_uv"], orders=(2, 2))  # fewer than kx + 1 rows

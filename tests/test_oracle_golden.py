@@ -459,3 +459,45 @@ def test_oracle_with_bilinear_interpolation(golden, tag):
     res = otracker.track(models, observers, np.arange(6)[:, None], np.ones(5), tile_size=(15, 15))
     np.testing.assert_allclose(res["means"], g[f"{tag}_means"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(res["sigmas"], g[f"{tag}_sigmas"], rtol=1e-9, atol=1e-10)
+
+
+def test_spline_orders_closed_form_matches_reference(golden):
+    """Every order RectBivariateSpline takes (1 .. 5, mixed), g23: the SciPy call the oracle makes AND the closed form the
+    general kernels implement (oracle/spline.py: fit_general / eval_general -- FITPACK's knots, banded solves, fpbspl)
+    against Observer.sample_tile of the reference, down to the least surface size (kx + 1) x (ky + 1)."""
+    from oracle import spline as ospline
+
+    g = golden("g23_orders.npz")
+    for c in range(int(g["n_cases"])):
+        kx, ky = (int(v) for v in g[f"c{c}_k"])
+        sse, box, uv, val = g[f"c{c}_sse"].astype(float), g[f"c{c}_box"], g[f"c{c}_uv"], g[f"c{c}_val"]
+        np.testing.assert_allclose(ospline.sample_tile(uv, sse, box, kx=kx, ky=ky), val, rtol=0, atol=1e-13)
+        cu, cv = ospline.cell_centres(box, sse.shape)
+        coef = ospline.fit_general(sse, kx, ky)
+        got = ospline.eval_general(coef, kx, ky, cv[0], cu[0], uv[:, 1], uv[:, 0])
+        np.testing.assert_allclose(got, val, rtol=0, atol=5e-12)
+    z = np.random.default_rng(0).random((9, 11))
+    np.testing.assert_array_equal(ospline.fit_general(z, 3, 3), ospline.fit_notaknot(z))
+
+
+@pytest.mark.parametrize("orders", [(2, 2), (5, 5), (3, 1), (4, 2)])
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_oracle_with_other_interpolation_orders(golden, orders, tag):
+    """Tracker(interpolation={"kx": .., "ky": ..}) for orders other than (3, 3) and (1, 1): the oracle's whole-track loop
+    against the reference run with the same seed (g23)."""
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    g = golden("g23_orders.npz")
+    scene = golden("g15_ragged.npz")
+    kx, ky = orders
+    observers = [otracker.Observer(list(scene["frames"]), np.tile(scene["cam"], (6, 1)), 0.3, interp=(kx, ky))]
+    wide = tag == "wide"
+    models = [omotion.CartesianMotion(xy=xy, xy_sigma=(0.2, 0.2) if wide else (0.004, 0.004), vxyz=(0.15, 0, 0),
+                                      vxyz_sigma=(0.2, 0.2, 0.0) if wide else (0.002, 0.002, 0.0), axyz=(0, 0, 0),
+                                      axyz_sigma=(0.05, 0.05, 0.0) if wide else (0.0005, 0.0005, 0.0), dem=0.0,
+                                      dem_sigma=0.0, n=200) for xy in g["xy"]]
+    np.random.seed(4700 + 10 * kx + ky)
+    res = otracker.track(models, observers, np.arange(6)[:, None], np.ones(5), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g[f"k{kx}{ky}_{tag}_means"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["sigmas"], g[f"k{kx}{ky}_{tag}_sigmas"], rtol=1e-9, atol=1e-10)

@@ -1066,7 +1066,69 @@ def g21_bilinear():
     np.savez_compressed(os.path.join(OUT, "g21_bilinear.npz"), **out)
 
 
+def g23_orders():
+    """Tracker(interpolation={"kx": ..., "ky": ...}) for every order RectBivariateSpline takes (1 .. 5, mixed): (a)
+    Observer.sample_tile on random surfaces down to the least size (kx + 1 rows, ky + 1 columns) with points on the edges
+    and corners; (b) whole tracks on the g15 scene, clouds wider and narrower than a pixel (the order also sets the least
+    size of the surface: tracker.py:585-590)."""
+    rng = np.random.default_rng(2323)
+    cam = synth.nadir_camera((64, 64))
+    imgs = [ref_image(np.zeros((64, 64), np.uint8), cam, datetime.datetime(2020, 1, 1 + i)) for i in range(2)]
+    obs = glimpse.Observer(imgs)
+    out = {}
+    orders = [(2, 2), (4, 4), (5, 5), (1, 3), (3, 2), (5, 1), (2, 4), (3, 5), (1, 2)]
+    out["orders"] = np.array(orders)
+    case = 0
+    for kx, ky in orders:
+        for ho, wo in [(kx + 1, ky + 1), (kx + 2, ky + 3), (9, 8), (23, 17), (40, 33)]:
+            sse = rng.random((ho, wo)).astype(np.float32)
+            l, t = rng.integers(0, 1000, 2)
+            duv = rng.uniform(-0.5, 0.5, 2)
+            box = np.array([l + 7.5 - 0.5, t + 7.5 - 0.5, l + 7.5 - 0.5 + wo, t + 7.5 - 0.5 + ho]) + np.tile(duv, 2)
+            n = 200
+            uv = np.column_stack((rng.uniform(box[0], box[2], n), rng.uniform(box[1], box[3], n)))
+            uv[0], uv[1], uv[2] = box[0:2], box[2:4], (box[0], box[3])
+            # knots of the even orders sit between the cell centres: points exactly on centres and on midpoints
+            uv[3] = (box[0] + 0.5 + wo // 2, box[1] + 0.5 + ho // 2)
+            uv[4] = (box[0] + 1.0 + wo // 2 - 1, box[1] + 1.0 + ho // 2 - 1)
+            out[f"c{case}_k"] = np.array([kx, ky])
+            out[f"c{case}_sse"], out[f"c{case}_box"], out[f"c{case}_uv"] = sse, box, uv
+            out[f"c{case}_val"] = obs.sample_tile(uv, tile=sse, box=box, grid=False, kx=kx, ky=ky)
+            case += 1
+    out["n_cases"] = case
+
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    cam2 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    seq, _ = synth.make_sequence(cam2, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam2, 3, border_px=70.0, seed=3)
+    g15 = np.load(os.path.join(OUT, "g15_ragged.npz"))
+    assert np.array_equal(g15["frames"], np.stack(seq)) and np.array_equal(g15["cam"], cam2)
+    frames_imgs = [ref_image(seq[i], cam2, t0 + i * day) for i in range(6)]
+    out["xy"] = pts
+    e2e = [(2, 2), (5, 5), (3, 1), (4, 2)]
+    out["e2e_orders"] = np.array(e2e)
+    for kx, ky in e2e:
+        tracker = glimpse.Tracker([glimpse.Observer(frames_imgs, sigma=0.3)], interpolation={"kx": kx, "ky": ky})
+        for tag, sig in (("wide", (0.2, 0.2)), ("tight", (0.004, 0.004))):
+            models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=sig,
+                                              vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0) if tag == "wide" else (0.002, 0.002, 0.0),
+                                              axyz=(0, 0, 0), axyz_sigma=(0.05, 0.05, 0.0) if tag == "wide" else (0.0005, 0.0005, 0.0))
+                      for xy in pts]
+            np.random.seed(4700 + 10 * kx + ky)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tracks = tracker.track(models, tile_size=(15, 15))
+            assert all(e is None for e in tracks.errors)
+            out[f"k{kx}{ky}_{tag}_means"], out[f"k{kx}{ky}_{tag}_sigmas"] = tracks.means, tracks.sigmas
+            print("g23", (kx, ky), tag, "vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g23_orders.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g23" in sys.argv:
+        g23_orders()
+        sys.exit(0)
     if "--g22" in sys.argv:
         g22_variants()
         sys.exit(0)
