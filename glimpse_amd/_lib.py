@@ -240,11 +240,11 @@ class Context:
         check(self.lib.glh_set_interpolation(self.handle, int(kx), int(ky)))
 
     def observer_set_depth(self, obs, dtype):
-        """Sample type of the observer's frames: uint8 (default), uint16, or float64 (one channel); before the first
-        upload."""
+        """Sample type of the observer's frames: uint8 (default), uint16, float32 or float64 (one or three channels);
+        before the first upload."""
         dtype = np.dtype(dtype)
-        if dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
-            raise TypeError(f"frames are uint8, uint16 or float64 (got {dtype})")
+        if dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError(f"frames are uint8, uint16, float32 or float64 (got {dtype})")
         check(self.lib.glh_observer_set_depth(self.handle, obs, 8 * dtype.itemsize))
         self._frame_dtype[obs] = dtype
 

@@ -27,7 +27,7 @@ struct ObsFrame {
   const uint8_t* frame;  // uint8 [H][W][C], or uint16 [H][W][C] when bits == 16
   int32_t on;            // images[o] >= 0
   int32_t width, height, channels;
-  int32_t bits;          // 8 or 16 (unsigned integer samples) or 64 (float64 samples, one channel): glh_observer_set_depth
+  int32_t bits;          // 8 or 16 (unsigned integer samples), 32 (float32 samples) or 64 (float64 samples): glh_observer_set_depth
   uint32_t* bins;        // 16-bit frames: [P][bins16_count(channels)] zeroed key histogram workspace (staged kernels)
   double* fwork;         // float64 frames: [P][fwork_cap] workspace (normalised / matched values of a tile)
   int64_t fwork_cap;
@@ -909,9 +909,141 @@ __device__ void search_tile_from_box16(const uint8_t* frame, int width, int chan
 // kernels only.  The median high-pass runs on the values themselves (the CDF match is monotone: the median of the
 // matched window is the matched median).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double pixel_f64(const uint8_t* frame, int width, int row, int col) {
-  return reinterpret_cast<const double*>(frame)[(size_t)row * width + col];
+// The gray value of a float pixel, in the frame's own arithmetic: one channel as it is; three channels their mean as
+// tile.mean(axis=2) computes it (tracker.py:523-524) -- the sum ((a0 + a1) + a2) and the division by 3 in the dtype of
+// the frame (a float32 frame gives a float32 mean).  bits: 32 (float32) or 64 (float64).
+__device__ __forceinline__ double pixel_float(const uint8_t* frame, int width, int channels, int bits, int row, int col) {
+  const size_t at = ((size_t)row * width + col) * channels;
+  if (bits == 32) {
+    const float* p = reinterpret_cast<const float*>(frame) + at;
+    return channels == 1 ? (double)p[0] : (double)(((p[0] + p[1]) + p[2]) / 3.0f);
+  }
+  const double* p = reinterpret_cast<const double*>(frame) + at;
+  return channels == 1 ? p[0] : ((p[0] + p[1]) + p[2]) / 3.0;
 }
+// np.add.reduce over n contiguous float32 items as NumPy's inner loop sums them (FLOAT_pairwise_sum: fewer than 8 items
+// one after another; up to 128 with 8 interleaved accumulators; longer ranges split at n / 2 rounded down to a multiple
+// of 8) -- what decides the last bit of a float32 mean / std (helpers.normalize on a float32 tile, helpers.py:344).
+__device__ __forceinline__ float np_pairwise_leaf_f32(const float* a, int n) {  // n <= 128
+  if (n < 8) {
+    float res = 0.0f;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  }
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+__device__ float np_pairwise_f32(const float* a, int n) {
+  // the recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2) on an explicit stack (depth <= log2(n / 128) + 1)
+  int off[24], len[24], state[24];
+  float left[24];
+  int sp = 0;
+  off[0] = 0; len[0] = n; state[0] = 0; left[0] = 0.0f;
+  float ret = 0.0f;
+  while (sp >= 0) {
+    if (len[sp] <= 128) {
+      ret = np_pairwise_leaf_f32(a + off[sp], len[sp]);
+      --sp;
+      continue;
+    }
+    int n2 = len[sp] / 2;
+    n2 -= n2 % 8;
+    if (state[sp] == 0) {
+      state[sp] = 1;
+      off[sp + 1] = off[sp]; len[sp + 1] = n2; state[sp + 1] = 0;
+      ++sp;
+    } else if (state[sp] == 1) {
+      left[sp] = ret;
+      state[sp] = 2;
+      off[sp + 1] = off[sp] + n2; len[sp + 1] = len[sp] - n2; state[sp + 1] = 0;
+      ++sp;
+    } else {
+      ret = left[sp] + ret;
+      --sp;
+    }
+  }
+  return ret;
+}
+// ... over a whole contiguous array: the reduction hands the inner loop chunks of 8192 items (np.getbufsize()) and adds
+// their sums to the running total in order (oracle/resample.py: numpy_pairwise_sum states the same for float64)
+__device__ float np_sum_flat_f32(const float* a, int n) {
+  float acc = 0.0f;
+  for (int s0 = 0; s0 < n; s0 += 8192) acc += np_pairwise_f32(a + s0, min(8192, n - s0));
+  return acc;
+}
+
+// normalize (helpers.py:344) of the box into y[n]: (a - a.mean()) * (1 / a.std()); all threads; ends with a barrier.
+// float64 frames: block reductions (the last bits of a float64 mean decide nothing).  float32 frames: float32 arithmetic
+// with NumPy's own summation order, on thread 0 -- a one-channel tile is a strided view of the frame, which NumPy sums
+// row by row (out += pairwise(row)); the channel mean of a three-channel tile is a new contiguous array, summed flat;
+// (a - mean)^2 is contiguous either way.  `tmp`: 2 n floats of scratch that may overlap y (not each other).
+__device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int width, int channels, int bits, const int* box,
+                                                    double* y, float* tmp_g, float* tmp_x2, double* red, bool* const_tile) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  if (bits == 32) {
+    __shared__ float s_mean, s_inv;
+    for (int idx = tid; idx < n; idx += BLK) {
+      const int r = idx / w, c = idx - r * w;
+      tmp_g[idx] = (float)pixel_float(frame, width, channels, 32, box[1] + r, box[0] + c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float acc = 0.0f;
+      if (channels == 1)
+        for (int r = 0; r < h; ++r) acc += np_pairwise_f32(tmp_g + (size_t)r * w, w);
+      else
+        acc = np_sum_flat_f32(tmp_g, n);
+      s_mean = acc / (float)n;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    for (int idx = tid; idx < n; idx += BLK) {
+      const float d = tmp_g[idx] - mean;
+      tmp_x2[idx] = d * d;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float var = np_sum_flat_f32(tmp_x2, n) / (float)n;
+      s_inv = 1.0f / sqrtf(var);
+      if (const_tile) *const_tile = !(var > 0.0f);
+    }
+    __syncthreads();
+    const float inv = s_inv;
+    // (y may overlap tmp_x2: every thread reads its g before anybody writes y -- g and y do not overlap)
+    for (int idx = tid; idx < n; idx += BLK) y[idx] = (double)((tmp_g[idx] - mean) * inv);
+    __syncthreads();
+    return;
+  }
+  double sx = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const int r = idx / w, c = idx - r * w;
+    const double x = pixel_float(frame, width, channels, 64, box[1] + r, box[0] + c);
+    y[idx] = x;
+    sx += x;
+  }
+  const double mean = block_sum(sx, red) / (double)n;
+  double sq = 0.0;
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double d = y[idx] - mean;
+    sq += d * d;
+  }
+  const double var = block_sum(sq, red) / (double)n;
+  const double inv_std = 1.0 / sqrt(var);
+  if (tid == 0 && const_tile) *const_tile = !(var > 0.0);
+  for (int idx = tid; idx < n; idx += BLK) y[idx] = (y[idx] - mean) * inv_std;
+  __syncthreads();
+}
+
 // scipy.ndimage.median_filter(size = (2 ry + 1, 2 rx + 1), mode = 'reflect') of a w x h array of doubles at (r, c)
 __device__ __forceinline__ double median_window_f64(const double* a, int w, int h, int r, int c, int rx, int ry) {
   double v[49];
@@ -929,37 +1061,14 @@ __device__ __forceinline__ double median_window_f64(const double* a, int w, int 
   }
   return best;
 }
-// normalize (helpers.py:344) of the box into y[n]: (a - a.mean()) * (1 / a.std()); all threads; ends with a barrier
-__device__ __forceinline__ void normalize_box_f64(const uint8_t* frame, int width, const int* box, double* y, double* red,
-                                                  bool* const_tile) {
-  const int tid = threadIdx.x;
-  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  double sx = 0.0;
-  for (int idx = tid; idx < n; idx += BLK) {
-    const int r = idx / w, c = idx - r * w;
-    const double x = pixel_f64(frame, width, box[1] + r, box[0] + c);
-    y[idx] = x;
-    sx += x;
-  }
-  const double mean = block_sum(sx, red) / (double)n;
-  double sq = 0.0;
-  for (int idx = tid; idx < n; idx += BLK) {
-    const double d = y[idx] - mean;
-    sq += d * d;
-  }
-  const double var = block_sum(sq, red) / (double)n;
-  const double inv_std = 1.0 / sqrt(var);
-  if (tid == 0 && const_tile) *const_tile = !(var > 0.0);
-  for (int idx = tid; idx < n; idx += BLK) y[idx] = (y[idx] - mean) * inv_std;
-  __syncthreads();
-}
-
 // template: y [n] and cnt [n] (uint32) in shared memory (n = tw * th)
-__device__ void template_from_boxf(const uint8_t* frame, int width, const int* box, double* y, uint32_t* cnt,
-                                   double* red, TemplateOut out, bool* const_tile, int hp_rx, int hp_ry) {
+__device__ void template_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box, double* y,
+                                   uint32_t* cnt, double* red, TemplateOut out, bool* const_tile, int hp_rx, int hp_ry) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  normalize_box_f64(frame, width, box, y, red, const_tile);
+  // (float32 scratch: the gray values over cnt, the squares over the first half of y -- both dead before they are reused)
+  normalize_box_float(frame, width, channels, bits, box, y, reinterpret_cast<float*>(cnt), reinterpret_cast<float*>(y), red,
+                      const_tile);
   // pass 1: pixels at or below this one (the cumulative count of its value), and whether an equal one precedes it
   for (int idx = tid; idx < n; idx += BLK) {
     const double yi = y[idx];
@@ -988,18 +1097,19 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, const int* b
   for (int idx = tid; idx < n; idx += BLK) {
     const int r = idx / w, c = idx - r * w;
     const double t = y[idx] - median_window_f64(y, w, h, r, c, hp_rx, hp_ry);
-    out.tile64[idx] = t;
+    out.tile64[idx] = bits == 32 ? (double)(float)t : t;  // (a float32 frame has a float32 template tile)
     out.tile32[idx] = (float)t;
   }
 }
 
 // search tile: work [2 n] doubles of memory (the normalised values, behind them the matched ones); the template CDF
-__device__ void search_tile_from_boxf(const uint8_t* frame, int width, const int* box, const double* hist_v,
-                                      const double* hist_q, int hist_n, double* work, double* red, float* out, int hp_rx,
-                                      int hp_ry) {
+__device__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
+                                      const double* hist_v, const double* hist_q, int hist_n, double* work, double* red,
+                                      float* out, int hp_rx, int hp_ry) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  normalize_box_f64(frame, width, box, work, red, nullptr);
+  float* scratch = reinterpret_cast<float*>(work + n);  // (the matched values go there afterwards)
+  normalize_box_float(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
   // helpers.match_cdf: quantile of every pixel = (pixels at or below it) / size, through np.interp of the template CDF
   double* matched = work + n;
   for (int idx = tid; idx < n; idx += BLK) {
@@ -1075,8 +1185,8 @@ __global__ __launch_bounds__(BLK) void k_template_init(TemplateArgs a) {
   out.hist_v = a.tmpl_hist_v + slot * a.tile_cap;
   out.hist_q = a.tmpl_hist_q + slot * a.tile_cap;
   out.hist_n = a.tmpl_hist_n + slot;
-  if (a.obs.bits == 64)
-    template_from_boxf(a.obs.frame, a.obs.width, s_box, reinterpret_cast<double*>(smem),
+  if (a.obs.bits >= 32)
+    template_from_boxf(a.obs.frame, a.obs.width, a.obs.channels, a.obs.bits, s_box, reinterpret_cast<double*>(smem),
                        reinterpret_cast<uint32_t*>(smem + (size_t)a.tw * a.th * 8), red, out, &s_const, a.hp_rx, a.hp_ry);
   else if (a.obs.bits == 16)
     template_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, reinterpret_cast<uint32_t*>(smem),
@@ -1298,8 +1408,8 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   }
   __syncthreads();
   if (s_status != GLH_OBS_OK) return;
-  if (a.obs.bits == 64)
-    search_tile_from_boxf(a.obs.frame, a.obs.width, s_box, a.tmpl_hist_v + slot * a.tile_cap,
+  if (a.obs.bits >= 32)
+    search_tile_from_boxf(a.obs.frame, a.obs.width, a.obs.channels, a.obs.bits, s_box, a.tmpl_hist_v + slot * a.tile_cap,
                           a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot], a.obs.fwork + (size_t)pt * a.obs.fwork_cap,
                           &red[0][0], a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
   else if (a.obs.bits == 16)

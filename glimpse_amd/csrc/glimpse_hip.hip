@@ -109,7 +109,7 @@ static const char* kStageNames[ST_COUNT] = {"init_particles", "evolve_project", 
 // ------------------------------------------------------------------------------------------
 struct Observer {
   int n_images = 0, width = 0, height = 0, channels = 0;
-  int bits = 8;  // bits per sample of the frames: 8, or 16 (glh_observer_set_depth)
+  int bits = 8;  // bits per sample of the frames: 8 or 16 (unsigned integers), 32 (float32), 64 (float64): glh_observer_set_depth
   size_t frame_bytes() const { return (size_t)width * height * channels * (bits / 8); }
   double sigma = 0.3;
   CamDev* cams = nullptr;               // device [n_images]
@@ -499,20 +499,21 @@ extern "C" int glh_observer_init(glh_ctx* c, int o, int n_images, int width, int
 
 extern "C" int glh_observer_set_depth(glh_ctx* c, int o, int bits) {
   CHK(check_obs(c, o));
-  if (bits != 8 && bits != 16 && bits != 64)
-    return fail(GLH_E_UNSUPPORTED, "frames are 8 or 16 bits per sample, or 64 = float64 samples (got %d)", bits);
+  if (bits != 8 && bits != 16 && bits != 32 && bits != 64)
+    return fail(GLH_E_UNSUPPORTED, "frames are 8 or 16 bits per sample (unsigned), 32 = float32 or 64 = float64 samples "
+                                   "(got %d)", bits);
   Observer& ob = c->obs[o];
   if (ob.n_images <= 0) return fail(GLH_E_STATE, "glh_observer_init first");
-  if (bits == 64 && ob.channels != 1)
-    return fail(GLH_E_UNSUPPORTED, "float64 frames have one channel (observer %d has %d)", o, ob.channels);
+  if (bits >= 32 && ob.channels != 1 && ob.channels != 3)
+    return fail(GLH_E_UNSUPPORTED, "float frames have one or three channels (observer %d has %d)", o, ob.channels);
   for (auto& p : ob.owned)
     if (p) return fail(GLH_E_STATE, "observer %d: set the depth before uploading frames", o);
   // what the wider tile kernels are sized for (their LDS requests grow with the context's limits)
   if (bits == 16 && (size_t)(BAND_H + 6) * c->cfg.max_search_dim * 4 > 96 * 1024)
     return fail(GLH_E_UNSUPPORTED, "16-bit frames: max_search_dim %d exceeds %d (one median band must fit 96 KiB of LDS)",
                 c->cfg.max_search_dim, (int)(96 * 1024 / ((BAND_H + 6) * 4)));
-  if (bits == 64 && (size_t)c->cfg.max_tile * c->cfg.max_tile * 12 > 64 * 1024)
-    return fail(GLH_E_UNSUPPORTED, "float64 frames: max_tile %d exceeds 73 (template workspace of 64 KiB of LDS)",
+  if (bits >= 32 && (size_t)c->cfg.max_tile * c->cfg.max_tile * 12 > 64 * 1024)
+    return fail(GLH_E_UNSUPPORTED, "float frames: max_tile %d exceeds 73 (template workspace of 64 KiB of LDS)",
                 c->cfg.max_tile);
   ob.bits = bits;
   return GLH_OK;
@@ -966,7 +967,7 @@ static void fill_obs(glh_ctx* c, int o, int image, ObsFrame* f) {
 
 // 16-bit frames: the zeroed per-point key histograms the staged tile kernels of observer `o` count into
 static int prepare_bins16(glh_ctx* c, int o) {
-  if (c->obs[o].bits == 64 && !c->fwork)  // float64 frames: two tile-sized arrays of doubles per point
+  if (c->obs[o].bits >= 32 && !c->fwork)  // float frames: two tile-sized arrays of doubles per point
     CHK(dalloc(&c->fwork, (size_t)c->cfg.max_points * 2 * c->cfg.max_search_dim * c->cfg.max_search_dim));
   if (c->obs[o].bits != 16) return GLH_OK;
   const size_t per = (size_t)(65535 * 3 + 1);
@@ -1094,7 +1095,7 @@ extern "C" int glh_init_templates(glh_ctx* c, int o, int image) {
   {
     StageTimer t(c, ST_TEMPLATE);
     hipLaunchKernelGGL(k_template_init, dim3(c->P), dim3(BLK),
-                       (size_t)c->tw * c->th * (ob.bits == 64 ? 12 : (ob.bits == 16 ? 4 : 2)), c->stream, a);
+                       (size_t)c->tw * c->th * (ob.bits >= 32 ? 12 : (ob.bits == 16 ? 4 : 2)), c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return GLH_OK;

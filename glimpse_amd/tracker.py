@@ -195,9 +195,10 @@ class Tracker:
                            max_search_dim=search_dim, max_frames=n_frames)
         for o, obs in enumerate(self.observers):
             first = obs.images[0].read()
-            if first.dtype not in (np.uint8, np.uint16, np.float64) or (first.dtype == np.float64 and first.ndim != 2):
-                raise NotImplementedError("frames must be uint8 or uint16 (gray or RGB) or one-channel float64 on the GPU "
-                                          f"path, not {first.dtype} {first.shape}")
+            if first.dtype not in (np.uint8, np.uint16, np.float32, np.float64) or \
+                    (first.ndim == 3 and first.shape[2] not in (1, 3)):
+                raise NotImplementedError("frames must be uint8, uint16, float32 or float64 with one or three channels on "
+                                          f"the GPU path, not {first.dtype} {first.shape}")
             h, w = first.shape[:2]
             ch = 1 if first.ndim == 2 else first.shape[2]
             ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
@@ -750,9 +751,10 @@ class Tracker:
                                max_search_dim=self.max_search_dim or 320, max_frames=2)
             for o, obs in enumerate(self.observers):
                 a0 = obs.images[0].read()
-                if a0.dtype not in (np.uint8, np.uint16, np.float64) or (a0.dtype == np.float64 and a0.ndim != 2):
-                    raise NotImplementedError("frames must be uint8, uint16 or one-channel float64 on the GPU path, not "
-                                              f"{a0.dtype} {a0.shape}")
+                if a0.dtype not in (np.uint8, np.uint16, np.float32, np.float64) or \
+                        (a0.ndim == 3 and a0.shape[2] not in (1, 3)):
+                    raise NotImplementedError("frames must be uint8, uint16, float32 or float64 with one or three channels "
+                                              f"on the GPU path, not {a0.dtype} {a0.shape}")
                 ctx.observer_init(o, len(obs.images), a0.shape[1], a0.shape[0], 1 if a0.ndim == 2 else a0.shape[2],
                                   obs.sigma)
                 ctx.observer_set_depth(o, a0.dtype)

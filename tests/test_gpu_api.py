@@ -601,7 +601,7 @@ def test_tracking_on_uint16_frames_reproduces_reference(golden, name, channels):
         tr = t2.track(models, tile_size=(15, 15), rng="philox", seed=3)
     assert np.isfinite(tr.means).all() and np.all(np.abs(tr.means[:, -1, 3] - 0.15) < 0.06)
     # other sample types are refused, not cast
-    bad = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f.astype(np.float32))
+    bad = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f.astype(np.int32))
            for i, f in enumerate(frames)]
     with pytest.raises(NotImplementedError):
         glimpse_amd.Tracker([glimpse_amd.Observer(bad, sigma=0.3)]).track(models, tile_size=(15, 15))
@@ -663,11 +663,42 @@ def test_tracking_on_float64_frames_reproduces_reference(golden):
         warnings.simplefilter("ignore")
         tr = tracker.track(models, tile_size=(15, 15), rng="philox", seed=3)
     assert np.isfinite(tr.means).all() and np.all(np.abs(tr.means[:, -1, 3] - 0.15) < 0.06)
-    # RGB float frames are refused (their channel mean has dtype-dependent rounding in the reference)
-    rgb = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=np.stack([f, f, f], axis=2))
-           for i, f in enumerate(frames)]
-    with pytest.raises(NotImplementedError):
-        glimpse_amd.Tracker([glimpse_amd.Observer(rgb, sigma=0.3)]).track(models, tile_size=(15, 15))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f32rgb", "f64rgb"])
+def test_tracking_float32_and_multichannel_float_frames_reproduces_reference(golden, tag):
+    """float32 frames (one or three channels) and three-channel float64 frames (tracker.py:494-534 works on any dtype):
+    the reference normalises a tile in the frame's own dtype -- a float32 mean, standard deviation and scaling, summed in
+    NumPy's order (row by row over the strided view of a one-channel tile, flat over the channel mean of an RGB one) --
+    and so does the device: the template of a float32 frame (tile and sorted distinct values) equals the reference's BIT
+    FOR BIT, the tracks follow (g24, reference run under this container's NumPy, same np.random seed)."""
+    from tests.test_oracle_golden import float_scenes
+
+    g = golden("g24_float_frames.npz")
+    cam_vec, scenes = float_scenes()
+    frames = scenes[tag]
+    cam = camera_from(cam_vec)
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(frames)]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in g["xy"]]
+    np.random.seed(4300 + len(tag))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    assert all(e is None for e in tracks.errors)
+    tpl = tracker._ctx.get_template(0, len(models) - 1)
+    np.testing.assert_array_equal(tpl["box"], g[f"{tag}_tpl_box"])
+    np.testing.assert_array_equal(tpl["histogram"][1], g[f"{tag}_tpl_hist_q"])
+    if tag.startswith("f32"):
+        np.testing.assert_array_equal(tpl["histogram"][0], g[f"{tag}_tpl_hist_v"].astype(np.float64))
+        np.testing.assert_array_equal(tpl["tile"], g[f"{tag}_tpl_tile"].astype(np.float64))
+    else:
+        np.testing.assert_allclose(tpl["histogram"][0], g[f"{tag}_tpl_hist_v"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(tpl["tile"], g[f"{tag}_tpl_tile"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(tracks.means, g[f"{tag}_means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"{tag}_sigmas"], rtol=RTOL, atol=1e-8)
 
 
 @pytest.mark.parametrize("tag", ["wide", "tight"])

@@ -414,6 +414,45 @@ def float64_scene():
     return cam, frames
 
 
+def float_scenes():
+    """The float scenes of g24 (tools/make_golden.py: float_scenes)."""
+    cam, frames64 = float64_scene()
+
+    def rgb(f):
+        return np.stack([f, 0.9 * f + 0.05, np.roll(f, 1, axis=1) * 1.1 - 0.1], axis=2)
+
+    return cam, {"f32": [f.astype(np.float32) for f in frames64], "f32rgb": [rgb(f).astype(np.float32) for f in frames64],
+                 "f64rgb": [rgb(f) for f in frames64]}
+
+
+@pytest.mark.parametrize("tag", ["f32", "f32rgb", "f64rgb"])
+def test_oracle_on_float32_and_multichannel_float_frames(golden, tag):
+    """float32 frames and three-channel float frames (tracker.py:494-534 works on any dtype; the normalisation then runs
+    in the frame's dtype): the oracle's tiles for explicit boxes and its whole tracks against the reference (g24, under this
+    container's NumPy)."""
+    from oracle import motion as omotion
+    from oracle import tracker as otracker
+
+    g = golden("g24_float_frames.npz")
+    cam, scenes = float_scenes()
+    frames = scenes[tag]
+    assert np.float64(sum(float(np.asarray(f, dtype=np.float64).sum()) for f in frames)) == g[f"{tag}_checksum"]
+    tile, hist = tiles.extract_tile(frames[0], g["tbox"], return_histogram=True)
+    assert tile.dtype == g[f"{tag}_tile"].dtype and hist[0].dtype == g[f"{tag}_hist_v"].dtype
+    np.testing.assert_array_equal(tile, g[f"{tag}_tile"])
+    np.testing.assert_array_equal(hist[0], g[f"{tag}_hist_v"])
+    np.testing.assert_array_equal(hist[1], g[f"{tag}_hist_q"])
+    np.testing.assert_array_equal(tiles.extract_tile(frames[1], g["sbox"], histogram=hist), g[f"{tag}_search"])
+    T = len(frames)
+    observers = [otracker.Observer(frames, np.tile(cam, (T, 1)), 0.3)]
+    models = [omotion.CartesianMotion(xy=xy, xy_sigma=(0.2, 0.2), vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                      axyz_sigma=(0.05, 0.05, 0.0), dem=0.0, dem_sigma=0.0, n=200) for xy in g["xy"]]
+    np.random.seed(4300 + len(tag))
+    res = otracker.track(models, observers, np.arange(T)[:, None], np.ones(T - 1), tile_size=(15, 15))
+    np.testing.assert_allclose(res["means"], g[f"{tag}_means"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(res["sigmas"], g[f"{tag}_sigmas"], rtol=1e-9, atol=1e-10)
+
+
 def test_oracle_on_float64_frames(golden):
     """float64 frames (tracker.py:494-534 works on any dtype): the oracle's tiles for explicit boxes and its
     whole-track loop on np.random against the reference run with the same seed (g20)."""

@@ -1125,7 +1125,60 @@ def g23_orders():
     np.savez_compressed(os.path.join(OUT, "g23_orders.npz"), **out)
 
 
+def float_scenes():
+    """The float scenes of g24 (tests regenerate them from the same recipe: glimpse_amd.synth only): float32 one channel,
+    float32 three channels, float64 three channels -- the reflectance-like doubles of g20, narrowed / spread over
+    channels that differ by a gain, an offset and a one-pixel shift (so that the channel mean is not any one channel)."""
+    cam, frames64 = scene64()
+    f32 = [f.astype(np.float32) for f in frames64]
+
+    def rgb(f):
+        return np.stack([f, 0.9 * f + 0.05, np.roll(f, 1, axis=1) * 1.1 - 0.1], axis=2)
+
+    return cam, {"f32": f32, "f32rgb": [rgb(f).astype(np.float32) for f in frames64], "f64rgb": [rgb(f) for f in frames64]}
+
+
+def g24_float_frames():
+    """float32 frames and multi-channel float frames (Tracker.extract_tile works on any dtype, tracker.py:494-534; the
+    arithmetic then runs in the frame's dtype under NumPy's rules -- these are outputs of the reference under the
+    container's NumPy 2.2): whole tracks, the last track's template, tiles for explicit boxes."""
+    day = datetime.timedelta(days=1)
+    t0 = datetime.datetime(2020, 1, 1)
+    cam, scenes = float_scenes()
+    pts = synth.grid_points(cam, 3, border_px=70.0, seed=3)
+    out = {"xy": pts, "numpy": np.array(np.__version__)}
+    for tag, frames in scenes.items():
+        imgs = [ref_image(frames[i], cam, t0 + i * day) for i in range(len(frames))]
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+        models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in pts]
+        np.random.seed(4300 + len(tag))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15))
+        assert all(e is None for e in tracks.errors)
+        tpl = tracker.templates[0]
+        out.update({f"{tag}_means": tracks.means, f"{tag}_sigmas": tracks.sigmas,
+                    f"{tag}_checksum": np.float64(sum(float(np.asarray(f, dtype=np.float64).sum()) for f in frames)),
+                    f"{tag}_tpl_tile": tpl["tile"], f"{tag}_tpl_hist_v": tpl["histogram"][0],
+                    f"{tag}_tpl_hist_q": tpl["histogram"][1], f"{tag}_tpl_box": np.asarray(tpl["box"])})
+        bt, bs = np.array((100, 90, 115, 105)), np.array((92, 80, 126, 117))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tile, hist = tracker.extract_tile(obs=0, img=0, box=bt, return_histogram=True)
+            search = tracker.extract_tile(obs=0, img=1, box=bs, histogram=hist)
+        out.update({f"{tag}_tile": tile, f"{tag}_hist_v": hist[0], f"{tag}_hist_q": hist[1], f"{tag}_search": search})
+        out["tbox"], out["sbox"] = bt, bs
+        print("g24", tag, "vx:", tracks.means[:, -1, 3], "tile dtype", tile.dtype, "hist dtype", hist[0].dtype, "search dtype",
+              search.dtype, "distinct", len(hist[0]), "of", tile.size)
+    np.savez_compressed(os.path.join(OUT, "g24_float_frames.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--g24" in sys.argv:
+        g24_float_frames()
+        sys.exit(0)
     if "--g23" in sys.argv:
         g23_orders()
         sys.exit(0)
