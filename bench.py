@@ -195,6 +195,18 @@ def pmc_traffic(wl, kernel):
     return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
+def sq_counters(wl):
+    """VALU wave-instructions per 64 particle-frames of the fused kernel from the committed SQ counter pass of this
+    workload shape (C3 only: the pass is expensive), or None."""
+    if (wl.name, wl.P, wl.N, wl.channels) != ("C3", 4096, 5000, 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_C3_sq_counters.json")) as f:
+            return float(json.load(f)["derived"]["valu_wave_instructions_per_64_particle_frames"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes_per_step(P, N, O, tile, boxes, status, channels=1):
     """P*(96 N) state + per observer (Ws*Hs*s_img + 20*tw*th + 96) per point (s_img = bytes per pixel)."""
     tw, th = tile
@@ -713,6 +725,17 @@ def worker(args):
                 "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
         out["roofline"] = roof
+        # The other ceiling, for the record: the step is bound by VALU issue, not by memory.  Wave-level
+        # VALU instructions per launch from the committed SQ counters of this workload (SQ_INSTS_VALU, rocprofv3 --pmc)
+        # against what the chip can issue: 256 CUs x 4 SIMDs, one 64-lane float64 / 3-operand instruction per 4 cycles.
+        sq = sq_counters(wl)
+        if sq is not None:
+            insts = sq * wl.P * wl.N / 64.0
+            peak_rate = 256 * 4 * 2.4e9 / 4.0
+            roof["valu_issue"] = {"wave_instructions_per_launch": insts, "per_64_particle_frames": sq,
+                                  "frac_of_issue_peak": insts / (peak_rate * per_launch_ms * 1e-3),
+                                  "model": "1 wave-instruction / 4 cycles / SIMD at 2.4 GHz, 1024 SIMDs",
+                                  "source": "profiles/r03_C3_sq_counters.json"}
         out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
         if len(launch_ms) == dom_n and launches_per_frame == 1:
             tail = launch_ms[-min(20, K * F):]
