@@ -605,20 +605,6 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
     }
   };
-  auto evolved = [&](int k, double* x) {
-    const int rec = COMMON || uin ? (int)uin[k] : k;
-    const double2* src = Pin2 + (size_t)rec * rec_stride;
-    const double2 v0 = src[0], v1 = src[chunk_stride], v2 = src[2 * chunk_stride];
-    x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y;
-    double n[3];
-    evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
-    if constexpr (SURF) {
-      bool oob = false;  // (flagged by phase A, which evolved the same particle)
-      evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &oob);
-    } else {
-      evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
-    }
-  };
 
   // ---------------- A: evolve, NaN test, project, bounding boxes -------------------------------
   // Observer 0's uv.  PPT > 0: u in PPT registers per thread, v parked in c[i] (LDS, free until phase C).
@@ -1382,10 +1368,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   for (int k = 0; k < 6; ++k) K[k] = s_K[k];
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
   constexpr int GU = 2;  // records in flight per thread
-  // One 16-wave workgroup per CU (TB >= 1024): the record index of a survivor, uin[source], is a memory load the record
-  // loads depend on, and nothing else on the CU hides it -- so the words of the NEXT iteration (source | copies from the
-  // rank table, record index from memory) are fetched while this iteration's records are evolved.
-  constexpr bool E_PIPELINED = TB >= 1024;
+  // The record index of a survivor, uin[source], is a memory load the record loads depend on: the words of the NEXT
+  // iteration (source | copies from the rank table, record index from memory) are fetched while this iteration's
+  // records are evolved (C4, whose 16-wave workgroup has its CU to itself: -0.8 %; C3 / C5: -0.2 .. -0.4 %).
   uint32_t sc_n[GU];
   int rec_n[GU];
   auto fetch_next = [&](int h0) {
@@ -1396,11 +1381,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       rec_n[g] = COMMON || uin ? (int)uin[sc_n[g] & 0xffffu] : (int)(sc_n[g] & 0xffffu);
     }
   };
-  if constexpr (E_PIPELINED) fetch_next(tid);
+  fetch_next(tid);
   for (int h0 = tid; h0 < U; h0 += GU * TB) {
     int lo[GU], cnt[GU];
     double x[GU][6], w[GU];
-    if constexpr (E_PIPELINED) {
+    {
       double2 v[GU][3];
 #pragma unroll
       for (int g = 0; g < GU; ++g) {
@@ -1414,19 +1399,6 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       for (int g = 0; g < GU; ++g) {
         x[g][0] = v[g][0].x; x[g][1] = v[g][0].y; x[g][2] = v[g][1].x; x[g][3] = v[g][1].y; x[g][4] = v[g][2].x; x[g][5] = v[g][2].y;
         evolve_loaded(lo[g], x[g]);
-        w[g] = c[lo[g]];
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < GU; ++g) {
-        const int h = h0 + g * TB;
-        const uint32_t sc = h < U ? usc[h] : 0u;
-        lo[g] = (int)(sc & 0xffffu);
-        cnt[g] = (int)(sc >> 16);
-      }
-#pragma unroll
-      for (int g = 0; g < GU; ++g) {
-        evolved(lo[g], x[g]);
         w[g] = c[lo[g]];
       }
     }
