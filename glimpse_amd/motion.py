@@ -1,11 +1,12 @@
 """Motion models (/root/reference/src/glimpse/track/motion.py).
 
 `CartesianMotion` (motion.py:92-204), `CylindricalMotion` (:207-311), `TangentCartesianMotion`
-(:314-412) and `TangentCylindricalMotion` (:415-522) with constant (scalar) `dem` / `dem_sigma`
-surfaces: the Tracker reads their parameters (`params_full`) and initialises / evolves the
-particles on the device.  Their methods are kept as host NumPy conveniences with the
-reference's semantics (legacy `np.random` draws in the same order) for users who call them
-directly; the Tracker does not use them.  Gridded DEM rasters are "next" (SURVEY.md 8(f) rank 1).
+(:314-412) and `TangentCylindricalMotion` (:415-522) with constant or gridded (`glimpse_amd.Raster`)
+`dem` / `dem_sigma` surfaces: the Tracker reads their parameters (`params_table`) and initialises /
+evolves the particles on the device.  Their methods are host NumPy code with the reference's semantics
+(legacy `np.random` draws in the same order) for users who call them directly and for the per-track
+loop (`Tracker._track_custom`: residual resampling on the np.random stream); the batched Tracker does
+not use them.  `Motion` is the reference's minimal model / interface statement (motion.py:13-89).
 """
 import numpy as np
 
@@ -65,7 +66,10 @@ def params_table(models):
 
 
 class Motion:
-    """Interface illustration (motion.py:13-89)."""
+    """The minimal motion model of the reference (motion.py:13-89), which doubles as the statement of the interface a
+    `Tracker` asks of any model: every particle starts AT `xy` with z = 0 and a velocity drawn around zero, moves with
+    that velocity, and contributes no likelihood term.  Used as it is, or subclassed, it runs like any user-defined model:
+    its methods on the host, everything else on the device (`Tracker._track_custom`)."""
 
     def __init__(self, xy, time_unit, n=1000, vxyz_sigma=(0, 0, 0)):
         self.xy = xy
@@ -73,13 +77,29 @@ class Motion:
         self.n = n
         self.vxyz_sigma = vxyz_sigma
 
+    def initialize_particles(self):
+        """(n, 6) particles (x, y, z, vx, vy, vz): motion.py:54-64 -- one randn(n, 3) draw, for the velocities."""
+        particles = np.zeros((self.n, 6), dtype=float)
+        particles[:, 0:2] = self.xy
+        particles[:, 3:6] = self.vxyz_sigma * np.random.randn(self.n, 3)
+        return particles
+
+    def evolve_particles(self, particles, dt):
+        """In place, motion.py:66-76: positions advance by the velocities, no draw."""
+        steps = dt.total_seconds() / self.time_unit.total_seconds()
+        particles[:, 0:3] += steps * particles[:, 3:6]
+
+    def compute_log_likelihoods(self, particles):
+        """motion.py:78-89: this model has no likelihood term."""
+        return None
+
 
 class CartesianMotion(Motion):
     def __init__(self, xy, time_unit, dem, dem_sigma=None, n=1000, xy_sigma=(0, 0), vxyz=(0, 0, 0),
                  vxyz_sigma=(0, 0, 0), axyz=(0, 0, 0), axyz_sigma=(0, 0, 0)):
-        """motion.py:121-147.  `dem` / `dem_sigma` must be numbers (constant surfaces): gridded
-        rasters are "next"; `dem_sigma=None` crashes in the reference (KeyError 'buf_xsize',
-        SURVEY.md 7.4 item 8), so a number is required here."""
+        """motion.py:121-147.  `dem` / `dem_sigma`: numbers (constant surfaces) or `glimpse_amd.Raster`s;
+        `dem_sigma=None` crashes in the reference (KeyError 'buf_xsize'), so a value is
+        required here."""
         self.xy = xy
         self.time_unit = time_unit
         self.dem = _surface(dem, "dem", "CartesianMotion")

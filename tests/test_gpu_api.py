@@ -786,3 +786,25 @@ def test_search_workspaces_size_themselves(golden, monkeypatch):
         np.testing.assert_array_equal(tracks.particles, explicit.particles)
         assert all(w is None or not any("max_search_dim" in str(x) for x in w) for w in tracks.warnings)
     np.testing.assert_allclose(auto.means[:3], g["means"][:3], rtol=RTOL, atol=1e-8)
+
+
+def test_reference_base_motion_model(golden):
+    """glimpse.Motion, the reference's minimal model (motion.py:13-89), used as it is: it has no device twin, so it runs
+    like any user-defined model -- its own NumPy methods on the host, in the reference's draw order, templates /
+    likelihoods / weights / resampling / moments on the device.  Same seed, same tracks (g25)."""
+    g = golden("g25_base_motion.npz")
+    scene = golden("g15_ragged.npz")
+    cam = camera_from(scene["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f)
+              for i, f in enumerate(scene["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.Motion(xy=tuple(xy), time_unit=DAY, n=300, vxyz_sigma=(0.3, 0.2, 0.0)) for xy in g["xy"]]
+    np.random.seed(2501)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert all(e is None for e in tracks.errors)
+    np.testing.assert_allclose(tracks.means, g["means"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.particles, g["particles"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.weights, g["weights"], rtol=RTOL, atol=1e-290)

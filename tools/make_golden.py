@@ -1175,7 +1175,32 @@ def g24_float_frames():
     np.savez_compressed(os.path.join(OUT, "g24_float_frames.npz"), **out)
 
 
+def g25_base_motion():
+    """The reference's minimal motion model used as it is (motion.py:13-89: particles start AT xy, z = 0, velocities
+    drawn around zero, no likelihood term) on the g15 scene -- the per-track loop with a model that has no device twin."""
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    cam2 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    seq, _ = synth.make_sequence(cam2, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam2, 3, border_px=70.0, seed=3)
+    imgs = [ref_image(seq[i], cam2, t0 + i * day) for i in range(6)]
+    tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)])
+    from glimpse.track.motion import Motion as RefMotion  # (not re-exported at the package top level)
+    models = [RefMotion(xy=tuple(xy), time_unit=day, n=300, vxyz_sigma=(0.3, 0.2, 0.0)) for xy in pts]
+    np.random.seed(2501)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15), return_particles=True)
+    assert all(e is None for e in tracks.errors)
+    print("g25 vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g25_base_motion.npz"), xy=pts, means=tracks.means, sigmas=tracks.sigmas,
+                        particles=tracks.particles, weights=tracks.weights)
+
+
 if __name__ == "__main__":
+    if "--g25" in sys.argv:
+        g25_base_motion()
+        sys.exit(0)
     if "--g24" in sys.argv:
         g24_float_frames()
         sys.exit(0)
