@@ -118,6 +118,87 @@ class Camera:
                      correction=dict(self.correction) if isinstance(self.correction, dict) else self.correction)
         return cam
 
+    # ---- the formats either side of the path: camera models live in JSON files (camera.py:334-509) --------------------
+    _FIELDS = ("xyz", "viewdir", "imgsz", "f", "c", "k", "p", "correction")
+
+    @classmethod
+    def from_json(cls, path, **kwargs):
+        """camera.py:334-357: the constructor arguments stored by `to_json`; entries that are null (all NaN once read as
+        numbers) count as absent; `kwargs` override the file."""
+        import json
+
+        with open(path) as fp:
+            stored = json.load(fp)
+        args = {}
+        for key, value in stored.items():
+            if isinstance(value, dict) or isinstance(value, bool):  # (correction: a dict of constants, or a flag)
+                args[key] = value
+                continue
+            numbers = np.array(value, dtype=float)
+            args[key] = None if np.isnan(numbers).all() else numbers
+        args.update(kwargs)
+        return cls(**args)
+
+    def to_array(self):
+        """camera.py:412-429: xyz | viewdir | imgsz | f | c | k | p as one vector of 20."""
+        return self._vector.copy()
+
+    def to_dict(self, attributes=_FIELDS):
+        """camera.py:431-460: attribute name -> plain Python lists / numbers."""
+        return {key: getattr(getattr(self, key), "tolist", lambda key=key: getattr(self, key))() for key in attributes}
+
+    def to_json(self, path=None, attributes=_FIELDS, **kwargs):
+        """camera.py:462-509: the dictionary of `to_dict` as JSON text, returned or written to `path`."""
+        import json
+
+        text = json.dumps(self.to_dict(attributes=attributes), **kwargs)
+        if path is None:
+            return text
+        with open(path, "w") as fp:
+            fp.write(text)
+        return None
+
+    def reset(self):
+        """camera.py:399-410: back to the state the camera was constructed (or copied) with."""
+        self._vector = self._original_vector.copy()
+
+    def idealize(self):
+        """camera.py:511-530: no distortion, no principal point offset."""
+        self.k, self.p, self.c = np.zeros(6), np.zeros(2), np.zeros(2)
+
+    def resize(self, size=1, force=False):
+        """camera.py:532-589: scale imgsz, f and c to a target image size (nx, ny) or by a factor of the ORIGINAL size.
+        A target size must be reachable by one factor for both axes (round(factor * original) == target) unless
+        `force`."""
+        target = np.atleast_1d(np.asarray(size, dtype=float))
+        original = self._original_vector[6:8]
+        if len(target) > 1 and force:
+            new_size = target
+        else:
+            if len(target) > 1:
+                # the factors s with round(s * original) == target on an axis form an interval; one factor must serve both
+                lo, hi = np.max((target - 0.5) / original), np.min((target + 0.5) / original)
+                exact = target / original
+                if np.all(exact == exact[0]):
+                    scale = exact[0]
+                elif lo < hi:
+                    scale = 0.5 * (lo + hi)
+                else:
+                    raise ValueError("Target image size does not preserve the original aspect ratio")
+            else:
+                scale = target[0]
+            new_size = np.floor(scale * original + 0.5)
+        ratio = new_size / self.imgsz
+        self.imgsz = np.round(new_size)
+        self.f = self.f * ratio
+        self.c = self.c * ratio
+
+    def infront(self, xyz, directions=False):
+        """camera.py:665-683: which points (or ray directions) lie in front of the camera, i.e. project at all."""
+        xyz = np.atleast_2d(np.asarray(xyz, dtype=float))
+        rel = xyz if directions else xyz - self.xyz
+        return (rel @ self.R.T)[:, 2] > 0
+
     # ---- projection (hot path: GPU)
     def xyz_to_uv(self, xyz, directions=False, return_depth=False):
         """camera.py:591-628, evaluated by the projection kernel (`directions=True`: xyz are rays, :1448)."""

@@ -333,3 +333,51 @@ def test_batches_of_motion_models():
     custom = DriftMotion.__new__(DriftMotion)
     custom.n = 100
     assert _batches([cart(), custom, cart(), cart()]) == [0, 1, 2]
+
+
+def test_camera_file_format_and_resizing(tmp_path):
+    """The Camera conveniences either side of the path, pinned by the reference's own doctests (camera.py:399-589,
+    :665-683): reset, to_array, to_dict, to_json / from_json, idealize, resize (aspect-ratio check), infront."""
+    import json
+
+    import glimpse_amd as g
+
+    cam = g.Camera(imgsz=1, f=1)
+    cam.f[0] += 1
+    cam.reset()
+    assert cam.f[0] == 1
+    cam = g.Camera(xyz=(1, 2, 3), viewdir=(4, 5, 6), imgsz=(7, 8), f=(9, 10), c=(11, 12), k=(13, 14, 15, 16, 17, 18), p=(19, 20))
+    np.testing.assert_array_equal(cam.to_array(), np.arange(1.0, 21.0))
+    cam = g.Camera(imgsz=(8, 6), f=(7.9, 6.1))
+    d = cam.to_dict()
+    assert d["imgsz"] == [8, 6] and d["f"] == [7.9, 6.1] and d["correction"] is False and set(d) == set(g.Camera._FIELDS)
+    assert cam.to_dict(("imgsz", "f")) == {"imgsz": [8, 6], "f": [7.9, 6.1]}
+    assert json.loads(cam.to_json())["k"] == [0.0] * 6
+    path = tmp_path / "cam.json"
+    full = g.Camera(imgsz=(80, 60), f=(79.0, 61.0), c=(1.5, -2.0), k=(0.1, 0.02), p=(0.001, 0.002), xyz=(5, 6, 7),
+                    viewdir=(10, -20, 3), correction=True)
+    full.to_json(path, indent=2)
+    back = g.Camera.from_json(path)
+    np.testing.assert_array_equal(back.to_array(), full.to_array())
+    assert back.correction == full.correction
+    assert g.Camera.from_json(path, f=(100, 100)).f.tolist() == [100, 100]  # (keyword arguments override the file)
+    (tmp_path / "sparse.json").write_text(json.dumps({"imgsz": [8, 6], "f": None, "fmm": [20, 20], "sensorsz": [16, 12]}))
+    assert g.Camera.from_json(tmp_path / "sparse.json").f.tolist() == [10.0, 10.0]   # (null entries count as absent)
+    cam = g.Camera(imgsz=1, f=1, c=(0.1, 0.2), k=(0.1, 0.2), p=(0.1, 0.2))
+    cam.idealize()
+    assert all(cam.c == 0) and all(cam.k == 0) and all(cam.p == 0)
+    cam = g.Camera(imgsz=(10, 20), f=(1, 2), c=(0.1, 0.2))
+    cam.resize(2)
+    assert cam.imgsz.tolist() == [20, 40] and cam.f.tolist() == [2.0, 4.0] and cam.c.tolist() == [0.2, 0.4]
+    cam.resize(1)
+    assert cam.imgsz.tolist() == [10, 20] and cam.f.tolist() == [1.0, 2.0]
+    with pytest.raises(ValueError, match="aspect ratio"):
+        cam.resize((11, 20))
+    cam.resize((11, 20), force=True)
+    assert cam.imgsz.tolist() == [11, 20]
+    cam = g.Camera(imgsz=(100, 50), f=(10, 10))
+    cam.resize((33, 17))  # (no single factor gives 33 / 100 = 17 / 50 exactly, but round(0.335 * (100, 50)) does)
+    assert cam.imgsz.tolist() == [33, 17]
+    cam = g.Camera(imgsz=10, f=10)
+    xyz = np.array([(1000, 10, 0), (0, 10, 0), (0, 0, 0), (0, -10, 0)], dtype=float)
+    assert cam.infront(xyz).tolist() == [True, True, False, False]
