@@ -163,6 +163,14 @@ KERNEL_OF_STAGE = {"point_step": "k_point_step", "evolve_project": "k_evolve_pro
                    "weights": "k_weights", "ssd": "k_ssd", "tileprep": "k_tileprep", "spline_fit": "k_spline_fit"}
 
 
+_T0 = time.perf_counter()
+
+
+def _mark(label):
+    """Section times of the run on stderr (the driver keeps stdout for the JSON line)."""
+    print(f"[bench.py {time.perf_counter() - _T0:7.1f} s] {label}", file=sys.stderr, flush=True)
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask and cgroup CPU quota, whichever is smaller."""
     n = os.cpu_count() or 1
@@ -231,42 +239,143 @@ def ssd_flops_per_step(O, tile, boxes, status):
     return total
 
 
-def _render_one(job):
-    wl, o, t = job
-    return wl.frame(o, t)
+_SHARED = {}  # name -> ndarray over anonymous shared memory, allocated before the helpers fork
+_WLS = {}  # name -> Workload (with its texture) the forked helpers render from: inherited, never pickled
 
 
-def render_frames(wl, workers):
-    """All frames of the workload, [O] arrays (T, H, W) uint8.  The ground map of every camera is computed once
-    here; the frames are then rendered by forked workers (this runs before the process touches the GPU)."""
-    cache = os.environ.get("GLH_FRAME_CACHE")  # (A/B tooling: repeated runs of one workload on one box)
-    key = None
-    if cache:
-        key = os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}_{wl.channels}")
-        if all(os.path.exists(f"{key}_{o}.npy") for o in range(wl.O)):
-            return [np.load(f"{key}_{o}.npy", mmap_mode="r") for o in range(wl.O)]
-    for o in range(wl.O):
-        wl.scene.ground_map(wl.cams[o])
-    jobs = [(wl, o, t) for o in range(wl.O) for t in range(wl.T)]
-    # forked helpers are only safe while this process has not initialised the GPU runtime; a profiler's preloaded
-    # library has done that before main() (rocprofv3 --pmc): render serially there
+def _shared_array(name, shape, dtype=np.uint8):
+    import mmap
+
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    buf = mmap.mmap(-1, max(n, 1))  # MAP_SHARED | MAP_ANONYMOUS: forked helpers write, this process reads
+    _SHARED[name] = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return _SHARED[name]
+
+
+def _ground_job(job):
+    from glimpse_amd import synth
+
+    if job[0] == "scene":
+        return _WLS[job[1]].scene
+    _, cam, r0, r1 = job
+    return synth.ground_rows(cam, r0, r1)
+
+
+def _render_job(job):
+    kind, name, wl, o, t = job
+    if kind == "rgb":  # the RGB frame of an already rendered gray one
+        from glimpse_amd import synth
+
+        _SHARED[name][t] = synth.gray_to_rgb(_SHARED[wl][t])
+    else:
+        _SHARED[name][t] = _WLS[wl].frame(o, t)
+    return None
+
+
+def _may_fork():
+    """Forked helpers are only safe while this process has not initialised the GPU runtime; a profiler's preloaded
+    library has done that before main() (rocprofv3 --pmc): render serially there."""
     from glimpse_amd import _lib as _l
 
     profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if workers > 1 and len(jobs) > 4 and not profiled and _l._lib is None:
+    return not profiled and _l._lib is None
+
+
+def render_all(wls, workers, rgb_of=None):
+    """Frames of several workloads at once: {name: [O] arrays (T, H, W[, 3]) uint8}.  `wls` is {name: Workload};
+    `rgb_of` = (name, source) adds the RGB frames of the one-observer gray workload `source` under `name` (the channel
+    remap of synth.gray_to_rgb on its rendered frames -- what Workload.channels = 3 renders).
+
+    The ground map of every distinct camera is computed once, in row bands, by forked helpers; a second set of
+    helpers (forked after the maps exist, so they inherit them) renders the frames into shared memory.  All of this
+    runs before the process touches the GPU."""
+    from glimpse_amd import synth
+
+    cache = os.environ.get("GLH_FRAME_CACHE")  # (A/B tooling: repeated runs of one workload on one box)
+
+    def cache_key(wl, channels):
+        return os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}_{channels}")
+
+    out, todo = {}, {}
+    for name, wl in wls.items():
+        key = cache_key(wl, wl.channels) if cache else None
+        if key and all(os.path.exists(f"{key}_{o}.npy") for o in range(wl.O)):
+            out[name] = [np.load(f"{key}_{o}.npy", mmap_mode="r") for o in range(wl.O)]
+        else:
+            todo[name] = wl
+    want_rgb = rgb_of is not None and rgb_of[1] in wls
+    if want_rgb and cache and os.path.exists(cache_key(wls[rgb_of[1]], 3) + "_0.npy"):
+        out[rgb_of[0]] = [np.load(cache_key(wls[rgb_of[1]], 3) + "_0.npy", mmap_mode="r")]
+        want_rgb = False
+    n_jobs = sum(wl.O * wl.T for wl in todo.values())
+    fork = workers > 1 and n_jobs > 4 and _may_fork()
+    if fork:
         import multiprocessing as mp
 
-        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
-            flat = pool.map(_render_one, jobs, chunksize=1)
-    else:
-        flat = [_render_one(j) for j in jobs]
-    frames = [np.stack(flat[o * wl.T:(o + 1) * wl.T]) for o in range(wl.O)]
-    if key:
-        os.makedirs(cache, exist_ok=True)
+        cams = {}
+        for wl in todo.values():
+            for cam in wl.cams:
+                if cam.tobytes() not in synth._GROUND_MAPS:
+                    cams[cam.tobytes()] = cam
+        # the textures (seconds each) first, then the ground maps in bands of rows
+        _WLS.update(todo)
+        first = [(name, ("scene", name)) for name, wl in todo.items() if wl._scene is None]
+        for key, cam in cams.items():
+            ny = int(cam[7])
+            first += [(key, ("rows", cam, r, min(ny, r + 64))) for r in range(0, ny, 64)]
+        if first:
+            with mp.get_context("fork").Pool(min(workers, len(first))) as pool:
+                parts = pool.map(_ground_job, [j for _, j in first], chunksize=1)
+            for (key, job), part in zip(first, parts):
+                if job[0] == "scene":
+                    todo[key]._scene = part
+            for key in cams:
+                synth._GROUND_MAPS[key] = np.concatenate([p for (k, j), p in zip(first, parts)
+                                                          if k == key and j[0] != "scene"])
+    for wl in todo.values():
+        wl.scene  # (the texture, before the helpers fork)
+    _WLS.update(todo)
+    jobs = []
+    for name, wl in todo.items():
+        shape = (wl.T, wl.imgsz[1], wl.imgsz[0]) + ((3,) if wl.channels == 3 else ())
+        out[name] = []
         for o in range(wl.O):
-            np.save(f"{key}_{o}.npy", frames[o])
-    return frames
+            out[name].append(_shared_array(f"{name}/{o}", shape) if fork else np.empty(shape, np.uint8))
+            _SHARED[f"{name}/{o}"] = out[name][o]
+            jobs += [("frame", f"{name}/{o}", name, o, t) for t in range(wl.T)]
+    rgb_jobs = []
+    if want_rgb:
+        src = wls[rgb_of[1]]
+        assert src.O == 1 and src.channels == 1
+        shape = (src.T, src.imgsz[1], src.imgsz[0], 3)
+        out[rgb_of[0]] = [_shared_array(f"{rgb_of[0]}/0", shape) if fork else np.empty(shape, np.uint8)]
+        _SHARED[f"{rgb_of[0]}/0"] = out[rgb_of[0]][0]
+        if f"{rgb_of[1]}/0" not in _SHARED:
+            _SHARED[f"{rgb_of[1]}/0"] = out[rgb_of[1]][0]
+        rgb_jobs = [("rgb", f"{rgb_of[0]}/0", f"{rgb_of[1]}/0", 0, t) for t in range(src.T)]
+    if fork:
+        with mp.get_context("fork").Pool(min(workers, max(1, len(jobs) + len(rgb_jobs)))) as pool:
+            pool.map(_render_job, jobs, chunksize=1)
+            pool.map(_render_job, rgb_jobs, chunksize=1)
+    else:
+        for j in jobs + rgb_jobs:
+            _render_job(j)
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        for name, wl in todo.items():
+            for o in range(wl.O):
+                np.save(f"{cache_key(wl, wl.channels)}_{o}.npy", out[name][o])
+        if want_rgb:
+            np.save(cache_key(wls[rgb_of[1]], 3) + "_0.npy", out[rgb_of[0]][0])
+    _SHARED.clear()
+    _WLS.clear()
+    return out
+
+
+def render_frames(wl, workers):
+    """All frames of one workload, [O] arrays (T, H, W[, 3]) uint8."""
+    return render_all({"w": wl}, workers)["w"]
 
 
 def cpu_model():
@@ -558,13 +667,14 @@ def worker(args):
                  and args.particles is None and args.motion == "cartesian" and B == 0 and args.channels == 1)
     frames_c5 = frames_rgb = None
     if world == 1:
-        frames = render_frames(wl, cores)
         if secondary:
-            frames_c5 = render_frames(workloads.Workload("C5", n_frames=T, n_points=workloads.CONFIGS["C5"]["points"],
-                                                         shard=0, seed=0), cores)
-            rgb = workloads.Workload("C3", n_frames=T, shard=0, seed=0)
-            rgb.channels = 3
-            frames_rgb = render_frames(rgb, cores)
+            # every secondary leg's frames with the headline's, by one set of helpers: C4 and C2 see the C3 frames, the
+            # RGB leg their channel remap; C5 has its own scene (it covers the oblique camera's footprint)
+            c5 = workloads.Workload("C5", n_frames=T, n_points=workloads.CONFIGS["C5"]["points"], shard=0, seed=0)
+            rendered = render_all({"C3": wl, "C5": c5}, cores, rgb_of=("C3_rgb", "C3"))
+            frames, frames_c5, frames_rgb = rendered["C3"], rendered["C5"], rendered["C3_rgb"]
+        else:
+            frames = render_frames(wl, cores)
     else:
         if rank == 0:
             frames = render_frames(wl, cores)
@@ -575,9 +685,11 @@ def worker(args):
 
     # one GPU per rank (LOCAL_RANK); GLH_BENCH_DEVICE is a test hook (several ranks on one GPU)
     device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank % max(1, _lib.device_count())))
+    _mark("frames rendered")
     ctx = _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=args.max_search_dim,
                        max_frames=T)
     workloads.setup_context(ctx, wl, frames)
+    _mark("context ready, frames uploaded")
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
     if args.motion != "cartesian":
@@ -649,6 +761,7 @@ def worker(args):
     dom = max(stage_ms, key=lambda k: stage_ms[k][0])
     launch_ms = ctx.profile_launches(dom)
     ctx.profile_enable(False)
+    _mark("headline timed")
 
     # health of the run: every point must still be tracked by every observer
     status = ctx.observer_status()
@@ -751,17 +864,20 @@ def worker(args):
             ctx.close()
             ctx_closed = True
             out["secondary"] = secondary_legs(args, device, T, frames, frames_c5, frames_rgb, seed)
+            _mark("secondary legs")
         if not args.no_api:
             if not ctx_closed:
                 ctx.close()
             ctx_closed = True
             try:
                 out.update(api_leg(wl, frames, T, seed, device, args.max_search_dim))
+                _mark("API leg")
             except Exception as e:  # noqa: BLE001
                 out["api_error"] = repr(e)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, frames, T, args.cpu_seconds)
+                _mark("CPU baseline, one core")
                 workers = args.cpu_workers if args.cpu_workers > 0 else usable_cores()
                 if workers > 1 and wl.P >= 2 * workers:
                     out["cpu_baseline_parallel"] = cpu_baseline_parallel(
@@ -777,6 +893,7 @@ def worker(args):
                        or leg.get("observer_ok_fraction", 1.0) < 0.99 for leg in out.get("secondary", {}).values()):
             rc = 3
             out["health"]["verdict"] = "UNHEALTHY"
+        _mark("done")
         print(json.dumps(out), flush=True)
     group.close()
     if not ctx_closed:

@@ -96,6 +96,28 @@ def make_texture(size, seed=0, blur=2.0):
     return t
 
 
+_GROUND_MAPS = {}  # packed camera -> world xy on z = 0 of every pixel centre (a property of the camera alone)
+
+
+def ground_rows(cam, r0, r1):
+    """World xy on z = 0 of the pixel centres of image rows [r0, r1) (row-major)."""
+    nx = int(cam[6])
+    cu, cv = np.meshgrid(np.arange(nx) + 0.5, np.arange(r0, r1) + 0.5)
+    return uv_to_ground(cam, np.column_stack((cu.ravel(), cv.ravel()))).astype(np.float64)
+
+
+_RGB_LUT = None
+
+
+def gray_to_rgb(img):
+    """The 8-bit RGB frame of a gray one: a deterministic, channel-dependent remap, so that the channels differ."""
+    global _RGB_LUT
+    if _RGB_LUT is None:
+        g = np.arange(256, dtype=np.int32)
+        _RGB_LUT = (np.clip(g + ((g * 7) % 5) - 2, 0, 255).astype(np.uint8), np.clip(255 - g // 2, 0, 255).astype(np.uint8))
+    return np.stack((img, _RGB_LUT[0][img], _RGB_LUT[1][img]), axis=-1)
+
+
 class Scene:
     """Planar textured ground moving at a constant world velocity."""
 
@@ -104,16 +126,14 @@ class Scene:
         self.texel = float(texel)  # world units per texel
         self.origin = np.asarray(origin, dtype=float)  # world xy of texel (0, 0) centre
         self.velocity = np.asarray(velocity, dtype=float)
-        self._maps = {}
 
     def ground_map(self, cam):
         key = cam.tobytes()
-        if key not in self._maps:
-            nx, ny = int(cam[6]), int(cam[7])
-            cu, cv = np.meshgrid(np.arange(nx) + 0.5, np.arange(ny) + 0.5)
-            uv = np.column_stack((cu.ravel(), cv.ravel()))
-            self._maps[key] = uv_to_ground(cam, uv).astype(np.float64)
-        return self._maps[key]
+        if key not in _GROUND_MAPS:
+            # in bands of rows: the undistortion iterates over its whole operand, which should stay in cache
+            ny = int(cam[7])
+            _GROUND_MAPS[key] = np.concatenate([ground_rows(cam, r, min(ny, r + 64)) for r in range(0, ny, 64)])
+        return _GROUND_MAPS[key]
 
     def render(self, cam, t, channels=1, bits=8):
         """uint8 (bits=8) or uint16 (bits=16) frame (ny, nx) or (ny, nx, 3) at time t (in time units)."""
@@ -133,11 +153,7 @@ class Scene:
             return img
         img = np.clip(np.rint(vals), 0, 255).astype(np.uint8).reshape(ny, nx)
         if channels == 3:
-            # deterministic, channel-dependent remap so RGB differs from gray
-            g = img.astype(np.int32)
-            img = np.stack(
-                (img, np.clip(g + ((g * 7) % 5) - 2, 0, 255).astype(np.uint8),
-                 np.clip(255 - g // 2, 0, 255).astype(np.uint8)), axis=2)
+            img = gray_to_rgb(img)
         return img
 
 

@@ -69,9 +69,7 @@ class Workload:
             self.cams.append(synth.pack_camera(imgsz=self.imgsz, f=1200.0, k=(0.03, 0, 0), xyz=(40, -30, 90),
                                                viewdir=(-53.13, -60.9, 0)))
             self.sigmas.append(0.3)
-        # the scene must cover every camera's footprint
-        foot = self.cams[-1] if self.O == 2 else cam0
-        self.scene = synth.default_scene(foot, seed=seed, velocity=VELOCITY, n_frames=self.T, margin=30.0)
+        self._scene = None
         border = 0.5 * max(self.tile) + 110.0 if min(self.imgsz) >= 1024 else 0.5 * max(self.tile) + 60.0
         # the scene drifts 1.5 px per frame: long sequences keep their points further from the image border, so that
         # the last frame's search boxes are still inside the image
@@ -112,6 +110,15 @@ class Workload:
         return sub
 
     channels = 1  # 3: RGB frames (what a time-lapse JPEG decodes to)
+
+    @property
+    def scene(self):
+        """The textured ground, built when the first frame is asked for (callers that bring their frames never pay
+        for the texture).  It must cover every camera's footprint."""
+        if self._scene is None:
+            self._scene = synth.default_scene(self.cams[-1], seed=self.seed, velocity=VELOCITY, n_frames=self.T,
+                                              margin=30.0)
+        return self._scene
 
     def frame(self, obs, t):
         return self.scene.render(self.cams[obs], float(t), channels=self.channels)
