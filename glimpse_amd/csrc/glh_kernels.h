@@ -118,13 +118,18 @@ __device__ __forceinline__ void philox_normals3(uint64_t seed, uint32_t c0, uint
 // The three evolve normals of particle i of point pt at frame `step`: host-fed (parity with
 // np.random, motion.py:176) or counter-based, hence recomputable wherever the particle is
 // needed again (the fused step re-evolves the resampled sources instead of storing them).
+// `third` (uniform): false where the caller knows the third normal is multiplied by a zero sigma -- it is then not
+// computed (the second Box-Muller pair of the block) and reads 0.
 __device__ __forceinline__ void evolve_noise(int rng_mode, const double* normals, uint64_t seed, uint64_t step,
-                                             int pt, int pt_base, int i, int N, double* n) {
+                                             int pt, int pt_base, int i, int N, double* n, bool third = true) {
   if (rng_mode == GLH_RNG_HOST) {
     const double* src = normals + ((size_t)pt * N + i) * 3;
     n[0] = src[0]; n[1] = src[1]; n[2] = src[2];
-  } else {
+  } else if (third) {
     philox_normals3(seed, (uint32_t)i, (uint32_t)(pt + pt_base), (uint32_t)step, 0x45564f4cu, n);
+  } else {
+    philox_normals2(seed, (uint32_t)i, (uint32_t)(pt + pt_base), (uint32_t)step, 0x45564f4cu, n[0], n[1]);
+    n[2] = 0.0;
   }
 }
 

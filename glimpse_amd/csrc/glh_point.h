@@ -595,9 +595,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const int rec_stride = COMMON || uin ? 1 : 3, chunk_stride = COMMON || uin ? N : 1;
   const double2* Pin2 = reinterpret_cast<const double2*>(Pin);
   // the evolve step of particle k re-applied to its pre-evolve record x (phase E)
+  // CartesianMotion with axyz_sigma[2] == 0 (uniform): the third normal only ever meets that zero
+  const bool third = SURF || m[15] != 0.0;
   auto evolve_loaded = [&](int k, double* x) {
     double n[3];
-    evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n);
+    evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
       evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &oob);
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       if (i < N) {
         double n[3];
-        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n);
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
         if constexpr (SURF)
           evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &raster_oob);
         else
