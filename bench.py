@@ -89,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
+    ap.add_argument("--bits", type=int, default=8, choices=[8, 16],
+                    help="frame samples: uint8 (BASELINE's configurations) or uint16 (the same scene on a 16-bit sensor)")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
                     help="frame channels: 1 (gray, BASELINE's configurations) or 3 (RGB uint8: what time-lapse JPEGs decode to)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -206,7 +208,7 @@ def pmc_traffic(wl, kernel):
 def sq_counters(wl):
     """VALU wave-instructions per 64 particle-frames of the fused kernel from the committed SQ counter pass of this
     workload shape (C3 only: the pass is expensive), or None."""
-    if (wl.name, wl.P, wl.N, wl.channels) != ("C3", 4096, 5000, 1):
+    if (wl.name, wl.P, wl.N, wl.channels, wl.bits) != ("C3", 4096, 5000, 1, 8):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r03_C3_sq_counters.json")) as f:
@@ -223,7 +225,7 @@ def algorithmic_bytes_per_step(P, N, O, tile, boxes, status, channels=1):
         ok = status[o] == 0
         ws = (boxes[o, :, 2] - boxes[o, :, 0])[ok].astype(np.float64)
         hs = (boxes[o, :, 3] - boxes[o, :, 1])[ok].astype(np.float64)
-        total += channels * float((ws * hs).sum()) + ok.sum() * (20.0 * tw * th + 96.0)
+        total += channels * float((ws * hs).sum()) + ok.sum() * (20.0 * tw * th + 96.0)  # (channels x bytes per sample)
     return total
 
 
@@ -295,7 +297,7 @@ def render_all(wls, workers, rgb_of=None):
     cache = os.environ.get("GLH_FRAME_CACHE")  # (A/B tooling: repeated runs of one workload on one box)
 
     def cache_key(wl, channels):
-        return os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}_{channels}")
+        return os.path.join(cache, f"{wl.name}_{wl.T}_{wl.imgsz[0]}x{wl.imgsz[1]}_{wl.O}_{channels}_{wl.bits}")
 
     out, todo = {}, {}
     for name, wl in wls.items():
@@ -339,9 +341,10 @@ def render_all(wls, workers, rgb_of=None):
     jobs = []
     for name, wl in todo.items():
         shape = (wl.T, wl.imgsz[1], wl.imgsz[0]) + ((3,) if wl.channels == 3 else ())
+        dtype = np.uint16 if wl.bits == 16 else np.uint8
         out[name] = []
         for o in range(wl.O):
-            out[name].append(_shared_array(f"{name}/{o}", shape) if fork else np.empty(shape, np.uint8))
+            out[name].append(_shared_array(f"{name}/{o}", shape, dtype) if fork else np.empty(shape, dtype))
             _SHARED[f"{name}/{o}"] = out[name][o]
             jobs += [("frame", f"{name}/{o}", name, o, t) for t in range(wl.T)]
     rgb_jobs = []
@@ -567,11 +570,11 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     ctx.profile_enable(False)
     status = ctx.observer_status()
     boxes = ctx.search_boxes()
-    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels)
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels * wl.bits // 8)
     dom_ms, dom_n = stage_ms[dom]
     per_launch = dom_ms / max(dom_n, 1)
     kern = KERNEL_OF_STAGE.get(dom, dom)
-    traffic = pmc_traffic(wl, kern) if math == "fast" and wl.channels == 1 else None
+    traffic = pmc_traffic(wl, kern) if math == "fast" and wl.channels == 1 and wl.bits == 8 else None
     moments = ctx.get_moments(0, n_frames)
     leg = {
         "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
@@ -593,27 +596,31 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     return leg
 
 
-def secondary_legs(args, device, T, frames_c3, frames_c5, frames_rgb, seed):
+def secondary_legs(args, device, T, rendered, seed):
     """What the headline does not show, each over its whole sequence from the prior on the frames already rendered:
     exact arithmetic at C3 (the arithmetic the oracle tests pin bit for bit), one GPU's shard of C4, C5 (two observers
-    + DEM term, all 2048 points on one GPU), C2, and C3 on RGB frames (what time-lapse JPEGs decode to: 766 key bins
-    instead of 256)."""
+    + DEM term, all 2048 points on one GPU), C2, C3 on RGB frames (what time-lapse JPEGs decode to: 766 key bins
+    instead of 256) and C3 on uint16 frames (the keys ranked in LDS instead of counted in 256 bins)."""
     from glimpse_amd import _lib, workloads
 
     legs = {}
-    plan = [("C3_exact", "C3", None, "exact", T, frames_c3, 1),
-            ("C4_shard", "C4", None, "fast", T, frames_c3, 1),
-            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, frames_c5, 1),
-            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), frames_c3, 1),
-            ("C3_rgb", "C3", None, "fast", T, frames_rgb, 3)]
-    for key, name, points, math, n_frames, frames, channels in plan:
+    plan = [("C3_exact", "C3", None, "exact", T, "C3", 1, 8),
+            ("C4_shard", "C4", None, "fast", T, "C3", 1, 8),
+            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, "C5", 1, 8),
+            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), "C3", 1, 8),
+            ("C3_rgb", "C3", None, "fast", T, "C3_rgb", 3, 8),
+            ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16)]
+    for key, name, points, math, n_frames, frames_of, channels, bits in plan:
+        frames = rendered.get(frames_of)
         if frames is None:
             continue
         try:
             wl = workloads.Workload(name, n_frames=T, n_points=points, shard=0, seed=0)
-            wl.channels = channels
-            with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile),
-                              max_search_dim=args.max_search_dim, max_frames=T) as ctx:
+            wl.channels, wl.bits = channels, bits
+            # (uint16 frames take the fused step while a tile's pixel count fits a 16-bit key: workspaces up to 255 px)
+            dim = min(args.max_search_dim, 255) if bits == 16 else args.max_search_dim
+            with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=dim,
+                              max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
                 legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
         except Exception as e:  # noqa: BLE001
@@ -659,20 +666,24 @@ def worker(args):
         point_offset = rank * wl.P
         sizes = [wl.P] * world
 
-    wl.channels = args.channels
+    wl.channels, wl.bits = args.channels, args.bits
     # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files -- by forked helpers,
     # hence BEFORE anything loads the HIP library (the device count below does)
     cores = usable_cores()
     secondary = (world == 1 and not args.no_secondary and args.workload == "C3" and args.points is None
-                 and args.particles is None and args.motion == "cartesian" and B == 0 and args.channels == 1)
-    frames_c5 = frames_rgb = None
+                 and args.particles is None and args.motion == "cartesian" and B == 0 and args.channels == 1
+                 and args.bits == 8)
+    rendered = {}
     if world == 1:
         if secondary:
             # every secondary leg's frames with the headline's, by one set of helpers: C4 and C2 see the C3 frames, the
-            # RGB leg their channel remap; C5 has its own scene (it covers the oblique camera's footprint)
+            # RGB leg their channel remap; C5 has its own scene (it covers the oblique camera's footprint); the 16-bit
+            # leg sees the C3 scene on a 16-bit sensor
             c5 = workloads.Workload("C5", n_frames=T, n_points=workloads.CONFIGS["C5"]["points"], shard=0, seed=0)
-            rendered = render_all({"C3": wl, "C5": c5}, cores, rgb_of=("C3_rgb", "C3"))
-            frames, frames_c5, frames_rgb = rendered["C3"], rendered["C5"], rendered["C3_rgb"]
+            u16 = workloads.Workload("C3", n_frames=T, shard=0, seed=0)
+            u16.bits = 16
+            rendered = render_all({"C3": wl, "C5": c5, "C3_u16": u16}, cores, rgb_of=("C3_rgb", "C3"))
+            frames = rendered["C3"]
         else:
             frames = render_frames(wl, cores)
     else:
@@ -771,7 +782,7 @@ def worker(args):
     # algorithmic bytes / SSD flops of one step, from the search boxes of the last timed step (the smallest tiles
     # of the sequence: the tile term, ~4 % of the bytes, is if anything understated for the first frames)
     boxes = ctx.search_boxes()
-    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels)
+    abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels * wl.bits // 8)
     flops = ssd_flops_per_step(wl.O, wl.tile, boxes, status)
     moments_local = ctx.get_moments(0, T)
 
@@ -828,7 +839,7 @@ def worker(args):
         ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         kern = KERNEL_OF_STAGE.get(dom, dom)
         roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern) if wl.channels == 1 else None,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern) if wl.channels == 1 and wl.bits == 8 else None,
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": abytes / launches_per_frame,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
@@ -863,7 +874,7 @@ def worker(args):
         if secondary:
             ctx.close()
             ctx_closed = True
-            out["secondary"] = secondary_legs(args, device, T, frames, frames_c5, frames_rgb, seed)
+            out["secondary"] = secondary_legs(args, device, T, rendered, seed)
             _mark("secondary legs")
         if not args.no_api:
             if not ctx_closed:

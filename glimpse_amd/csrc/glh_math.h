@@ -437,6 +437,40 @@ GLH_HD int template_box(double u, double v, int tw, int th, double imgw, double 
 
 // np.interp for one x (numpy/_core/src/multiarray/compiled_base.c: arr_interp), with the
 // default left = fp[0], right = fp[n-1].  xp is non-decreasing, n >= 1.
+// In two halves: the interval search (its result -- or the two out-of-range cases -- as one number) and the
+// evaluation, so that a caller with many x of few distinct values searches once per value.
+constexpr int NP_INTERP_LEFT = -1;  // x < xp[0]
+GLH_HD int np_interp_find(double x, const double* xp, int n, int lo = 0, int hi = -1) {
+  if (n == 1) return 0;
+  if (x > xp[n - 1]) return n - 1;  // (evaluates to fp[n - 1])
+  if (x < xp[0]) return NP_INTERP_LEFT;
+  if (hi < 0) hi = n - 1;  // invariant: xp[lo] <= x, and (hi == n-1 or x < xp[hi])
+  if (x >= xp[n - 1]) {
+    lo = n - 1;
+  } else {
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (x >= xp[mid])
+        lo = mid;
+      else
+        hi = mid;
+    }
+  }
+  return lo;
+}
+GLH_HD double np_interp_at(int j, double x, const double* xp, const double* fp, int n) {
+  if (j == NP_INTERP_LEFT) return fp[0];
+  if (j == n - 1) return fp[j];
+  if (xp[j] == x) return fp[j];
+  double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  double res = slope * (x - xp[j]) + fp[j];
+  if (isnan(res)) {
+    res = slope * (x - xp[j + 1]) + fp[j + 1];
+    if (isnan(res) && fp[j] == fp[j + 1]) res = fp[j];
+  }
+  return res;
+}
+// (np_interp itself keeps its one-piece form: the 8-bit LUT code of the fused kernel is compiled from it)
 GLH_HD double np_interp(double x, const double* xp, const double* fp, int n) {
   if (n == 1) return fp[0];
   if (x > xp[n - 1]) return fp[n - 1];

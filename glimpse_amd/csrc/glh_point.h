@@ -164,6 +164,83 @@ struct TileWs {
   int ld;
 };
 
+// scipy.ndimage 'reflect' (d c b a | a b c d | d c b a) border of the key tile, columns first: 2 left, 3 right of every
+// crop row (tiles are >= 8 pixels on a side, so one reflection is exact) ...
+template <int TB>
+__device__ __forceinline__ void pt_border_cols(uint16_t* keys, int wp, int w, int h) {
+  for (int idx = threadIdx.x; idx < 5 * h; idx += TB) {
+    const int r = idx / 5, k = idx - 5 * r;
+    const int c = k < 2 ? -1 - k : w + (k - 2);         // -1, -2, w, w + 1, w + 2
+    const int src = k < 2 ? k : w - 1 - (k - 2);        //  0,  1, w - 1, w - 2, w - 3
+    keys[r * wp + c] = keys[r * wp + src];
+  }
+}
+// ... then (after a barrier) whole padded rows: -1 <- 0, -2 <- 1, h <- h - 1, h + 1 <- h - 2
+template <int TB>
+__device__ __forceinline__ void pt_border_rows(uint16_t* keys, int wp, int h) {
+  for (int idx = threadIdx.x; idx < 4 * wp; idx += TB) {
+    const int k = idx / wp, c = idx - k * wp - 2;
+    const int r = k < 2 ? -1 - k : h + (k - 2);
+    const int src = k < 2 ? k : h - 1 - (k - 2);
+    keys[r * wp + c] = keys[src * wp + c];
+  }
+}
+
+// tile - median_filter(tile) (tracker.py:530-531) of the CDF-matched tile into ws.S, from the bordered key tile: the match
+// is monotone in the key, so the median is taken on the keys and `value_of` (key -> matched value, float64) is applied
+// to the pixel and to its median.  Ends with a barrier.
+template <int TB, bool GEN, typename MAP>
+__device__ __forceinline__ void pt_highpass_write(const TileWs& ws, const uint16_t* keys, int wp, int w, int h, int hp_rx,
+                                                  int hp_ry, int key_max, MAP value_of) {
+  const int tid = threadIdx.x, n = w * h;
+  const int ld = ws.ld;
+  // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
+  for (int idx = tid; idx < h * (ld - w); idx += TB) {
+    const int r = idx / (ld - w), c = w + idx - r * (ld - w);
+    ws.S[r * ld + c] = 0.0f;
+  }
+  // 5x5 median of the raw keys around every pixel, TWO horizontally adjacent pixels per thread on
+  // packed 16-bit lanes (same selection network, v_pk_min/max_u16).  The window of the pair (r, c0), (r, c0 + 1)
+  // is columns c0 - 2 .. c0 + 3 of rows r - 2 .. r + 2 of the bordered tile: three aligned 32-bit words per row
+  // (c0 and the row stride are even), i.e. the pairs (k0 k1) (k2 k3) (k4 k5) directly and (k1 k2) (k3 k4) by a
+  // funnel shift.
+  if (GEN && (hp_rx != 2 || hp_ry != 2)) {
+    // another window: the median by bisection over the key range, one pixel per thread, on the same key tile
+    // (`reflect` by index arithmetic: the tile's own border is the 5 x 5 window's) -- what k_tileprep does
+    const UDiv by_w2 = udiv_make(w);
+    for (int idx = tid; idx < n; idx += TB) {
+      const int r = udiv(by_w2, idx), c = idx - r * w;
+      const int key = keys[r * wp + c];
+      const int med = median_window(keys, wp, 0, w, h, r, c, hp_rx, hp_ry, key_max);
+      ws.S[r * ld + c] = (float)(value_of(key) - value_of(med));
+    }
+    __syncthreads();
+    return;
+  }
+  const int npc = (w + 1) >> 1;
+  const UDiv by_npc = udiv_make(npc);
+  for (int idx = tid; idx < h * npc; idx += TB) {
+    const int r = udiv(by_npc, idx), c0 = 2 * (idx - r * npc);
+    const uint32_t* win = reinterpret_cast<const uint32_t*>(keys + (r - 2) * wp + (c0 - 2));
+    glh_us2 v[25];
+#pragma unroll
+    for (int dr = 0; dr < 5; ++dr) {
+      const uint32_t d0 = win[dr * (wp / 2)], d1 = win[dr * (wp / 2) + 1], d2 = win[dr * (wp / 2) + 2];
+      const uint32_t m01 = (d0 >> 16) | (d1 << 16), m12 = (d1 >> 16) | (d2 << 16);
+      v[dr * 5 + 0] = __builtin_bit_cast(glh_us2, d0);   // pixel c0 | pixel c0 + 1 in the low | high half
+      v[dr * 5 + 1] = __builtin_bit_cast(glh_us2, m01);
+      v[dr * 5 + 2] = __builtin_bit_cast(glh_us2, d1);
+      v[dr * 5 + 3] = __builtin_bit_cast(glh_us2, m12);
+      v[dr * 5 + 4] = __builtin_bit_cast(glh_us2, d2);
+    }
+    const glh_us2 key = v[12];
+    const glh_us2 med = median25_pk(v);
+    ws.S[r * ld + c0] = (float)(value_of(key.x) - value_of(med.x));
+    if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(value_of(key.y) - value_of(med.y));
+  }
+  __syncthreads();
+}
+
 // extract_tile(histogram=template CDF) (tracker.py:605-607) into ws.S; see search_tile_from_box.
 // GEN (the general instantiations): any odd median window up to 7 x 7 (`hp_rx`, `hp_ry` half sizes; Tracker(highpass=
 // {"size": ...}), tracker.py:59, :530) -- the 5 x 5 default keeps its packed network everywhere.
@@ -203,14 +280,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   }
   __syncthreads();
   TP_STAMP(13);
-  // scipy.ndimage 'reflect' (d c b a | a b c d | d c b a), columns first: 2 left, 3 right of every crop row
-  // (tiles are >= 8 pixels on a side, so one reflection is exact) ...
-  for (int idx = tid; idx < 5 * h; idx += TB) {
-    const int r = idx / 5, k = idx - 5 * r;
-    const int c = k < 2 ? -1 - k : w + (k - 2);         // -1, -2, w, w + 1, w + 2
-    const int src = k < 2 ? k : w - 1 - (k - 2);        //  0,  1, w - 1, w - 2, w - 3
-    keys[r * wp + c] = keys[r * wp + src];
-  }
+  pt_border_cols<TB>(keys, wp, w, h);
   {
     // inclusive scan of the nb <= 2 * TB bins: two bins per thread + block scan
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
@@ -233,13 +303,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
     }
   }
   __syncthreads();
-  // ... then whole padded rows: -1 <- 0, -2 <- 1, h <- h - 1, h + 1 <- h - 2 (the column borders are in place)
-  for (int idx = tid; idx < 4 * wp; idx += TB) {
-    const int k = idx / wp, c = idx - k * wp - 2;
-    const int r = k < 2 ? -1 - k : h + (k - 2);
-    const int src = k < 2 ? k : h - 1 - (k - 2);
-    keys[r * wp + c] = keys[src * wp + c];
-  }
+  pt_border_rows<TB>(keys, wp, h);  // (the column borders are in place)
   if (ws.cum != ws.hist) {
     for (int b = tid; b < nb; b += TB) {
       if (ws.hist[b]) {
@@ -250,52 +314,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   }
   __syncthreads();
   TP_STAMP(14);
-  const int ld = ws.ld;
-  // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
-  for (int idx = tid; idx < h * (ld - w); idx += TB) {
-    const int r = idx / (ld - w), c = w + idx - r * (ld - w);
-    ws.S[r * ld + c] = 0.0f;
-  }
-  // 5x5 median of the raw keys around every pixel, TWO horizontally adjacent pixels per thread on
-  // packed 16-bit lanes (same selection network, v_pk_min/max_u16).  The window of the pair (r, c0), (r, c0 + 1)
-  // is columns c0 - 2 .. c0 + 3 of rows r - 2 .. r + 2 of the bordered tile: three aligned 32-bit words per row
-  // (c0 and the row stride are even), i.e. the pairs (k0 k1) (k2 k3) (k4 k5) directly and (k1 k2) (k3 k4) by a
-  // funnel shift.
-  if (GEN && (hp_rx != 2 || hp_ry != 2)) {
-    // another window: the median by bisection over the key range, one pixel per thread, on the same key tile
-    // (`reflect` by index arithmetic: the tile's own border is the 5 x 5 window's) -- what k_tileprep does
-    const UDiv by_w2 = udiv_make(w);
-    for (int idx = tid; idx < n; idx += TB) {
-      const int r = udiv(by_w2, idx), c = idx - r * w;
-      const int key = keys[r * wp + c];
-      const int med = median_window(keys, wp, 0, w, h, r, c, hp_rx, hp_ry, nb - 1);
-      ws.S[r * ld + c] = (float)(ws.lut[key] - ws.lut[med]);
-    }
-    __syncthreads();
-    return;
-  }
-  const int npc = (w + 1) >> 1;
-  const UDiv by_npc = udiv_make(npc);
-  for (int idx = tid; idx < h * npc; idx += TB) {
-    const int r = udiv(by_npc, idx), c0 = 2 * (idx - r * npc);
-    const uint32_t* win = reinterpret_cast<const uint32_t*>(keys + (r - 2) * wp + (c0 - 2));
-    glh_us2 v[25];
-#pragma unroll
-    for (int dr = 0; dr < 5; ++dr) {
-      const uint32_t d0 = win[dr * (wp / 2)], d1 = win[dr * (wp / 2) + 1], d2 = win[dr * (wp / 2) + 2];
-      const uint32_t m01 = (d0 >> 16) | (d1 << 16), m12 = (d1 >> 16) | (d2 << 16);
-      v[dr * 5 + 0] = __builtin_bit_cast(glh_us2, d0);   // pixel c0 | pixel c0 + 1 in the low | high half
-      v[dr * 5 + 1] = __builtin_bit_cast(glh_us2, m01);
-      v[dr * 5 + 2] = __builtin_bit_cast(glh_us2, d1);
-      v[dr * 5 + 3] = __builtin_bit_cast(glh_us2, m12);
-      v[dr * 5 + 4] = __builtin_bit_cast(glh_us2, d2);
-    }
-    const glh_us2 key = v[12];
-    const glh_us2 med = median25_pk(v);
-    ws.S[r * ld + c0] = (float)(ws.lut[key.x] - ws.lut[med.x]);
-    if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(ws.lut[key.y] - ws.lut[med.y]);
-  }
-  __syncthreads();
+  pt_highpass_write<TB, GEN>(ws, keys, wp, w, h, hp_rx, hp_ry, nb - 1, [&](int k) -> double { return ws.lut[k]; });
 #undef TP_STAMP
 }
 
@@ -418,6 +437,157 @@ __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
       if (idx < n) dst[idx] = v[q];
     }
   }
+}
+
+// 16-bit frames (uint16 gray or RGB; tracker.py:494-534 works on any dtype): a key is the pixel value or the channel sum
+// (<= 3 * 65535), far too many for a histogram in LDS.  What extract_tile needs of np.unique is, per pixel, the number of
+// pixels at or below its key -- cumsum(counts)[inverse] -- and that count IS a key the rest of the stage can work on: it
+// is monotone in the pixel key (equal keys, equal counts), fits 16 bits (tiles of the fused step have < 65 536 pixels),
+// so the median network runs on it unchanged, and its matched value is np.interp(count / n, template CDF) -- what the
+// 8-bit LUT tabulates -- taken where it is needed.  The counts come from a two-level ranking in LDS: the keys of the
+// tile, offset by their minimum, are bucketed by their high bits (PT_WIDE_BUCKETS buckets over the tile's own key range:
+// at most 8 low bits remain, none for tiles spanning fewer than 1 024 levels), the bucket offsets are a block scan, and
+// a pixel's count is its bucket's offset plus the members of its bucket whose low bits are at or below its own.
+// General instantiations only; same results as search_tile_from_box16 (the staged kernel), bit for bit.
+constexpr int PT_WIDE_BUCKETS = 1024;
+__host__ __device__ __forceinline__ int pt_wide_tab_bytes() { return (PT_WIDE_BUCKETS + 4) * 4; }
+
+// tab: [PT_WIDE_BUCKETS + 4] words in LDS; raw: [n] words, low: [n] bytes (LDS, or a workspace in memory for tiles that do
+// not fit); cdf_lds: room for the template CDF (2 x align16(8 hist_n) bytes, may lie over raw / low) or null (the CDF is
+// then read from memory); jt: [n + 1] uint16 clear of the CDF copy (may lie over raw / low otherwise); ws: keys (bordered
+// tile), S, ld, cdf_q / cdf_v (memory).
+template <int TB>
+__device__ __forceinline__ void pt_tile_prep_wide(const ObsFrame& ob, const int* box, int hist_n, const TileWs& ws,
+                                                  uint32_t* tab, uint32_t* raw, uint8_t* low, double* cdf_lds,
+                                                  uint16_t* jt, uint32_t* scan_tmp, int hp_rx, int hp_ry,
+                                                  unsigned long long* stp = nullptr) {
+  // diagnostic s_memtime stamps 13 / 14 inside this stage (tools/phase_probe.py), when armed
+#define TPW_STAMP(k)                                                                                     \
+  do {                                                                                                   \
+    if (stp && threadIdx.x == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  static_assert(PT_WIDE_BUCKETS % TB == 0, "whole buckets per thread");
+  constexpr int NBK = PT_WIDE_BUCKETS, PER = NBK / TB;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  const int wp = pt_keys_stride(w);
+  uint16_t* keys = ws.keys + 2 * wp + 2;
+  for (int b = tid; b < NBK; b += TB) tab[b] = 0;
+  if (tid == 0) {
+    tab[NBK] = 0xffffffffu;
+    tab[NBK + 1] = 0u;
+  }
+  __syncthreads();
+  const UDiv by_w = udiv_make(w);
+  uint32_t kmin = 0xffffffffu, kmax = 0u;
+  for (int base = 0; base < n; base += 4 * TB) {  // (four pixel loads in flight per thread)
+    int key[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      const int r = udiv(by_w, idx), c = idx - r * w;
+      key[q] = idx < n ? pixel_key16(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (key[q] >= 0) {
+        raw[base + q * TB + tid] = (uint32_t)key[q];
+        kmin = min(kmin, (uint32_t)key[q]);
+        kmax = max(kmax, (uint32_t)key[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, WAVE));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, WAVE));
+  }
+  if (lane == 0) {
+    atomicMin(&tab[NBK], kmin);
+    atomicMax(&tab[NBK + 1], kmax);
+  }
+  __syncthreads();
+  const uint32_t k0 = tab[NBK], range = tab[NBK + 1] - k0;
+  int shift = 0;  // uniform; <= 8 (range <= 3 * 65535)
+  while ((range >> shift) >= (uint32_t)NBK) ++shift;
+  const uint32_t lmask = (1u << shift) - 1u;
+  for (int idx = tid; idx < n; idx += TB) atomicAdd(&tab[(raw[idx] - k0) >> shift], 1u);
+  __syncthreads();
+  {
+    // exclusive scan of the bucket counts: PER buckets per thread + block scan
+    uint32_t cnt[PER], local = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      cnt[k] = tab[PER * tid + k];
+      local += cnt[k];
+    }
+    const uint32_t incl = wave_scan_add_u32(local);
+    if (lane == WAVE - 1) scan_tmp[tid / WAVE] = incl;
+    __syncthreads();
+    uint32_t run = incl - local;
+    for (int wv = 0; wv < tid / WAVE; ++wv) run += scan_tmp[wv];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      tab[PER * tid + k] = run;
+      run += cnt[k];
+    }
+  }
+  __syncthreads();
+  // the low bits of every key into its bucket (any order); afterwards tab[b] is the END of bucket b
+  for (int idx = tid; idx < n; idx += TB) {
+    const uint32_t d = raw[idx] - k0;
+    const uint32_t pos = atomicAdd(&tab[d >> shift], 1u);
+    low[pos] = (uint8_t)(d & lmask);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += TB) {
+    const uint32_t d = raw[idx] - k0, b = d >> shift, mine = d & lmask;
+    const uint32_t lo = b ? tab[b - 1] : 0u, hi = tab[b];
+    uint32_t cnt = hi;  // (no low bits: a bucket is one key)
+    if (shift) {
+      cnt = lo;
+      for (uint32_t j = lo; j < hi; ++j) cnt += low[j] <= mine;
+    }
+    const int r = udiv(by_w, idx), c = idx - r * w;
+    keys[r * wp + c] = (uint16_t)cnt;  // np.cumsum(counts)[inverse]
+  }
+  __syncthreads();
+  TPW_STAMP(13);
+  pt_border_cols<TB>(keys, wp, w, h);
+  const double *cq = ws.cdf_q, *cv = ws.cdf_v;
+  if (cdf_lds) {  // (raw / low are dead)
+    double* lv = cdf_lds + pt_align16(hist_n * 8) / 8;
+    pt_stage<TB>(cdf_lds, ws.cdf_q, hist_n);
+    pt_stage<TB>(lv, ws.cdf_v, hist_n);
+    cq = cdf_lds;
+    cv = lv;
+  }
+  __syncthreads();
+  pt_border_rows<TB>(keys, wp, h);
+  // helpers.match_cdf (helpers.py:489-493) = np.interp(count / n, template quantiles, template values) for a pixel and
+  // for its median: the interval search is made once per pixel, into jt[count] (equal counts write equal intervals), and
+  // starts from an index of the quantiles by 1/256 steps (acc, over the bucket table: dead)
+  uint16_t* acc = reinterpret_cast<uint16_t*>(tab);
+  for (int i = tid; i <= 256; i += TB) {
+    const int j = np_interp_find((double)i * (1.0 / 256.0), cq, hist_n);
+    acc[i] = (uint16_t)(j < 0 ? 0 : j);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += TB) {
+    const int r = udiv(by_w, idx), c = idx - r * w;
+    const int k = keys[r * wp + c];
+    const double x = (double)k / (double)n;  // np.cumsum(counts) / a.size
+    const int s256 = min(255, (int)(x * 256.0));
+    // xp[acc[s]] <= s / 256 <= x < (s + 1) / 256 < xp[acc[s + 1] + 1]: the interval of x lies between them
+    jt[k] = (uint16_t)np_interp_find(x, cq, hist_n, acc[s256], min(hist_n - 1, acc[s256 + 1] + 1));
+  }
+  __syncthreads();
+  TPW_STAMP(14);
+  pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, [&](int k) -> double {
+    const int j = jt[k];
+    return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, (double)k / (double)n, cq, cv, hist_n);
+  });
+#undef TPW_STAMP
 }
 
 #define PT_STAMP(k)                                                                      \
@@ -546,10 +716,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (i0 < hist_n) { cq[i0] = t.q0; cv[i0] = t.v0; }
     if (i1 < hist_n) { cq[i1] = t.q1; cv[i1] = t.v1; }
   };
-  auto load_template = [&](int o) {
+  auto load_template = [&](int o, bool with_cdf) {
     const size_t slot = (size_t)o * a.P + pt;
     const int tw = a.tw, th = a.th, twp = ssd_twp(tw);
-    const int hist_n = a.tmpl_hist_n[slot];
+    const int hist_n = with_cdf ? a.tmpl_hist_n[slot] : 0;
     float* T = reinterpret_cast<float*>(r2);
     const float* tg = a.tmpl_tile32 + slot * a.tile_cap;
     const UDiv by_twp = udiv_make(twp);
@@ -614,7 +784,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // (L2 / Infinity Cache).
   constexpr int NREG = PPT > 0 ? PPT : 1;
   TmplRegs tmpl0{};
-  const bool tmpl_early = live[0] && tmpl_small(hist_n0);  // uniform
+  // (16-bit frames: the template CDF has up to tw x th entries; the tile stage places it itself)
+  const bool tmpl_early = live[0] && tmpl_small(hist_n0) && !(SURF && a.obs[0].bits == 16);  // uniform
   const int rounds = (N + TB - 1) / TB;  // <= PPT when PPT > 0 (the host picks the variant)
   double* V0 = a.uv + (size_t)pt * N * 2;
   double u0[NREG];
@@ -810,7 +981,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int ninv = ho * ho + wo * wo;
     const bool inv_lds = dense;  // (ninv <= 512 <= TB)
     const int l2 = dense ? 2 * zb + (inv_lds ? pt_align16(ninv * 8) : 0) : zb + pt_align16(5 * (ho + wo) * 8);
-    const bool fits = off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
+    const bool wide = SURF && ob.bits == 16;  // uniform: 16-bit frames (pt_tile_prep_wide), through the workspace branch
+    const bool fits = !wide && off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
@@ -818,7 +990,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (o == 0 && tmpl_early)
       tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
     else
-      load_template(o);
+      load_template(o, !wide);
     // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
     //      once per branch below so that the coefficient loads keep their address space
     auto sample_all = [&](const double* Z, auto cells_tag) {
@@ -1022,7 +1194,31 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.cdf_v = hv_g;
       ws.fh = fh_g;
       ws.fw = fw_g;
-      if (offT + hcl + pt_align16(pt_keys_count(ws_, hs) * 2) <= a.r2_bytes) {
+      if (wide) {
+        // [T | bucket table | key tile | raw keys + low bits, then the template CDF over them]: whatever of it fits;
+        // the rest in the workspaces (the surface's, free until the SSD, takes the raw keys)
+        const int npx = ws_ * hs;
+        uint32_t* tab = reinterpret_cast<uint32_t*>(X);
+        int used = offT + pt_align16(pt_wide_tab_bytes());
+        const int kb = pt_align16(pt_keys_count(ws_, hs) * 2);
+        if (used + kb <= a.r2_bytes) {
+          ws.keys = reinterpret_cast<uint16_t*>(r2 + used);
+          used += kb;
+        }
+        const int rb = pt_align16(npx * 4) + pt_align16(npx), jb = pt_align16((npx + 1) * 2);
+        const bool raw_lds = used + rb <= a.r2_bytes;
+        uint32_t* raw = raw_lds ? reinterpret_cast<uint32_t*>(r2 + used) : reinterpret_cast<uint32_t*>(ws.Z);
+        uint8_t* low = reinterpret_cast<uint8_t*>(raw) + pt_align16(npx * 4);
+        double* cdf_l = used + 2 * cdfb <= a.r2_bytes ? reinterpret_cast<double*>(r2 + used) : nullptr;
+        // the interval table: behind the CDF copy, else over the raw keys in LDS (no CDF copy there), else in memory
+        uint16_t* jt = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(ws.Z) + rb);
+        if (cdf_l && used + 2 * cdfb + jb <= a.r2_bytes)
+          jt = reinterpret_cast<uint16_t*>(r2 + used + 2 * cdfb);
+        else if (!cdf_l && raw_lds)
+          jt = reinterpret_cast<uint16_t*>(raw);
+        pt_tile_prep_wide<TB>(ob, box, hist_n, ws, tab, raw, low, cdf_l, jt, scan_tmp, a.hp_rx, a.hp_ry,
+                              (unsigned long long*)a.stamps);
+      } else if (offT + hcl + pt_align16(pt_keys_count(ws_, hs) * 2) <= a.r2_bytes) {
         // only the float32 search tile is too large: the key tile stays in LDS (its own call, so that the
         // median's window loads keep their address space)
         ws.keys = reinterpret_cast<uint16_t*>(X + hcl);

@@ -1349,8 +1349,11 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   int nb = 256;
   for (int o = 0; o < O; ++o) {
     if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
-    if (c->obs[o].bits != 8) return false;  // 16-bit frames: staged kernels (key histograms in HBM)
-    if (c->obs[o].channels == 3) nb = 766;
+    // 16-bit frames: ranked in LDS (glh_point.h: pt_tile_prep_wide) while a tile's pixel count fits a 16-bit key;
+    // float frames and wider workspaces: staged kernels
+    if (c->obs[o].bits == 16 && c->cfg.max_search_dim > 255) return false;
+    if (c->obs[o].bits != 8 && c->obs[o].bits != 16) return false;
+    if (c->obs[o].channels == 3 || c->obs[o].bits == 16) nb = 766;  // (16-bit: the bucket table is no larger)
   }
   // c[N] and, behind region 2, the pairwise-sum plan
   const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
@@ -1488,7 +1491,8 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     bool common = fast && rng_mode == GLH_RNG_PHILOX && c->compact && !c->have_mask;
     for (int o = 0; o < O; ++o) common &= a.obs[o].on && !(a.cam_flags[o] & CAM_F_NOT_SIMPLE);
     // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
-    const bool plain = c->hp_rx == 2 && c->hp_ry == 2 && c->interp_k == 3;  // the 5 x 5 median, bicubic sampling
+    bool plain = c->hp_rx == 2 && c->hp_ry == 2 && c->interp_k == 3;  // the 5 x 5 median, bicubic sampling ...
+    for (int o = 0; o < O; ++o) plain &= c->obs[o].bits == 8;            // ... of 8-bit frames
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common) ||
                       !plain;
     int tbv = 512, nobsv = O;

@@ -110,6 +110,7 @@ class Workload:
         return sub
 
     channels = 1  # 3: RGB frames (what a time-lapse JPEG decodes to)
+    bits = 8      # 16: the same scene on a 16-bit sensor (uint16 frames)
 
     @property
     def scene(self):
@@ -121,7 +122,7 @@ class Workload:
         return self._scene
 
     def frame(self, obs, t):
-        return self.scene.render(self.cams[obs], float(t), channels=self.channels)
+        return self.scene.render(self.cams[obs], float(t), channels=self.channels, bits=self.bits)
 
     def frames(self, obs):
         return [self.frame(obs, t) for t in range(self.T)]
@@ -131,7 +132,7 @@ class Workload:
                 "tangent_cartesian": "TangentCartesianMotion", "tangent_cylindrical": "TangentCylindricalMotion"}[motion]
         return {
             "workload": f"{self.name}: {self.P} points x {self.N} particles x {self.T} frames "
-                        f"{self.imgsz[0]}x{self.imgsz[1]} uint8{' RGB' if self.channels == 3 else ''}, tile {self.tile[0]}x{self.tile[1]}, "
+                        f"{self.imgsz[0]}x{self.imgsz[1]} uint{self.bits}{' RGB' if self.channels == 3 else ''}, tile {self.tile[0]}x{self.tile[1]}, "
                         f"{self.O} observer(s), {name}, radial k={tuple(self.cfg['k'])}",
             "points_per_gpu": self.P,
             "particles": self.N,
@@ -146,6 +147,8 @@ def setup_context(ctx, wl, frames=None, channels=None):
     channels = wl.channels if channels is None else channels
     for o in range(wl.O):
         ctx.observer_init(o, wl.T, wl.imgsz[0], wl.imgsz[1], channels, wl.sigmas[o])
+        if wl.bits == 16:
+            ctx.observer_set_depth(o, np.uint16)
         ctx.observer_set_cameras(o, np.tile(wl.cams[o], (wl.T, 1)))
         for t in range(wl.T):
             f = frames[o][t] if frames is not None else wl.frame(o, t)

@@ -141,8 +141,9 @@ int glh_observer_init(glh_ctx* ctx, int obs, int n_images, int width, int height
 /* Sample type of the observer's frames: 8 (default, uint8), 16 (uint16), 32 (float32) or 64 (float64), one or three
  * channels -- Tracker.extract_tile works on any dtype (tracker.py:494-534) and normalises a float tile in the frame's
  * own dtype (a float32 mean / std in NumPy's summation order).  After glh_observer_init, before the first upload; the
- * upload calls then copy width * height * channels * bits / 8 bytes.  16-bit and float observers run on the staged
- * kernels (float: the distinct values of a tile are found by counting, O(pixels^2) per tile: modest tiles).          */
+ * upload calls then copy width * height * channels * bits / 8 bytes.  16-bit observers run on the fused step while
+ * max_search_dim <= 255 (a tile's pixel count is then a 16-bit key), on the staged kernels beyond; float observers on the
+ * staged kernels (the distinct values of a tile are found by counting, O(pixels^2) per tile: modest tiles).          */
 int glh_observer_set_depth(glh_ctx* ctx, int obs, int bits);
 /* One Camera per image (Image.cam, image.py:110; Camera.R camera.py:239-280 is evaluated
  * on the host in float64 at upload).  cams: [n_images][GLH_CAM_LEN].                      */

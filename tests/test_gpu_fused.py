@@ -514,3 +514,74 @@ def test_other_median_windows_and_bilinear_sampling_on_the_fused_kernel(lib, var
         np.testing.assert_array_equal(res[0][1], res[1][1])
         np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
         assert abs(np.median(res[0][2][-1, :, 3]) - 0.15) < 0.06
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+@pytest.mark.parametrize("variant", [dict(), dict(highpass=(3, 3)), dict(interpolation=(1, 1))])
+def test_sixteen_bit_frames_on_the_fused_kernel(lib, variant, math):
+    """uint16 frames, gray and RGB, run on the general instantiations of the fused kernel (rounds 1-3a: staged kernels
+    with key histograms in memory): the pixel keys are ranked in LDS (glh_point.h: pt_tile_prep_wide) -- bit for bit the
+    staged kernels, with the key tile in LDS and (mode 2) in the workspaces, host-fed and device draws; one observer
+    and two.  Frames whose values span the 16-bit range, and the same scene squeezed into 300 levels (buckets without
+    low bits) and a constant-free but coarse one (many equal keys per bucket)."""
+    from glimpse_amd import workloads
+
+    T = 5
+    cases = (("C2", 6, 1500, 1, None), ("C5", 3, 2000, 3, None), ("C2", 4, 1200, 1, 300), ("C2", 4, 1200, 3, 40000))
+    for name, P, N, channels, levels in cases:
+        wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+        wl.channels, wl.bits = channels, 16
+        frames = [wl.frames(o) for o in range(wl.O)]
+        if levels:  # (a narrow range of levels, offset from zero)
+            frames = [[(f.astype(np.uint32) * levels // 65535 + 1000).astype(np.uint16) for f in fo] for fo in frames]
+        assert frames[0][0].dtype == np.uint16
+        rng = np.random.default_rng(7)
+        ev, us = rng.standard_normal((P, N, 3)), rng.random(P)
+        res = []
+        for mode in (1, 2, 0):
+            with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
+                workloads.setup_context(ctx, wl, frames)
+                if "highpass" in variant:
+                    ctx.set_highpass(variant["highpass"])
+                if "interpolation" in variant:
+                    ctx.set_interpolation(*variant["interpolation"])
+                ctx.set_math(math)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=11)
+                for o in range(wl.O):
+                    ctx.init_templates(o, 0)
+                ctx.record_moments(0)
+                idx = []
+                for i in range(1, T):
+                    if i == 2:
+                        ctx.step(i, 1.0, [i] * wl.O, normals=ev, u=us)  # (one step on host-fed draws)
+                    else:
+                        ctx.step(i, 1.0, [i] * wl.O, seed=11)
+                    idx.append(ctx.resample_indices())
+                    if mode:
+                        assert ctx.last_variant()[3] & 2  # the general code
+                assert (ctx.observer_status() == lib.OBS_OK).all() and (ctx.point_status() == 0).all()
+                stages = {k for k, v in ctx.profile_get().items() if v[1] > 0}
+                assert ("point_step" in stages) == bool(mode)
+                res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T), np.stack(idx)))
+        for other in (res[1], res[2]):
+            if math == "fast" and other is res[1]:
+                continue  # (mode 2 has its own bound on the per-cell sampling form: compared in exact arithmetic)
+            np.testing.assert_array_equal(res[0][3], other[3])
+            np.testing.assert_array_equal(res[0][0], other[0])
+            np.testing.assert_array_equal(res[0][1], other[1])
+            np.testing.assert_allclose(res[0][2], other[2], rtol=1e-12, atol=1e-13)
+        assert abs(np.median(res[0][2][-1, :, 3]) - 0.15) < 0.06
+    # a search workspace beyond 255 pixels (a tile's pixel count no longer fits a 16-bit key): the staged kernels
+    with lib.Context(2, 500, 1, max_search_dim=256, max_frames=2) as ctx:
+        wl = workloads.Workload("C2", n_frames=2, n_points=2, n_particles=500, imgsz=(640, 640))
+        wl.bits = 16
+        workloads.setup_context(ctx, wl)
+        ctx.set_debug(2)
+        ctx.set_frame(0)
+        ctx.init_particles(seed=1)
+        ctx.init_templates(0, 0)
+        ctx.step(1, 1.0, [1], seed=1)
+        assert "point_step" not in {k for k, v in ctx.profile_get().items() if v[1] > 0}

@@ -15,11 +15,16 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else None
 N = int(sys.argv[3]) if len(sys.argv) > 3 else None
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N)
+wl.bits = int(os.environ.get("GLH_BITS", "8"))          # 16: uint16 frames (pt_tile_prep_wide)
+wl.channels = int(os.environ.get("GLH_CHANNELS", "1"))
+HP = os.environ.get("GLH_HP")                            # e.g. 3: a 3 x 3 median, i.e. the general instantiation
 frames = [wl.frames(o) for o in range(wl.O)]
 NAMES = ["", "A evolve+project", "B tile_prep", "B ssd", "B spline_fit", "C sample", "C exp", "D resample",
          "E gather", "F moments"]
-with _lib.Context(wl.P, wl.N, wl.O, max_frames=T) as ctx:
+with _lib.Context(wl.P, wl.N, wl.O, max_frames=T, max_search_dim=255 if wl.bits == 16 else 320) as ctx:
     workloads.setup_context(ctx, wl, frames)
+    if HP:
+        ctx.set_highpass((int(HP), int(HP)))
     ctx.set_math(os.environ.get("GLH_MATH", "fast"))
     ctx.set_frame(0)
     ctx.init_particles(seed=3)
