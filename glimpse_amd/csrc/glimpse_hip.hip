@@ -171,6 +171,7 @@ struct glh_ctx {
   size_t tracks_tmp_n = 0;
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
+  int plan_N = 0;  // the N the pairwise-sum plan on the device was made for (0: none)
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
@@ -639,24 +640,29 @@ extern "C" int glh_begin_sequence(glh_ctx* c, int P, int N, int tw, int th) {
                        (size_t)c->cfg.max_frames * c->cfg.max_points * 36, (double)NAN);
     HIPCHK(hipGetLastError());
   }
-  // NumPy pairwise-sum plan for this N
-  PairwisePlan pl;
-  pairwise_plan(N, pl);
-  dfree(c->leaf_off); dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
-  CHK(dalloc(&c->leaf_off, pl.leaf_off.size()));
-  CHK(dalloc(&c->leaf_len, pl.leaf_len.size()));
-  CHK(dalloc(&c->sum_ops, pl.ops.size()));
-  CHK(dalloc(&c->level_off, pl.level_off.size()));
-  CHK(dalloc(&c->roots, pl.roots.size()));
-  HIPCHK(hipMemcpy(c->leaf_off, pl.leaf_off.data(), pl.leaf_off.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->leaf_len, pl.leaf_len.data(), pl.leaf_len.size() * 4, hipMemcpyHostToDevice));
-  if (!pl.ops.empty()) HIPCHK(hipMemcpy(c->sum_ops, pl.ops.data(), pl.ops.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->level_off, pl.level_off.data(), pl.level_off.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->roots, pl.roots.data(), pl.roots.size() * 4, hipMemcpyHostToDevice));
-  c->nleaves = (int)pl.leaf_off.size();
-  c->nnodes = pl.nnodes;
-  c->nlevels = (int)pl.level_off.size() - 1;
-  c->nroots = (int)pl.roots.size();
+  // NumPy pairwise-sum plan for this N (kept from the last sequence when N is the same: five frees, allocations and
+  // blocking copies -- ~10 ms -- that a tracker reusing its context for the next run does not pay again)
+  if (c->plan_N != N) {
+    PairwisePlan pl;
+    pairwise_plan(N, pl);
+    dfree(c->leaf_off); dfree(c->leaf_len); dfree(c->sum_ops); dfree(c->level_off); dfree(c->roots);
+    c->plan_N = 0;
+    CHK(dalloc(&c->leaf_off, pl.leaf_off.size()));
+    CHK(dalloc(&c->leaf_len, pl.leaf_len.size()));
+    CHK(dalloc(&c->sum_ops, pl.ops.size()));
+    CHK(dalloc(&c->level_off, pl.level_off.size()));
+    CHK(dalloc(&c->roots, pl.roots.size()));
+    HIPCHK(hipMemcpy(c->leaf_off, pl.leaf_off.data(), pl.leaf_off.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->leaf_len, pl.leaf_len.data(), pl.leaf_len.size() * 4, hipMemcpyHostToDevice));
+    if (!pl.ops.empty()) HIPCHK(hipMemcpy(c->sum_ops, pl.ops.data(), pl.ops.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->level_off, pl.level_off.data(), pl.level_off.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->roots, pl.roots.data(), pl.roots.size() * 4, hipMemcpyHostToDevice));
+    c->nleaves = (int)pl.leaf_off.size();
+    c->nnodes = pl.nnodes;
+    c->nlevels = (int)pl.level_off.size() - 1;
+    c->nroots = (int)pl.roots.size();
+    c->plan_N = N;
+  }
   c->moments_frame = -1;
   return GLH_OK;
 }
