@@ -116,6 +116,7 @@ struct PointArgs {
   int32_t cell_cap;  // fast arithmetic: surfaces of up to this many cells are sampled in per-cell form (0: never)
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
+  int32_t stop_at;   // diagnostic (tools/phase_counts.sh): every workgroup returns at this stamp (-1: never)
   int32_t nleaves, nnodes, nlevels, nroots;
 };
 
@@ -139,6 +140,9 @@ __host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
 // words per row, without index arithmetic.
 __host__ __device__ __forceinline__ int pt_keys_stride(int w) { return (w + 6 + 1) & ~1; }
 __host__ __device__ __forceinline__ int pt_keys_count(int w, int h) { return (h + 4) * pt_keys_stride(w); }
+
+// dynamic LDS the moment sums of phase F are parked in: [13][512] doubles + their 13 totals
+__host__ __device__ __forceinline__ int pt_park_bytes() { return (13 * 512 + 16) * 8; }
 
 // ints of the NumPy pairwise-sum plan staged in LDS: leaf_off | leaf_len | ops | level_off | roots
 __host__ __device__ __forceinline__ int pt_plan_ints(int nleaves, int nnodes, int nlevels, int nroots) {
@@ -593,6 +597,7 @@ __device__ __forceinline__ void pt_tile_prep_wide(const ObsFrame& ob, const int*
 #define PT_STAMP(k)                                                                      \
   do {                                                                                   \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * PT_NSTAMP + (k)] = __builtin_amdgcn_s_memtime(); \
+    if (a.stop_at == (k)) return;                                                        \
   } while (0)
 
 // SURF: the general instantiation -- gridded surfaces (dem / dem_sigma / viewshed rasters) and every motion model
@@ -1653,27 +1658,53 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   }
   PT_STAMP(8);
   {
-    // one pass for the 13 sums: wave shuffles -> LDS [wave][13] -> thread k < 6 finishes component k
-    double* mred = reinterpret_cast<double*>(r2);  // region 2 is free (the rank tables are dead after the gather)
+    // The 13 sums over the workgroup.  c[] and region 2 are free (weights gathered, rank tables dead): the partial sums
+    // are parked there, [sum][512 slots] (1 024 threads: lane pairs are added first); 16 lanes per sum then add 32 of
+    // them each (two chains) and finish on a DPP row -- a quarter of the instructions of 13 wave reductions (which were
+    // 6 % of the kernel's vector instructions).  A fixed order: the result depends on nothing but the partial sums.
+    // (The launch allocates at least pt_park_bytes() of dynamic LDS: fused_step.)
     pt_lds_barrier();  // LDS only: the gather's stores drain in the background
-    const double t0 = pt_wave_sum63(s0);
-    if (lane == WAVE - 1) mred[wave * 13] = t0;
+    constexpr int NP = 512;
+    double* M = c;
+    if constexpr (TB > NP) {
+      static_assert(TB == 2 * NP, "lane pairs");
+      s0 = group_sum_dpp(s0, 2);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double t1 = pt_wave_sum63(s1[k]), t2 = pt_wave_sum63(s2[k]);
-      if (lane == WAVE - 1) {
-        mred[wave * 13 + 1 + k] = t1;
-        mred[wave * 13 + 7 + k] = t2;
+      for (int k = 0; k < 6; ++k) {
+        s1[k] = group_sum_dpp(s1[k], 2);
+        s2[k] = group_sum_dpp(s2[k], 2);
+      }
+    }
+    if (TB == NP || !(tid & 1)) {
+      const int slot = TB == NP ? tid : tid >> 1;
+      M[slot] = s0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        M[(1 + k) * NP + slot] = s1[k];
+        M[(7 + k) * NP + slot] = s2[k];
       }
     }
     pt_lds_barrier();
-    if (tid < 6) {
-      double S0 = mred[0], S1 = mred[1 + tid], S2 = mred[7 + tid];
-      for (int w = 1; w < PT_WAVES; ++w) {
-        S0 += mred[w * 13];
-        S1 += mred[w * 13 + 1 + tid];
-        S2 += mred[w * 13 + 7 + tid];
+    double* tot = M + 13 * NP;
+    if (tid < 13 * 16) {
+      const double* src = M + (tid >> 4) * NP + (tid & 15);
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+      for (int i = 0; i < NP / 16; i += 2) {
+        acc0 += src[16 * i];
+        acc1 += src[16 * i + 16];
       }
+      const double t = group_sum_dpp(acc0 + acc1, 16);
+      if ((tid & 15) == 0) tot[tid >> 4] = t;
+    }
+    pt_lds_barrier();
+    double S0 = 0.0, S1 = 0.0, S2 = 0.0;
+    if (tid < 6) {
+      S0 = tot[0];
+      S1 = tot[1 + tid];
+      S2 = tot[7 + tid];
+    }
+    if (tid < 6) {
       const double m1 = S1 / S0, m2 = S2 / S0;
       const double var = m2 - m1 * m1;
       double* out = a.moments + (size_t)pt * 12;

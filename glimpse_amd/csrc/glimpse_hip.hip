@@ -1470,6 +1470,11 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.hp_ry = c->hp_ry;
   a.interp_k = c->interp_k;
   a.pt_base = c->pt_base;
+  a.stop_at = -1;
+  if (const char* stop = getenv("GLH_PT_STOP")) {  // diagnostic: "stamp:frame" -- that launch ends at that stamp
+    int k = -1, f = -1;
+    if (sscanf(stop, "%d:%d", &k, &f) == 2 && f == frame) a.stop_at = k;
+  }
   a.surf = surfaces(c);
   a.nleaves = c->nleaves;
   a.nnodes = c->nnodes;
@@ -1477,8 +1482,10 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.nroots = c->nroots;
   {
     StageTimer t(c, ST_POINT_STEP);
-    const size_t lds = (size_t)pt_align16(c->N * 8) + r2_bytes +
-                       pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
+    // (at least what phase F parks its partial sums in: every plan but fused_plan's small-LDS test hook has more)
+    const size_t lds = std::max((size_t)pt_align16(c->N * 8) + r2_bytes +
+                                    pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots)),
+                                (size_t)pt_park_bytes());
     const dim3 grid(c->P);
     // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  uv of observer 0
     // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that -- and always
