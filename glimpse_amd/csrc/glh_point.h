@@ -829,6 +829,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       if (i < N) {
         double n[3];
+#ifdef GLH_PAD_VALU  // sensitivity probe: this many extra vector instructions per particle (tools/ab.sh pad.so)
+        {
+          uint32_t padv = (uint32_t)i;
+#pragma unroll
+          for (int q = 0; q < GLH_PAD_VALU; ++q) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(padv) : "v"(tid));
+          asm volatile("" ::"v"(padv));
+        }
+#endif
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
         if constexpr (SURF)
           evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &raster_oob);
