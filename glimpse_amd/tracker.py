@@ -14,6 +14,7 @@ gives the reference's particles, indices and posteriors.  `rng="philox"` draws o
 (counter-based Philox4x32, fast arithmetic: `glh_set_math`) and is what large runs use.
 """
 import datetime
+import operator
 import os
 import warnings as _warnings
 
@@ -49,10 +50,31 @@ def _on_device(model):
     return type(model) in _DEVICE_MODELS
 
 
+_GET_N = operator.attrgetter("n")
+
+
+def _any_raster(models, attr):
+    """Some model's `attr` is a Raster (the types of the attribute values, collected at C speed)."""
+    return any(issubclass(t, Raster) for t in set(map(type, map(operator.attrgetter(attr), models))))
+
+
+def _any_raster_safe(models, attr):
+    try:
+        return _any_raster(models, attr)
+    except AttributeError:  # (some model without the attribute: the caller's own loop decides)
+        return True
+
+
 def _batches(models):
     """First index of every run of consecutive motion models that one device batch can hold: device models (`_on_device`)
     with the same particle count and at most ONE gridded dem and ONE gridded dem_sigma among them (constant surfaces are
     parameters of the point and mix freely); a user-defined model is a run of its own."""
+    # the usual batch -- thousands of device models with one particle count and constant surfaces -- is recognised by
+    # sets built at C speed; anything else takes the loop below
+    models = list(models)
+    if models and set(map(type, models)) <= set(_DEVICE_MODELS) and len(set(map(_GET_N, models))) == 1 \
+            and not _any_raster(models, "dem") and not _any_raster(models, "dem_sigma"):
+        return [0]
     starts, n, dem, sigma, device = [], None, None, None, False
     for i, m in enumerate(models):
         d = m.dem if isinstance(getattr(m, "dem", None), Raster) else None
@@ -282,8 +304,10 @@ class Tracker:
         """One gridded dem, one dem_sigma (shared by every model of the batch that uses a raster: `_batches` splits the
         tracks accordingly) and the viewshed."""
         for which, attr in ((_lib.RASTER_DEM, "dem"), (_lib.RASTER_DEM_SIGMA, "dem_sigma")):
-            rasters = {id(getattr(m, attr)): getattr(m, attr) for m in motion_models
-                       if isinstance(getattr(m, attr), Raster)}
+            rasters = {}
+            if _any_raster_safe(motion_models, attr):  # (checked on the attribute types first: thousands of models)
+                rasters = {id(getattr(m, attr)): getattr(m, attr) for m in motion_models
+                           if isinstance(getattr(m, attr), Raster)}
             assert len(rasters) <= 1, "a batch shares one raster per surface"
             ctx.set_raster(which, next(iter(rasters.values())) if rasters else None)
         ctx.set_raster(_lib.RASTER_VIEWSHED, self.viewshed)
