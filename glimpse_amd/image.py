@@ -3,8 +3,11 @@
 Holds a `Camera`, a capture datetime and the pixels: an in-memory array (the reference's cached read,
 image.py:180-186, :211-213) or a file that is decoded on first use (the reference reads it band by band
 through GDAL, image.py:187-210; here Pillow decodes it, which for the 8-bit JPEG / PNG / TIFF files of a
-time-lapse camera gives the same samples).  EXIF parsing, resized reads, `project`, `write` and `plot` are
-out of scope.
+time-lapse camera gives the same samples).  A read at another size than the file's (`cam.resize(...)`, image.py:188-193)
+is GDAL's default RasterIO resampling -- nearest neighbour, destination pixel i from source column
+floor((i + 0.5) * src / dst) -- on the decoded array; GDAL itself is absent here, and for JPEG files it would first pick
+one of the decoder's built-in 1/2, 1/4, 1/8 overviews, which this does not reproduce (parity unpinned for resized
+reads).  EXIF parsing, `project`, `write` and `plot` are out of scope.
 """
 import numpy as np
 
@@ -48,16 +51,41 @@ class Image:
             a = a[:, :, 0]
         return a
 
+    @staticmethod
+    def _nearest(n_src, n_dst, offset=0.0, count=None):
+        """Source index of every destination pixel under GDAL's default (nearest neighbour) RasterIO resampling of a
+        window of `count` source pixels starting at `offset` into `n_dst` pixels."""
+        count = n_src if count is None else count
+        idx = np.floor(offset + (np.arange(n_dst) + 0.5) * (count / n_dst) + 1e-10).astype(np.int64)
+        return np.clip(idx, 0, n_src - 1)
+
     def read(self, box=None, cache=True):
-        """image.py:137-214: the cached array, or the file (decoded once and kept when `cache`)."""
+        """image.py:137-214: the cached array, or the file (decoded once and kept when `cache`), at the camera's image
+        size: an array of another size is resampled to it (and the resampled array is what is cached, like the
+        reference caches what GDAL returned).  `box` = (left, top, right, bottom) in camera image coordinates;
+        with `cache=False` the box is read straight from the file's own pixels (image.py:194-201)."""
+        cw, ch = (int(v) for v in self.cam.imgsz)
         array = self.array
-        if array is None:
+        if array is not None and array.shape[1::-1] != (cw, ch) and self.path is not None:
+            array = None  # (a cached read of another size is not reused: image.py:183-187)
+        from_file = array is None
+        if from_file:
             array = self._decode()
-            if cache:
-                self.array = array
         h, w = array.shape[:2]
-        if (w, h) != tuple(self.cam.imgsz):
-            raise NotImplementedError("resized reads (cam.imgsz != array size) are out of scope")
+        if (w, h) != (cw, ch):
+            if box is not None and not cache and from_file:
+                # the window of the file that the box covers, resampled to the box's size (image.py:196-201)
+                xs, ys = w / cw, h / ch
+                x0, y0 = int(round(box[0] * xs)), int(round(box[1] * ys))
+                nx, ny = int(round((box[2] - box[0]) * xs)), int(round((box[3] - box[1]) * ys))
+                cols = self._nearest(w, box[2] - box[0], x0, nx)
+                rows = self._nearest(h, box[3] - box[1], y0, ny)
+                return array[rows][:, cols]
+            array = array[self._nearest(h, ch)][:, self._nearest(w, cw)]
+        if from_file and cache:
+            self.array = array
+        elif not from_file and array is not self.array and cache:
+            self.array = array  # (image.py:207-209: a cached array of another size is replaced by the resized read)
         if box is not None:
             return array[box[1]:box[3], box[0]:box[2]]
         return array

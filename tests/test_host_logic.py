@@ -218,8 +218,8 @@ def test_image_reads_files_like_arrays(tmp_path):
     path = tmp_path / "p.png"
     PIL.fromarray(rgb).convert("P").save(path)
     assert glimpse_amd.Image(path, cam=cam, datetime=T0).read().shape == (30, 40, 3)
-    with pytest.raises(NotImplementedError, match="resized"):
-        glimpse_amd.Image(tmp_path / "g.png", cam=glimpse_amd.Camera(imgsz=(20, 15), f=100), datetime=T0).read()
+    # a camera of another size than the file: the read is resized (test_image_reads_at_the_camera_size)
+    assert glimpse_amd.Image(tmp_path / "g.png", cam=glimpse_amd.Camera(imgsz=(20, 15), f=100), datetime=T0).read().shape[:2] == (15, 20)
     with pytest.raises(ValueError):
         glimpse_amd.Image(cam=cam, datetime=T0)
 
@@ -381,3 +381,45 @@ def test_camera_file_format_and_resizing(tmp_path):
     cam = g.Camera(imgsz=10, f=10)
     xyz = np.array([(1000, 10, 0), (0, 10, 0), (0, 0, 0), (0, -10, 0)], dtype=float)
     assert cam.infront(xyz).tolist() == [True, True, False, False]
+
+
+def test_image_reads_at_the_camera_size(tmp_path):
+    """Image.read (image.py:137-214): the image is resized as needed to the camera's image size (the reference's doctest:
+    cam.resize(0.5) -> a.shape == (268, 400), back to 1 -> (536, 800)), a box is a slice of that array whether or not the
+    read is cached, and a cached read of another size is not reused.  Nearest neighbour like GDAL's default RasterIO
+    resampling (GDAL is absent here: the sampling rule is restated, not pinned)."""
+    import datetime
+
+    from PIL import Image as PILImage
+
+    import glimpse_amd
+
+    rng = np.random.default_rng(5)
+    full = rng.integers(0, 256, size=(536, 800, 3), dtype=np.uint8)
+    path = tmp_path / "frame.png"
+    PILImage.fromarray(full).save(path)
+    cam = glimpse_amd.Camera(imgsz=(800, 536), f=(1000, 1000))
+    img = glimpse_amd.Image(str(path), cam=cam, datetime=datetime.datetime(2020, 1, 1))
+    np.testing.assert_array_equal(img.read(), full)
+    img.cam.resize(0.5)
+    assert tuple(img.cam.imgsz) == (400, 268)
+    half = img.read()
+    assert half.shape == (268, 400, 3)
+    np.testing.assert_array_equal(half, full[1::2, 1::2])  # floor((i + 0.5) * 2) = 2 i + 1
+    box = (0, 5, 100, 94)
+    np.testing.assert_array_equal(img.read(box), half[5:94, 0:100])
+    img.array = None
+    np.testing.assert_array_equal(img.read(box, cache=False), half[5:94, 0:100])
+    assert img.array is None
+    img.read()
+    img.cam.resize(1)
+    back = img.read()  # (the half-size array in the cache is not what a full-size read returns)
+    np.testing.assert_array_equal(back, full)
+    # a size that is not a divisor
+    img.cam.resize(0.3)
+    small = img.read()
+    w, h = (int(v) for v in img.cam.imgsz)
+    assert small.shape == (h, w, 3)
+    rows = np.floor((np.arange(h) + 0.5) * 536 / h + 1e-10).astype(int)
+    cols = np.floor((np.arange(w) + 0.5) * 800 / w + 1e-10).astype(int)
+    np.testing.assert_array_equal(small, full[rows][:, cols])
