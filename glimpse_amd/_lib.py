@@ -97,6 +97,7 @@ SIGNATURES = {
     "glh_record_moments": (_I, [_P, _I]),
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
     "glh_track": (_I, [_P, _I, _P, _P, _P, _U64]),
+    "glh_track_covariances": (_I, [_P, _I]),
     "glh_set_fused": (_I, [_P, _I]),
     "glh_set_math": (_I, [_P, _I]),
     "glh_set_highpass": (_I, [_P, _I, _I]),
@@ -438,6 +439,10 @@ class Context:
         if ta.shape != fr.shape or im.shape != (len(fr), self.O):
             raise ValueError("frames (T,), taus (T,) and images (T, O) do not agree")
         check(self.lib.glh_track(self.handle, len(fr), _ptr(fr), _ptr(ta), _ptr(np.ascontiguousarray(im)), seed))
+
+    def track_covariances(self, on=True):
+        """`track` also records the covariances of every frame it runs (glh_track_covariances)."""
+        check(self.lib.glh_track_covariances(self.handle, int(bool(on))))
 
     def set_fused(self, mode=1):
         """0 staged kernels, 1 fused per-point kernel (default), 2 fused with tiles forced to HBM (test)."""

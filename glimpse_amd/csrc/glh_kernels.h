@@ -554,6 +554,7 @@ __global__ __launch_bounds__(BLK) void k_moments(MomentsArgs a) {
 struct CovArgs {
   const double* particles;
   const double* weights;
+  const uint16_t* uidx;  // [P][N] or null: the state is run-length compact (planar records, uidx[j] = record of particle j)
   const uint8_t* active;
   double* out;  // [P][36]
   int32_t N;
@@ -567,11 +568,24 @@ __global__ __launch_bounds__(BLK) void k_covariance(CovArgs a) {
   const int tid = threadIdx.x;
   const double* P0 = a.particles + (size_t)pt * a.N * 6;
   const double* W0 = a.weights + (size_t)pt * a.N;
+  // particle i of the point: its record, expanded or compact -- the same values in the same order either way, so the
+  // sums (and the covariance) are bit for bit those of the expanded state
+  const uint16_t* U0 = a.uidx ? a.uidx + (size_t)pt * a.N : nullptr;
+  auto load = [&](int i, double2& v0, double2& v1, double2& v2) -> double {
+    if (U0) {
+      const int r = U0[i];
+      const double2* src = reinterpret_cast<const double2*>(P0) + r;  // planar: chunk c of record r at c N + r
+      v0 = src[0]; v1 = src[a.N]; v2 = src[2 * (size_t)a.N];
+      return W0[r];
+    }
+    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
+    v0 = src[0]; v1 = src[1]; v2 = src[2];
+    return W0[i];
+  };
   double sw = 0.0, s[6] = {0, 0, 0, 0, 0, 0};
   for (int i = tid; i < a.N; i += BLK) {
-    const double w = W0[i];
-    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
-    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    double2 v0, v1, v2;
+    const double w = load(i, v0, v1, v2);
     sw += w;
     s[0] += v0.x * w; s[1] += v0.y * w; s[2] += v1.x * w;
     s[3] += v1.y * w; s[4] += v2.x * w; s[5] += v2.y * w;
@@ -584,9 +598,8 @@ __global__ __launch_bounds__(BLK) void k_covariance(CovArgs a) {
 #pragma unroll
   for (int k = 0; k < 21; ++k) q[k] = 0.0;
   for (int i = tid; i < a.N; i += BLK) {
-    const double w = W0[i];
-    const double2* src = reinterpret_cast<const double2*>(P0 + (size_t)i * 6);
-    const double2 v0 = src[0], v1 = src[1], v2 = src[2];
+    double2 v0, v1, v2;
+    const double w = load(i, v0, v1, v2);
     const double d[6] = {v0.x - mean[0], v0.y - mean[1], v1.x - mean[2], v1.y - mean[3], v2.x - mean[4], v2.y - mean[5]};
     int k = 0;
 #pragma unroll

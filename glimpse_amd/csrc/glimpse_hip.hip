@@ -172,6 +172,7 @@ struct glh_ctx {
   uint16_t* ws_keys = nullptr;  // raw-key workspace of the fused kernel for tiles that do not fit in LDS
   int keys_cap = 0;
   int plan_N = 0;  // the N the pairwise-sum plan on the device was made for (0: none)
+  bool track_covariances = false;  // glh_track_covariances
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
@@ -1541,7 +1542,8 @@ extern "C" int glh_get_residual_draws(glh_ctx* c, int32_t* draws) {
 
 extern "C" int glh_record_covariances(glh_ctx* c, int frame) {
   CHK(need_seq(c));
-  CHK(ensure_expanded(c));
+  // (a run-length compact state -- what the fused step leaves -- is read through its record indices: expanding it first
+  // would cost a pass over the state and send the next frame to the general instantiation)
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (frame < 0 || frame >= c->cfg.max_frames) return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frame);
   if (!c->covariances) {
@@ -1553,6 +1555,7 @@ extern "C" int glh_record_covariances(glh_ctx* c, int frame) {
   CovArgs a{};
   a.particles = c->particles[c->cur];
   a.weights = c->weights[c->cur];
+  a.uidx = c->compact ? c->uidx[c->cur] : nullptr;
   a.active = c->have_active ? c->active : nullptr;
   a.out = c->covariances + (size_t)frame * c->P * 36;
   a.N = c->N;
@@ -1608,8 +1611,18 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
       return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frames[k]);
     CHK(check_images(c, images + (size_t)k * O));
   }
-  for (int k = 0; k < n_frames; ++k)
+  for (int k = 0; k < n_frames; ++k) {
     CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
+    if (c->track_covariances) CHK(glh_record_covariances(c, frames[k]));
+  }
+  return GLH_OK;
+}
+
+// glh_track also records the particle covariances of every frame it runs (Tracker.track(return_covariances=True),
+// tracker.py:307-308, :352): 0 (default) or 1.
+extern "C" int glh_track_covariances(glh_ctx* c, int on) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  c->track_covariances = on != 0;
   return GLH_OK;
 }
 

@@ -408,6 +408,7 @@ class Tracker:
             ctx.set_point_offset(point_offset)
             # device-RNG runs have no reference stream to be bit-exact with: fast arithmetic (GLH_MATH_FAST)
             ctx.set_math("fast" if draws is None else "exact")
+            ctx.track_covariances(bool(return_covariances))  # (runs of frames in one call record them on the way)
             for w in warn_log:
                 w.clear()
             out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None
@@ -435,7 +436,7 @@ class Tracker:
                 window = starting | running
                 if common(i):
                     set_active(window)
-                    if draws is None and not return_covariances and not return_particles:
+                    if draws is None and not return_particles:
                         # device RNG: the whole run of common frames in one call (glh_track: the launches are
                         # enqueued back to back, no host round trip per frame); every frame keeps its own status
                         # words, so the per-frame warnings are read afterwards

@@ -264,6 +264,9 @@ int glh_step(glh_ctx* ctx, int frame, double tau, const int32_t* images, int rng
  * (-1 = None).  Same results as the same glh_step calls.                                       */
 int glh_track(glh_ctx* ctx, int n_frames, const int32_t* frames, const double* taus, const int32_t* images,
               uint64_t seed);
+/* on = 1: glh_track also records the covariance of the particles after every frame it runs (glh_record_covariances:
+ * Tracker.track(return_covariances=True), track/tracker.py:307-308, :352), so that such a run is still one call.   */
+int glh_track_covariances(glh_ctx* ctx, int on);
 
 /* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +
  * re-evolving gather + moments in one launch, evolved state never round-trips through HBM)

@@ -117,6 +117,25 @@ def test_philox_tracking_recovers_velocity(golden):
     assert np.all(np.abs(v[:, 1]) < 0.05), v
 
 
+def test_philox_tracking_returns_covariances_in_one_run(golden):
+    """return_covariances=True on the device RNG (tracker.py:307-308, :352): the frames still go out as one glh_track run
+    (glh_track_covariances), the covariances are read from the compact state -- and equal np.cov of the particles the
+    same seed returns with return_particles=True (the frame-by-frame path)."""
+    g = golden("g8_c2mini.npz")
+    tracker = glimpse_amd.Tracker(observers_from(g), max_search_dim=128)
+    models = models_from(g)[:3]
+    for m in models:
+        m.n = 1500
+    cov = tracker.track(models, tile_size=(15, 15), rng="philox", seed=5, return_covariances=True)
+    full = tracker.track(models, tile_size=(15, 15), rng="philox", seed=5, return_particles=True)
+    np.testing.assert_array_equal(cov.means, full.means)
+    assert cov.sigmas is None and cov.covariances.shape == full.means.shape + (6,)
+    for p in range(len(models)):
+        for t in range(full.means.shape[1]):
+            want = np.cov(full.particles[p, t].T, aweights=full.weights[p, t], ddof=0)
+            np.testing.assert_allclose(cov.covariances[p, t], want, rtol=1e-7, atol=1e-12)
+
+
 @pytest.mark.parametrize("method", ["stratified", "residual", "choice"])
 def test_philox_tracking_with_the_other_resampling_methods(golden, method):
     """Every resampling method of tracker.py:151-223 drives a whole run on the device RNG (residual resampling on

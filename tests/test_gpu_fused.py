@@ -595,3 +595,34 @@ def test_sixteen_bit_frames_on_the_fused_kernel(lib, variant, math):
         ctx.init_templates(0, 0)
         ctx.step(1, 1.0, [1], seed=1)
         assert "point_step" not in {k for k, v in ctx.profile_get().items() if v[1] > 0}
+
+
+def test_covariances_of_the_compact_state_equal_those_of_the_expanded_state(lib):
+    """glh_record_covariances reads the run-length compact state the fused step leaves through its record indices (rounds
+    1-3a expanded it first, and the next frame then ran on the general instantiation): the same particles in the same
+    order, hence bit for bit the covariance of the expanded state -- and the fast common instantiation keeps running."""
+    from glimpse_amd import workloads
+
+    T = 5
+    wl = workloads.Workload("C2", n_frames=T, n_points=8, n_particles=2000, imgsz=(640, 640))
+    frames = [wl.frames(0)]
+    with lib.Context(wl.P, wl.N, 1, max_search_dim=160, max_frames=T + 1) as ctx:
+        workloads.setup_context(ctx, wl, frames)
+        ctx.set_math("fast")
+        ctx.set_frame(0)
+        ctx.init_particles(seed=4)
+        ctx.init_templates(0, 0)
+        ctx.record_moments(0)
+        for i in range(1, T):
+            ctx.step(i, 1.0, [i], seed=4)
+            ctx.record_covariances(i)
+            if i >= 2:
+                assert ctx.last_variant()[3] == 5  # fast | contract: the state stayed compact
+        compact = ctx.get_covariances(T - 1, 1)[0]
+        ctx.get_particles()            # (expands the state)
+        ctx.record_covariances(T)      # the same state, expanded, into another history slot
+        expanded = ctx.get_covariances(T, 1)[0]
+        np.testing.assert_array_equal(compact, expanded)
+        assert np.isfinite(compact).all() and (np.einsum("pii->pi", compact)[:, [0, 1, 3, 4]] > 0).all()  # (z does not vary)
+        mom = ctx.get_moments(T - 1, 1)[0]
+        np.testing.assert_allclose(np.sqrt(np.einsum("pii->pi", compact)), mom[:, 6:], rtol=1e-9, atol=1e-12)
