@@ -444,8 +444,11 @@ class Tracker:
                         while j + 1 <= hi and common(j + 1):
                             j += 1
                         ctx.track(list(range(i, j + 1)), taus[i - 1:j], [images_of(k) for k in range(i, j + 1)], seed=seed)
-                        for status in ctx.observer_status_frames(i, j - i + 1):
-                            note_skips(running, status)
+                        statuses = ctx.observer_status_frames(i, j - i + 1)
+                        # (one test for the whole run; the per-frame bookkeeping only where something was skipped)
+                        skipped = (statuses == _lib.OBS_OUT_OF_BOUNDS) | (statuses == _lib.OBS_TILE_TOO_LARGE)
+                        for k in np.nonzero(skipped.any(axis=(1, 2)))[0]:
+                            note_skips(running, statuses[k])
                         i = j + 1
                         continue
                     if draws is None:
@@ -509,7 +512,7 @@ class Tracker:
         if return_covariances:  # tracker.py:307-308, :352: (P, T, 6, 6) instead of sigmas
             covariances = np.ascontiguousarray(np.transpose(ctx.get_covariances(0, ntimes), (1, 0, 2, 3)))
         errors = [None] * ntracks
-        for p in range(ntracks):
+        for p in np.nonzero(status)[0]:
             if status[p]:
                 for bit, cls, msg in _ERRORS:
                     if status[p] & bit:
