@@ -1121,25 +1121,109 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, int channels
 }
 
 // search tile: work [2 n] doubles of memory (the normalised values, behind them the matched ones); the template CDF
+// `tab`: >= NBINS words of LDS, `scan_tmp`: NWAVES words.  The pixels at or below every pixel (np.unique's
+// cumsum(counts)[inverse]) by the two-level ranking of the fused kernel's 16-bit path (glh_point.h: pt_tile_prep_wide) on
+// the normalised values: buckets over the tile's own value range, a block scan for their offsets, the values scattered
+// into bucket order (over the matched-value array, which is written afterwards), a pixel's count = its bucket's offset
+// + the members of its bucket at or below it.  (Rounds 2-3a counted over the whole tile for
+// every pixel: O(n^2 / BLK) per thread.)
 __device__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
                                       const double* hist_v, const double* hist_q, int hist_n, double* work, double* red,
-                                      float* out, int hp_rx, int hp_ry) {
+                                      float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
+                                      unsigned char* lds, int lds_bytes) {
+  __shared__ double s_mm[NWAVES][2];
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  float* scratch = reinterpret_cast<float*>(work + n);  // (the matched values go there afterwards)
+  // the float32 scratch of the normalisation (2 n floats; a float32 frame is summed in NumPy's order by ONE thread, whose
+  // 4 n dependent loads should not be cache misses): LDS when it fits, else behind the values (the matched ones go there)
+  float* scratch = 2 * n * (int)sizeof(float) <= lds_bytes ? reinterpret_cast<float*>(lds) : reinterpret_cast<float*>(work + n);
   normalize_box_float(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
-  // helpers.match_cdf: quantile of every pixel = (pixels at or below it) / size, through np.interp of the template CDF
+  if (2 * hist_n * (int)sizeof(double) <= lds_bytes) {
+    // the template CDF into LDS (np.interp searches it twice per pixel)
+    double* cdf_lds = reinterpret_cast<double*>(lds);
+    for (int k = tid; k < hist_n; k += BLK) {
+      cdf_lds[k] = hist_q[k];
+      cdf_lds[hist_n + k] = hist_v[k];
+    }
+    hist_q = cdf_lds;
+    hist_v = cdf_lds + hist_n;
+    // (visible after the barriers of the ranking below)
+  }
   double* matched = work + n;
+  double* sorted = matched;                          // values in bucket order, until `matched` is made
+  uint32_t* leq = reinterpret_cast<uint32_t*>(out);  // counts, until `out` is made
+  constexpr int NBK = NBINS;
+  static_assert(NBK % BLK == 0, "whole buckets per thread");
+  for (int b = tid; b < NBK; b += BLK) tab[b] = 0;
+  double xmin = INFINITY, xmax = -INFINITY;
   for (int idx = tid; idx < n; idx += BLK) {
-    const double yi = work[idx];
-    uint32_t leq = 0;
-    for (int j = 0; j < n; ++j) leq += work[j] <= yi;
-    matched[idx] = np_interp((double)leq / (double)n, hist_q, hist_v, hist_n);
+    const double x = work[idx];
+    xmin = fmin(xmin, x);
+    xmax = fmax(xmax, x);
+  }
+  xmin = wave_min(xmin);
+  xmax = wave_max(xmax);
+  if ((tid & (WAVE - 1)) == 0) {
+    s_mm[tid / WAVE][0] = xmin;
+    s_mm[tid / WAVE][1] = xmax;
+  }
+  __syncthreads();
+  xmin = s_mm[0][0];
+  xmax = s_mm[0][1];
+  for (int wv = 1; wv < NWAVES; ++wv) {
+    xmin = fmin(xmin, s_mm[wv][0]);
+    xmax = fmax(xmax, s_mm[wv][1]);
+  }
+  // buckets LINEAR in the value (a floating-point map that is monotone non-decreasing: x <= y implies bucket(x) <=
+  // bucket(y), which is all the ranking needs; the bit pattern of a double would be logarithmic in it -- nearly all of a
+  // normalised tile in half a dozen buckets)
+  const double scale = xmax > xmin ? (double)(NBK - 1) / (xmax - xmin) : 0.0;
+  auto bucket = [&](double x) -> int { return min(NBK - 1, max(0, (int)((x - xmin) * scale))); };
+  for (int idx = tid; idx < n; idx += BLK) atomicAdd(&tab[bucket(work[idx])], 1u);
+  __syncthreads();
+  {
+    constexpr int PER = NBK / BLK;
+    uint32_t cnt[PER], local = 0;
+    for (int k = 0; k < PER; ++k) {
+      cnt[k] = tab[PER * tid + k];
+      local += cnt[k];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan_u32(local, scan_tmp, &total);  // (barriers inside)
+    for (int k = 0; k < PER; ++k) {
+      tab[PER * tid + k] = run;
+      run += cnt[k];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double x = work[idx];
+    sorted[atomicAdd(&tab[bucket(x)], 1u)] = x;
+  }
+  __syncthreads();  // (tab[b] is now the END of bucket b; the scattered values are visible to the block)
+  for (int idx = tid; idx < n; idx += BLK) {
+    const double x = work[idx];
+    const int b = bucket(x);
+    const uint32_t lo = b ? tab[b - 1] : 0u, hi = tab[b];
+    uint32_t c = lo;
+    for (uint32_t j = lo; j < hi; ++j) c += sorted[j] <= x;
+    leq[idx] = c;
+  }
+  __syncthreads();
+  // helpers.match_cdf: quantile of every pixel = (pixels at or below it) / size, through np.interp of the template CDF.
+  // The counts move over the normalised values (dead): the high-pass takes its median on them -- the match is monotone in
+  // the count, so the median of the matched window is the matched value of the median count (integers in registers for
+  // the 5 x 5 window, where a window of doubles lived in scratch memory: 6.7 -> ms per frame at 1 024 points).
+  uint32_t* rank = reinterpret_cast<uint32_t*>(work);
+  for (int idx = tid; idx < n; idx += BLK) {
+    matched[idx] = np_interp((double)leq[idx] / (double)n, hist_q, hist_v, hist_n);
+    rank[idx] = leq[idx];
   }
   __syncthreads();
   for (int idx = tid; idx < n; idx += BLK) {
     const int r = idx / w, c = idx - r * w;
-    out[idx] = (float)(matched[idx] - median_window_f64(matched, w, h, r, c, hp_rx, hp_ry));
+    const int med = median_window32(rank, w, 0, w, h, r, c, hp_rx, hp_ry);
+    out[idx] = (float)(matched[idx] - np_interp((double)med / (double)n, hist_q, hist_v, hist_n));
   }
 }
 
@@ -1358,6 +1442,7 @@ struct TilePrepArgs {
   int32_t o, O, P, NB, tw, th, tile_cap, search_cap, max_dim;
   int32_t hp_rx, hp_ry;     // half sizes of the median high-pass window
   int32_t kcols, krows;     // interpolation orders that set the least surface size (search_box)
+  int32_t lds_bytes;        // dynamic LDS of the launch
   const double* bbox_part;  // [O][P][NB][5]
   const int32_t* tmpl_valid;
   const double* tmpl_hist_v;
@@ -1429,7 +1514,8 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
   if (a.obs.bits >= 32)
     search_tile_from_boxf(a.obs.frame, a.obs.width, a.obs.channels, a.obs.bits, s_box, a.tmpl_hist_v + slot * a.tile_cap,
                           a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot], a.obs.fwork + (size_t)pt * a.obs.fwork_cap,
-                          &red[0][0], a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
+                          &red[0][0], a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry, hist, scan_tmp, smem,
+                          a.lds_bytes);
   else if (a.obs.bits == 16)
     search_tile_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, a.tmpl_hist_v + slot * a.tile_cap,
                            a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot],

@@ -1149,6 +1149,12 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     {
       StageTimer t(c, ST_TILEPREP);
       size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * (c->obs[o].bits == 16 ? 4 : 2);  // (halo of up to 3 rows)
+      // float frames: the template CDF (up to tw x th values and quantiles) is searched twice per pixel -- from LDS
+      // ... and the float32 scratch of a typical tile's normalisation (2 n floats) is read by one thread -- from LDS
+      if (c->obs[o].bits >= 32)
+        lds = std::max({lds, (size_t)2 * c->tile_cap * sizeof(double),
+                        std::min((size_t)8 * c->cfg.max_search_dim * c->cfg.max_search_dim, (size_t)40 * 1024)});
+      tp.lds_bytes = (int32_t)lds;
       hipLaunchKernelGGL(k_tileprep, dim3(c->P), dim3(BLK), lds, c->stream, tp);
     }
     HIPCHK(hipGetLastError());

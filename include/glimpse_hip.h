@@ -143,7 +143,7 @@ int glh_observer_init(glh_ctx* ctx, int obs, int n_images, int width, int height
  * own dtype (a float32 mean / std in NumPy's summation order).  After glh_observer_init, before the first upload; the
  * upload calls then copy width * height * channels * bits / 8 bytes.  16-bit observers run on the fused step while
  * max_search_dim <= 255 (a tile's pixel count is then a 16-bit key), on the staged kernels beyond; float observers on the
- * staged kernels (the distinct values of a tile are found by counting, O(pixels^2) per tile: modest tiles).          */
+ * staged kernels (the pixels at or below every pixel of a tile by a two-level ranking over the tile's value range).     */
 int glh_observer_set_depth(glh_ctx* ctx, int obs, int bits);
 /* One Camera per image (Image.cam, image.py:110; Camera.R camera.py:239-280 is evaluated
  * on the host in float64 at upload).  cams: [n_images][GLH_CAM_LEN].                      */
