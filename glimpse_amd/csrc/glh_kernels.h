@@ -857,67 +857,6 @@ __device__ void template_from_box16(const uint8_t* frame, int width, int channel
   }
 }
 
-__device__ void search_tile_from_box16(const uint8_t* frame, int width, int channels, const int* box,
-                                       const double* hist_v, const double* hist_q, int hist_n, uint32_t* bins,
-                                       uint32_t* band, uint32_t* scan_tmp, float* out, int hp_rx, int hp_ry) {
-  const int tid = threadIdx.x;
-  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  const int nb = bins16_count(channels);
-  for (int idx = tid; idx < n; idx += BLK) {
-    int r = idx / w, c = idx - r * w;
-    atomicAdd(&bins[pixel_key16(frame, width, channels, box[1] + r, box[0] + c)], 1u);
-  }
-  __syncthreads();
-  // inclusive scan of the bins in place: np.cumsum(counts) by key
-  const int chunk = (nb + BLK - 1) / BLK;
-  const int b0 = min(tid * chunk, nb), b1 = min(b0 + chunk, nb);
-  uint32_t cnt = 0;
-  for (int b = b0; b < b1; ++b) cnt += __hip_atomic_load(&bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t total;
-  uint32_t cum = block_excl_scan_u32(cnt, scan_tmp, &total);
-  for (int b = b0; b < b1; ++b) {
-    cum += __hip_atomic_load(&bins[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&bins[b], cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  auto matched = [&](int key) -> double {  // helpers.match_cdf for one value (helpers.py:489-493)
-    const uint32_t c = __hip_atomic_load(&bins[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return np_interp((double)c / (double)n, hist_q, hist_v, hist_n);
-  };
-  for (int r0 = 0; r0 < h; r0 += BAND_H) {
-    const int rows = min(BAND_H, h - r0);
-    for (int idx = tid; idx < (rows + 2 * hp_ry) * w; idx += BLK) {
-      int br = idx / w, c = idx - br * w;
-      int rr = reflect_index(r0 + br - hp_ry, h);
-      band[idx] = (uint32_t)pixel_key16(frame, width, channels, box[1] + rr, box[0] + c);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < rows * w; idx += BLK) {
-      int br = idx / w, c = idx - br * w;
-      // the band holds the (already reflected) rows r0 - ry .. r0 + rows + ry - 1: a window never leaves it
-      int v[49];
-      const int nx = 2 * hp_rx + 1, nwin = nx * (2 * hp_ry + 1);
-      for (int dr = 0; dr <= 2 * hp_ry; ++dr)
-        for (int dc = -hp_rx; dc <= hp_rx; ++dc) v[dr * nx + dc + hp_rx] = (int)band[(br + dr) * w + reflect_index(c + dc, w)];
-      int med;
-      if (hp_rx == 2 && hp_ry == 2) {
-        med = median25(v);
-      } else {
-        const int need = (nwin + 1) / 2;
-        med = 0x7fffffff;
-        for (int i = 0; i < nwin; ++i) {
-          int cnt2 = 0;
-          for (int j = 0; j < nwin; ++j) cnt2 += v[j] <= v[i];
-          if (cnt2 >= need && v[i] < med) med = v[i];
-        }
-      }
-      const int key = (int)band[(br + hp_ry) * w + c];
-      out[(size_t)(r0 + br) * w + c] = (float)(matched(key) - matched(med));
-    }
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // Float64 frames (one channel): Tracker.extract_tile works on any dtype (tracker.py:522-534).  The values of a
 // tile are arbitrary doubles, so np.unique is not a histogram over keys: what the reference needs from it is, per
@@ -1120,24 +1059,20 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, int channels
   }
 }
 
-// search tile: work [2 n] doubles of memory (the normalised values, behind them the matched ones); the template CDF
+// search tile from values: work [2 n] doubles of memory (the values -- any increasing function of the pixel --, behind them
+// the matched ones); the template CDF
 // `tab`: >= NBINS words of LDS, `scan_tmp`: NWAVES words.  The pixels at or below every pixel (np.unique's
 // cumsum(counts)[inverse]) by the two-level ranking of the fused kernel's 16-bit path (glh_point.h: pt_tile_prep_wide) on
 // the normalised values: buckets over the tile's own value range, a block scan for their offsets, the values scattered
 // into bucket order (over the matched-value array, which is written afterwards), a pixel's count = its bucket's offset
 // + the members of its bucket at or below it.  (Rounds 2-3a counted over the whole tile for
 // every pixel: O(n^2 / BLK) per thread.)
-__device__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
-                                      const double* hist_v, const double* hist_q, int hist_n, double* work, double* red,
-                                      float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
-                                      unsigned char* lds, int lds_bytes) {
+__device__ void search_tile_from_values(int w, int h, const double* hist_v, const double* hist_q, int hist_n, double* work,
+                                        float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
+                                        unsigned char* lds, int lds_bytes) {
   __shared__ double s_mm[NWAVES][2];
   const int tid = threadIdx.x;
-  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
-  // the float32 scratch of the normalisation (2 n floats; a float32 frame is summed in NumPy's order by ONE thread, whose
-  // 4 n dependent loads should not be cache misses): LDS when it fits, else behind the values (the matched ones go there)
-  float* scratch = 2 * n * (int)sizeof(float) <= lds_bytes ? reinterpret_cast<float*>(lds) : reinterpret_cast<float*>(work + n);
-  normalize_box_float(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
+  const int n = w * h;
   if (2 * hist_n * (int)sizeof(double) <= lds_bytes) {
     // the template CDF into LDS (np.interp searches it twice per pixel)
     double* cdf_lds = reinterpret_cast<double*>(lds);
@@ -1225,6 +1160,35 @@ __device__ void search_tile_from_boxf(const uint8_t* frame, int width, int chann
     const int med = median_window32(rank, w, 0, w, h, r, c, hp_rx, hp_ry);
     out[idx] = (float)(matched[idx] - np_interp((double)med / (double)n, hist_q, hist_v, hist_n));
   }
+}
+
+// float frames: the tile normalised in the frame's dtype (helpers.normalize), then the ranking above
+__device__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
+                                      const double* hist_v, const double* hist_q, int hist_n, double* work, double* red,
+                                      float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
+                                      unsigned char* lds, int lds_bytes) {
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  // the float32 scratch of the normalisation (2 n floats; a float32 frame is summed in NumPy's order by ONE thread, whose
+  // 4 n dependent loads should not be cache misses): LDS when it fits, else behind the values (the matched ones go there)
+  float* scratch = 2 * n * (int)sizeof(float) <= lds_bytes ? reinterpret_cast<float*>(lds) : reinterpret_cast<float*>(work + n);
+  normalize_box_float(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
+  search_tile_from_values(w, h, hist_v, hist_q, hist_n, work, out, hp_rx, hp_ry, tab, scan_tmp, lds, lds_bytes);
+}
+
+// 16-bit frames: the keys themselves are the values (any increasing function of the key ranks the same; the template's
+// normalisation is in its CDF) -- the ranking replaces the per-point histogram over all 65 536 / 196 606 keys that rounds
+// 2-3a kept in memory (zeroed and scanned for every tile: 11.4 ms per frame at C3)
+__device__ void search_tile_from_box16_ranked(const uint8_t* frame, int width, int channels, const int* box,
+                                              const double* hist_v, const double* hist_q, int hist_n, double* work,
+                                              float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
+                                              unsigned char* lds, int lds_bytes) {
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  for (int idx = threadIdx.x; idx < n; idx += BLK) {
+    const int r = idx / w, c = idx - r * w;
+    work[idx] = (double)pixel_key16(frame, width, channels, box[1] + r, box[0] + c);
+  }
+  __syncthreads();
+  search_tile_from_values(w, h, hist_v, hist_q, hist_n, work, out, hp_rx, hp_ry, tab, scan_tmp, lds, lds_bytes);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1517,10 +1481,10 @@ __global__ __launch_bounds__(BLK) void k_tileprep(TilePrepArgs a) {
                           &red[0][0], a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry, hist, scan_tmp, smem,
                           a.lds_bytes);
   else if (a.obs.bits == 16)
-    search_tile_from_box16(a.obs.frame, a.obs.width, a.obs.channels, s_box, a.tmpl_hist_v + slot * a.tile_cap,
-                           a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot],
-                           a.obs.bins + (size_t)pt * bins16_count(a.obs.channels), reinterpret_cast<uint32_t*>(smem),
-                           scan_tmp, a.search + slot * (size_t)a.search_cap, a.hp_rx, a.hp_ry);
+    search_tile_from_box16_ranked(a.obs.frame, a.obs.width, a.obs.channels, s_box, a.tmpl_hist_v + slot * a.tile_cap,
+                                  a.tmpl_hist_q + slot * a.tile_cap, a.tmpl_hist_n[slot],
+                                  a.obs.fwork + (size_t)pt * a.obs.fwork_cap, a.search + slot * (size_t)a.search_cap, a.hp_rx,
+                                  a.hp_ry, hist, scan_tmp, smem, a.lds_bytes);
   else
     search_tile_from_box(a.obs.frame, a.obs.width, a.obs.channels, s_box,
                          a.tmpl_hist_v + slot * a.tile_cap, a.tmpl_hist_q + slot * a.tile_cap,

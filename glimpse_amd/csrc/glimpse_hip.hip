@@ -973,10 +973,10 @@ static void fill_obs(glh_ctx* c, int o, int image, ObsFrame* f) {
 }
 
 // 16-bit frames: the zeroed per-point key histograms the staged tile kernels of observer `o` count into
-static int prepare_bins16(glh_ctx* c, int o) {
-  if (c->obs[o].bits >= 32 && !c->fwork)  // float frames: two tile-sized arrays of doubles per point
+static int prepare_bins16(glh_ctx* c, int o, bool search_tiles = false) {
+  if (c->obs[o].bits >= 16 && !c->fwork)  // 16-bit and float frames: two tile-sized arrays of doubles per point
     CHK(dalloc(&c->fwork, (size_t)c->cfg.max_points * 2 * c->cfg.max_search_dim * c->cfg.max_search_dim));
-  if (c->obs[o].bits != 16) return GLH_OK;
+  if (c->obs[o].bits != 16 || search_tiles) return GLH_OK;  // (search tiles are ranked; only templates count into bins)
   const size_t per = (size_t)(65535 * 3 + 1);
   if (!c->bins16) CHK(dalloc(&c->bins16, (size_t)c->cfg.max_points * per));
   HIPCHK(hipMemsetAsync(c->bins16, 0, (size_t)c->P * (65535 * c->obs[o].channels + 1) * sizeof(uint32_t), c->stream));
@@ -1143,7 +1143,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
     tp.box = c->box;
     tp.obs_status = cur_status(c);
     tp.search = c->search;
-    CHK(prepare_bins16(c, o));
+    CHK(prepare_bins16(c, o, true));
     tp.obs.bins = c->bins16;
     tp.obs.fwork = c->fwork;
     {
@@ -1151,7 +1151,7 @@ static int launch_tile_stages(glh_ctx* c, const int32_t* images) {
       size_t lds = (size_t)(BAND_H + 6) * c->cfg.max_search_dim * (c->obs[o].bits == 16 ? 4 : 2);  // (halo of up to 3 rows)
       // float frames: the template CDF (up to tw x th values and quantiles) is searched twice per pixel -- from LDS
       // ... and the float32 scratch of a typical tile's normalisation (2 n floats) is read by one thread -- from LDS
-      if (c->obs[o].bits >= 32)
+      if (c->obs[o].bits >= 16)
         lds = std::max({lds, (size_t)2 * c->tile_cap * sizeof(double),
                         std::min((size_t)8 * c->cfg.max_search_dim * c->cfg.max_search_dim, (size_t)40 * 1024)});
       tp.lds_bytes = (int32_t)lds;
