@@ -71,7 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--transport", default=None, choices=["rccl", "host"],
                     help="collective transport for N > 1 (default: RCCL when every rank can make the communicator, "
                          "else host copies through the rendezvous directory -- reported in the JSON line)")
-    ap.add_argument("--max-search-dim", type=int, default=320, help="search-tile workspace side (pixels)")
+    ap.add_argument("--max-search-dim", type=int, default=None,
+                    help="search-tile workspace side (pixels); default 320, 255 for --bits 16 (what the fused step takes)")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frame updates per library call: 0 = all the timed steps in one glh_track call (the frame loop "
                          "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
@@ -633,6 +634,9 @@ def secondary_legs(args, device, T, rendered, seed):
 # ------------------------------------------------------------------------------------------------
 def worker(args):
     from glimpse_amd import _lib, sharding, workloads
+
+    if args.max_search_dim is None:
+        args.max_search_dim = 255 if args.bits == 16 else 320
 
     group = sharding.Group.from_env()
     rank, world = group.rank, group.world
