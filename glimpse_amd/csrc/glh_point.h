@@ -428,18 +428,14 @@ __device__ __forceinline__ void pt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 template <int TB, typename T>
 __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
   const int tid = threadIdx.x;
+  // (four named values, not an array: inside the observer pass the array form was left in scratch memory)
   for (int base = 0; base < n; base += 4 * TB) {
-    T v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      v[q] = src[idx < n ? idx : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      if (idx < n) dst[idx] = v[q];
-    }
+    const int i0 = base + tid, i1 = i0 + TB, i2 = i1 + TB, i3 = i2 + TB;
+    const T v0 = src[i0 < n ? i0 : 0], v1 = src[i1 < n ? i1 : 0], v2 = src[i2 < n ? i2 : 0], v3 = src[i3 < n ? i3 : 0];
+    if (i0 < n) dst[i0] = v0;
+    if (i1 < n) dst[i1] = v1;
+    if (i2 < n) dst[i2] = v2;
+    if (i3 < n) dst[i3] = v3;
   }
 }
 
@@ -887,7 +883,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       }
     };
-    if constexpr (PPT > 0 && NOBS == 1 && !SURF) {
+    if constexpr (PPT > 0 && NOBS <= 2 && !SURF) {
       // unrolled over the per-thread particles (u0[r] = u with a static index instead of a compare-select chain
       // over the array); only where one observer keeps the body small
 #pragma unroll
@@ -962,8 +958,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const bool w_here = NOBS == 1 && !a.has_dem;  // uniform: phase C of observer 0 writes weights, not log likelihoods
   bool w_done = false;
   bool c_ready = false;  // uniform: c[] holds log likelihoods (not observer 0's parked coordinates)
-  for (int o = 0; o < NOBS; ++o) {
-    if (s_status[o] != GLH_OBS_OK) continue;  // uniform
+  // The body of the observer loop.  FIRST: observer 0 (o is then a constant): its coordinates live in registers / c[],
+  // the others' in the uv scratch.  With several observers the first pass is peeled off the loop, so that observer 0's
+  // registers are dead while the later observers' tile pipelines run (in a rolled loop they stay live through every
+  // iteration: the two-observer instantiation spilled them).
+  auto observer_pass = [&](auto first_tag, const int o) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    if (s_status[o] != GLH_OBS_OK) return;  // uniform
     const size_t slot = (size_t)o * a.P + pt;
     const ObsFrame& ob = a.obs[o];
     const int* box = s_box[o];
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int ws_ = box[2] - box[0], hs = box[3] - box[1];
     const int wo = ws_ - tw + 1, ho = hs - th + 1;
     const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
-    const int hist_n = o == 0 ? hist_n0 : a.tmpl_hist_n[slot];
+    const int hist_n = FIRST ? hist_n0 : a.tmpl_hist_n[slot];
     const int twp = ssd_twp(tw);
     // ---- LDS carve: [T | S | X] with X = max(hist + cum + lut + keys, Z + LU).  The template CDF (cq | cv) lies at the
     //      head of S: it is read while the LUT is made, the search tile is written after that -- 4 KB that decide whether
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
     const double* fw_g = a.lu + a.lu_off[wo];
-    if (o == 0 && tmpl_early)
+    if (FIRST && tmpl_early)
       tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
     else
       load_template(o, !wide);
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       // point instead of four comparisons per particle
       if (!(s_uvbb[o][0] >= sb[0] && s_uvbb[o][2] <= sb[2] && s_uvbb[o][1] >= sb[1] && s_uvbb[o][3] <= sb[3]))
         outside = true;
-      if (o == 0) {
+      if constexpr (FIRST) {
         auto sample_one = [&](double2 q) -> double {
           const double term = eval(q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
@@ -1281,6 +1282,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     if (cells) sample_all(reinterpret_cast<const double*>(r2), std::true_type{});  // one instance for every branch
     __syncthreads();  // region 2 is free for the next observer
+  };
+  observer_pass(std::true_type{}, 0);
+  if constexpr (NOBS > 1) {
+#pragma unroll 1
+    for (int o = 1; o < NOBS; ++o) observer_pass(std::false_type{}, o);
   }
   if (!c_ready) {  // every observer skipped (same-thread indices)
     if (SURF && !motion_term) {

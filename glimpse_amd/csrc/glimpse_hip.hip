@@ -1494,15 +1494,18 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
                                     pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots)),
                                 (size_t)pt_park_bytes());
     const dim3 grid(c->P);
-    // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  uv of observer 0
-    // in registers (PPT per thread) up to 10240 particles, parked in LDS / the uv scratch beyond that -- and always
-    // with two observers: their register-resident variants spill (37 VGPRs at PPT = 10) and measured 4 % slower at C5.
+    // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  u of observer 0 in registers
+    // (PPT per thread) and its v in c[] up to 10240 particles, both parked in LDS / the uv scratch beyond that and with
+    // three or four observers.  Two observers keep observer 0 in registers as well (round 4: the first observer's pass is
+    // peeled off the observer loop, so the registers are dead during the second observer's tile pipeline).
     const bool big = c->N > 10 * PT_BLK;
     const int tb = big ? PT_BLK_BIG : PT_BLK;
     const dim3 block(tb);
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
     if (big && ppt == 4) ppt = 10;
-    if (getenv("GLH_PT_UVLDS") || O >= 2) ppt = 0;
+    if (O == 2 && ppt == 4) ppt = 10;  // (the library carries <.., 10, 2> only)
+    if (getenv("GLH_PT_UVLDS") || O >= 3) ppt = 0;
+    if (O == 2 && getenv("GLH_PT_PPT0")) ppt = 0;  // diagnostic: the round-3 form (everything through the scratch)
     // the general instantiation: gridded surfaces and / or motion models other than CartesianMotion
     const bool fast = use_fast(c);
     // ... and, in fast arithmetic, everything the common instantiation is not compiled for (glh_point.h: COMMON): it
@@ -1516,11 +1519,9 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common) ||
                       !plain;
     int tbv = 512, nobsv = O;
-    if (!big) {
-      if (O >= 2) ppt = 0;
-    } else {
+    if (big) {
       tbv = 1024;
-      if (O >= 2 || ppt != 10) ppt = 0;
+      if (ppt != 10) ppt = 0;
     }
     c->last_variant[0] = tbv; c->last_variant[1] = ppt; c->last_variant[2] = nobsv;
     c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);

@@ -64,7 +64,7 @@ def test_benched_instantiation_matches_the_oracle(name, N):
 
 
 @pytest.mark.parametrize("name,P,N,variant", [("C3", 6, 5000, (512, 10, 1)), ("C4", 3, 10000, (1024, 10, 1)),
-                                              ("C5", 4, 5000, (512, 0, 2)), ("C2", 8, 2000, (512, 4, 1))])
+                                              ("C5", 4, 5000, (512, 10, 2)), ("C2", 8, 2000, (512, 4, 1))])
 def test_which_instantiation_takes_which_step(name, P, N, variant):
     """bench.py's configurations in fast arithmetic run on the COMMON instantiation (flags == 5: fast | contract) from their second
     frame on -- the one the fast parity tests (fused == staged bit for bit, fast vs exact to rounding:

@@ -117,7 +117,7 @@ def _compare(dev, ref, T):
 
 
 @pytest.mark.parametrize("name,P,N,variant", [("C3", 3, 5000, (512, 10, 1)), ("C4", 2, 10000, (1024, 10, 1)),
-                                              ("C5", 3, 5000, (512, 0, 2)), ("C2", 4, 2000, (512, 4, 1))])
+                                              ("C5", 3, 5000, (512, 10, 2)), ("C2", 4, 2000, (512, 4, 1))])
 def test_benched_arithmetic_and_streams_match_the_oracle(name, P, N, variant):
     """fast arithmetic + device Philox on BASELINE's frames: from the second update on this is the common
     instantiation (flags == 5), the kernel of bench.py's headline, the C4 shard, C5 and C2."""
