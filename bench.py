@@ -206,16 +206,37 @@ def pmc_traffic(wl, kernel):
     return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
-def sq_counters(wl):
-    """VALU wave-instructions per 64 particle-frames of the fused kernel from the committed SQ counter pass of this
-    workload shape (C3 only: the pass is expensive), or None."""
-    if (wl.name, wl.P, wl.N, wl.channels, wl.bits) != ("C3", 4096, 5000, 1, 8):
-        return None
+def pmc_traffic_source(wl, kernel):
+    """Where `roofline.traffic` comes from: NOT this run -- the PMC passes are separate rocprofv3 runs of the same
+    command on the builder's GPU box, committed under profiles/."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_C3_sq_counters.json")) as f:
-            return float(json.load(f)["derived"]["valu_wave_instructions_per_64_particle_frames"])
-    except (OSError, ValueError, KeyError):
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
         return None
+    entry = table.get(f"{wl.name}:{wl.P}x{wl.N}", {}).get(kernel)
+    if entry is None:
+        return None
+    return ("committed profile, not measured in this run: " + entry.get("source", "profiles/pmc_traffic.json")
+            + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the builder's gpurun box"
+            + (", " + table["_meta"]["collected"] if "_meta" in table and "collected" in table["_meta"] else "") + ")")
+
+
+SQ_COUNTER_FILES = ("r04_C3_sq_counters.json", "r03_C3_sq_counters.json")  # (the newest committed pass)
+
+
+def sq_counters(wl):
+    """(VALU wave-instructions per 64 particle-frames of the fused kernel, file) from the committed SQ counter pass of
+    this workload shape (C3 only: the pass is expensive), or (None, None)."""
+    if (wl.name, wl.P, wl.N, wl.channels, wl.bits) != ("C3", 4096, 5000, 1, 8):
+        return None, None
+    for name in SQ_COUNTER_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["derived"]["valu_wave_instructions_per_64_particle_frames"]), name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def algorithmic_bytes_per_step(P, N, O, tile, boxes, status, channels=1):
@@ -530,6 +551,23 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
             "api_tracks_ok": ok, "api_last_means_finite": finite}
 
 
+def apply_motion(ctx, wl, motion):
+    """The workload's points under another motion model than CartesianMotion (motion.py:207-522)."""
+    from glimpse_amd import _lib, workloads
+
+    if motion == "cartesian":
+        return
+    full = np.zeros((wl.P, _lib.MOTION_FULL_LEN))
+    full[:, :_lib.MOTION_LEN] = wl.params
+    full[:, 18] = _lib.MOTION_KINDS[motion]
+    full[:, 19] = 0.05  # slope_sigma (tangent models)
+    if "cylindrical" in motion:  # (speed, direction, dz/dt) and their sigmas
+        full[:, 4:7] = (workloads.VELOCITY[0], 0.0, 0.0)
+        full[:, 7:10] = (workloads.SIGMA, 0.5, 0.0)
+        full[:, 13:16] = (workloads.SIGMA / 4, 0.1, 0.0)
+    ctx.set_motion(full)
+
+
 # ------------------------------------------------------------------------------------------------
 # secondary legs of the default run: the other configurations and the parity-grade arithmetic, short
 # ------------------------------------------------------------------------------------------------
@@ -605,13 +643,17 @@ def secondary_legs(args, device, T, rendered, seed):
     from glimpse_amd import _lib, workloads
 
     legs = {}
-    plan = [("C3_exact", "C3", None, "exact", T, "C3", 1, 8),
-            ("C4_shard", "C4", None, "fast", T, "C3", 1, 8),
-            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, "C5", 1, 8),
-            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), "C3", 1, 8),
-            ("C3_rgb", "C3", None, "fast", T, "C3_rgb", 3, 8),
-            ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16)]
-    for key, name, points, math, n_frames, frames_of, channels, bits in plan:
+    plan = [("C3_exact", "C3", None, "exact", T, "C3", 1, 8, "cartesian"),
+            ("C4_shard", "C4", None, "fast", T, "C3", 1, 8, "cartesian"),
+            ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, "C5", 1, 8, "cartesian"),
+            # what each of C5's four GPUs runs: 512 of the 2 048 points
+            ("C5_shard", "C5", None, "fast", T, "C5", 1, 8, "cartesian"),
+            ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), "C3", 1, 8, "cartesian"),
+            # TangentCartesianMotion, the model of real glacier runs (motion.py:339-430): the general instantiation
+            ("C3_tangent", "C3", None, "fast", T, "C3", 1, 8, "tangent_cartesian"),
+            ("C3_rgb", "C3", None, "fast", T, "C3_rgb", 3, 8, "cartesian"),
+            ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16, "cartesian")]
+    for key, name, points, math, n_frames, frames_of, channels, bits, motion in plan:
         frames = rendered.get(frames_of)
         if frames is None:
             continue
@@ -623,7 +665,10 @@ def secondary_legs(args, device, T, rendered, seed):
             with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=dim,
                               max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
+                apply_motion(ctx, wl, motion)
                 legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
+                if motion != "cartesian":
+                    legs[key]["motion"] = motion
         except Exception as e:  # noqa: BLE001
             legs[key] = {"error": repr(e)}
     return legs
@@ -707,16 +752,7 @@ def worker(args):
     _mark("context ready, frames uploaded")
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
-    if args.motion != "cartesian":
-        full = np.zeros((wl.P, _lib.MOTION_FULL_LEN))
-        full[:, :_lib.MOTION_LEN] = wl.params
-        full[:, 18] = _lib.MOTION_KINDS[args.motion]
-        full[:, 19] = 0.05  # slope_sigma (tangent models)
-        if "cylindrical" in args.motion:  # (speed, direction, dz/dt) and their sigmas
-            full[:, 4:7] = (workloads.VELOCITY[0], 0.0, 0.0)
-            full[:, 7:10] = (workloads.SIGMA, 0.5, 0.0)
-            full[:, 13:16] = (workloads.SIGMA / 4, 0.1, 0.0)
-        ctx.set_motion(full)
+    apply_motion(ctx, wl, args.motion)
     ctx.set_point_offset(point_offset)
     ctx.set_math(args.math)
     transport = group.attach(ctx, args.transport)
@@ -852,18 +888,22 @@ def worker(args):
                 # hipMemcpyDtoD rate ("a measured device-copy ceiling")
                 "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = pmc_traffic_source(wl, kern)
         out["roofline"] = roof
         # The other ceiling, for the record: the step is bound by VALU issue, not by memory.  Wave-level
         # VALU instructions per launch from the committed SQ counters of this workload (SQ_INSTS_VALU, rocprofv3 --pmc)
         # against what the chip can issue: 256 CUs x 4 SIMDs, one 64-lane float64 / 3-operand instruction per 4 cycles.
-        sq = sq_counters(wl)
+        sq, sq_file = sq_counters(wl)
         if sq is not None:
             insts = sq * wl.P * wl.N / 64.0
             peak_rate = 256 * 4 * 2.4e9 / 4.0
             roof["valu_issue"] = {"wave_instructions_per_launch": insts, "per_64_particle_frames": sq,
                                   "frac_of_issue_peak": insts / (peak_rate * per_launch_ms * 1e-3),
                                   "model": "1 wave-instruction / 4 cycles / SIMD at 2.4 GHz, 1024 SIMDs",
-                                  "source": "profiles/r03_C3_sq_counters.json"}
+                                  "source": "profiles/" + sq_file,
+                                  "source_run": "committed profile, not measured in this run: a separate rocprofv3 "
+                                                "--pmc SQ_INSTS_VALU pass of this command on the builder's gpurun box"}
         out["stage_ms_per_step"] = {k: ms / K for k, (ms, _) in stage_ms.items() if ms > 0}
         if len(launch_ms) == dom_n and launches_per_frame == 1:
             tail = launch_ms[-min(20, K * F):]

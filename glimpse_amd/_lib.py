@@ -56,6 +56,7 @@ SIGNATURES = {
     "glh_version": (_I, []),
     "glh_last_error": (C.c_char_p, []),
     "glh_device_count": (_I, [_P]),
+    "glh_device_memory": (_I, [_I, _P, _P]),
     "glh_create": (_I, [_P, _P]),
     "glh_destroy": (_I, [_P]),
     "glh_sync": (_I, [_P]),
@@ -185,6 +186,13 @@ def device_count():
     n = C.c_int(0)
     check(load().glh_device_count(C.byref(n)))
     return n.value
+
+
+def device_memory(device_id=0):
+    """(free, total) bytes of a device (hipMemGetInfo)."""
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    check(load().glh_device_memory(int(device_id), C.byref(free), C.byref(total)))
+    return free.value, total.value
 
 
 def comm_unique_id():

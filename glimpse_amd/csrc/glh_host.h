@@ -166,12 +166,20 @@ inline void spline_lu(int n, double* out) {
 // either side: out = [L: k arrays of n, L_d[i] at (i, i - d)] [u0inv: n] [U: k arrays of n, U_d[i] at (i, i + d)],
 // (2 k + 1) n doubles.  Same elimination as oracle/spline.py: lu_general.
 inline void spline_lu_general(int n, int k, double* out) {
-  std::vector<double> a((size_t)n * n, 0.0);
+  // banded storage, (2 k + 1) columns per row: a(i, j) at band[i * W + (j - i + k)] -- the elimination below only ever
+  // touches |i - j| <= k (round 4: this was a dense n x n matrix, O(dim^2) memory per size and O(dim^3) over the sizes
+  // of a context, seconds at the 1280 .. 2000 pixel workspaces the Tracker's growth loop can reach)
+  const int W = 2 * k + 1;
+  std::vector<double> band((size_t)n * W, 0.0);
+  auto A = [&](int i, int j) -> double& { return band[(size_t)i * W + (j - i + k)]; };
   for (int i = 0; i < n; ++i) {
     const int l = gspl_interval((double)i, n, k);
     double h[GLH_SPL_KMAX + 1];
     gspl_basis((double)i, l, n, k, h);
-    for (int m = 0; m <= k; ++m) a[(size_t)i * n + (l - k + m)] = h[m];
+    for (int m = 0; m <= k; ++m) {
+      const int j = l - k + m;
+      if (j - i >= -k && j - i <= k) A(i, j) = h[m];  // (the support of row i lies within k of the diagonal)
+    }
   }
   double* L = out;
   double* u0inv = out + (size_t)k * n;
@@ -179,16 +187,16 @@ inline void spline_lu_general(int n, int k, double* out) {
   for (size_t q = 0; q < (size_t)(2 * k + 1) * n; ++q) out[q] = 0.0;
   for (int c = 0; c < n; ++c) {
     for (int i = c + 1; i < std::min(c + k + 1, n); ++i) {
-      const double m = a[(size_t)i * n + c] / a[(size_t)c * n + c];
+      const double m = A(i, c) / A(c, c);
       L[(size_t)(i - c - 1) * n + i] = m;
-      for (int j = c; j < std::min(c + k + 1, n); ++j) a[(size_t)i * n + j] -= m * a[(size_t)c * n + j];
-      a[(size_t)i * n + c] = 0.0;
+      for (int j = c; j < std::min(c + k + 1, n); ++j) A(i, j) -= m * A(c, j);
+      A(i, c) = 0.0;
     }
   }
   for (int i = 0; i < n; ++i) {
-    u0inv[i] = 1.0 / a[(size_t)i * n + i];
+    u0inv[i] = 1.0 / A(i, i);
     for (int d = 1; d <= k; ++d)
-      if (i + d < n) U[(size_t)(d - 1) * n + i] = a[(size_t)i * n + i + d];
+      if (i + d < n) U[(size_t)(d - 1) * n + i] = A(i, i + d);
   }
 }
 

@@ -221,26 +221,57 @@ __device__ __forceinline__ void pt_highpass_write(const TileWs& ws, const uint16
     __syncthreads();
     return;
   }
-  const int npc = (w + 1) >> 1;
+  // Round 4: FOUR vertically adjacent outputs per thread from sorted rows (glh_median.h: GLH_SORT5_NETWORK ...): the
+  // eight window rows r0 - 2 .. r0 + 5 are fetched and sorted once, rows 1..4 and 3..6 of them are reduced to the six
+  // candidates every window containing them shares, and each output costs ten more operations -- 87 min / max per
+  // output instead of 198, and a quarter of the tasks (one pass over a steady-state tile instead of three).
+  constexpr int MR = 4;
+  const int npc = (w + 1) >> 1, nrb = (h + MR - 1) / MR;
   const UDiv by_npc = udiv_make(npc);
-  for (int idx = tid; idx < h * npc; idx += TB) {
-    const int r = udiv(by_npc, idx), c0 = 2 * (idx - r * npc);
-    const uint32_t* win = reinterpret_cast<const uint32_t*>(keys + (r - 2) * wp + (c0 - 2));
-    glh_us2 v[25];
-#pragma unroll
-    for (int dr = 0; dr < 5; ++dr) {
-      const uint32_t d0 = win[dr * (wp / 2)], d1 = win[dr * (wp / 2) + 1], d2 = win[dr * (wp / 2) + 2];
+  for (int idx = tid; idx < nrb * npc; idx += TB) {
+    const int rb = udiv(by_npc, idx), c0 = 2 * (idx - rb * npc), r0 = rb * MR;
+    const uint32_t* win = reinterpret_cast<const uint32_t*>(keys + (r0 - 2) * wp + (c0 - 2));
+    const int last = h + 3 - r0;  // the last row of the bordered tile, as a window row of this run (>= 4)
+    uint32_t centre[MR];
+    // window row dr of the run, sorted: pixel c0 in the low halves, pixel c0 + 1 in the high halves
+    auto row = [&](int dr, glh_us2* v) {
+      const int q = (dr < last ? dr : last) * (wp / 2);  // (rows past the tile serve outputs that are not stored)
+      const uint32_t d0 = win[q], d1 = win[q + 1], d2 = win[q + 2];
       const uint32_t m01 = (d0 >> 16) | (d1 << 16), m12 = (d1 >> 16) | (d2 << 16);
-      v[dr * 5 + 0] = __builtin_bit_cast(glh_us2, d0);   // pixel c0 | pixel c0 + 1 in the low | high half
-      v[dr * 5 + 1] = __builtin_bit_cast(glh_us2, m01);
-      v[dr * 5 + 2] = __builtin_bit_cast(glh_us2, d1);
-      v[dr * 5 + 3] = __builtin_bit_cast(glh_us2, m12);
-      v[dr * 5 + 4] = __builtin_bit_cast(glh_us2, d2);
-    }
-    const glh_us2 key = v[12];
-    const glh_us2 med = median25_pk(v);
-    ws.S[r * ld + c0] = (float)(value_of(key.x) - value_of(med.x));
-    if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(value_of(key.y) - value_of(med.y));
+      if (dr >= 2 && dr < 2 + MR) centre[dr - 2] = d1;
+      v[0] = __builtin_bit_cast(glh_us2, d0);
+      v[1] = __builtin_bit_cast(glh_us2, m01);
+      v[2] = __builtin_bit_cast(glh_us2, d1);
+      v[3] = __builtin_bit_cast(glh_us2, m12);
+      v[4] = __builtin_bit_cast(glh_us2, d2);
+      med_sort5_pk(v);
+    };
+    auto store = [&](int j, glh_us2 med) {
+      const int r = r0 + j;
+      if (r < h) {
+        const glh_us2 key = __builtin_bit_cast(glh_us2, centre[j]);
+        ws.S[r * ld + c0] = (float)(value_of(key.x) - value_of(med.x));
+        if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(value_of(key.y) - value_of(med.y));
+      }
+    };
+    glh_us2 ra[5], rb5[5], r2[5], m12[10], m34[10], x[6];
+    row(1, ra);
+    row(2, r2);
+    med_merge55_pk(ra, r2, m12);
+    row(3, ra);
+    row(4, rb5);
+    med_merge55_pk(ra, rb5, m34);
+    med_mid6_pk(m12, m34, x);
+    row(0, ra);
+    store(0, med_fin_pk(x, ra));
+    row(5, rb5);
+    store(1, med_fin_pk(x, rb5));
+    row(6, ra);
+    med_merge55_pk(rb5, ra, m12);  // (rows 5 and 6)
+    med_mid6_pk(m34, m12, x);
+    store(2, med_fin_pk(x, r2));
+    row(7, ra);
+    store(3, med_fin_pk(x, ra));
   }
   __syncthreads();
 }
@@ -428,14 +459,18 @@ __device__ __forceinline__ void pt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 template <int TB, typename T>
 __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
   const int tid = threadIdx.x;
-  // (four named values, not an array: inside the observer pass the array form was left in scratch memory)
   for (int base = 0; base < n; base += 4 * TB) {
-    const int i0 = base + tid, i1 = i0 + TB, i2 = i1 + TB, i3 = i2 + TB;
-    const T v0 = src[i0 < n ? i0 : 0], v1 = src[i1 < n ? i1 : 0], v2 = src[i2 < n ? i2 : 0], v3 = src[i3 < n ? i3 : 0];
-    if (i0 < n) dst[i0] = v0;
-    if (i1 < n) dst[i1] = v1;
-    if (i2 < n) dst[i2] = v2;
-    if (i3 < n) dst[i3] = v3;
+    T v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      v[q] = src[idx < n ? idx : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = base + q * TB + tid;
+      if (idx < n) dst[idx] = v[q];
+    }
   }
 }
 
@@ -958,13 +993,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   const bool w_here = NOBS == 1 && !a.has_dem;  // uniform: phase C of observer 0 writes weights, not log likelihoods
   bool w_done = false;
   bool c_ready = false;  // uniform: c[] holds log likelihoods (not observer 0's parked coordinates)
-  // The body of the observer loop.  FIRST: observer 0 (o is then a constant): its coordinates live in registers / c[],
-  // the others' in the uv scratch.  With several observers the first pass is peeled off the loop, so that observer 0's
-  // registers are dead while the later observers' tile pipelines run (in a rolled loop they stay live through every
-  // iteration: the two-observer instantiation spilled them).
-  auto observer_pass = [&](auto first_tag, const int o) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    if (s_status[o] != GLH_OBS_OK) return;  // uniform
+  // With two observers the loop is unrolled: observer 0's coordinates live in registers (u) and c[] (v), and in a rolled
+  // loop those registers stay live through every iteration -- the two-observer instantiation spilled them (round 3:
+  // 144 bytes of scratch); unrolled, they are dead while the second observer's tile pipeline runs.
+  constexpr int OBS_UNROLL = NOBS <= 2 ? NOBS : 1;
+#pragma unroll OBS_UNROLL
+  for (int o = 0; o < NOBS; ++o) {
+    if (s_status[o] != GLH_OBS_OK) continue;  // uniform
     const size_t slot = (size_t)o * a.P + pt;
     const ObsFrame& ob = a.obs[o];
     const int* box = s_box[o];
@@ -972,7 +1007,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int ws_ = box[2] - box[0], hs = box[3] - box[1];
     const int wo = ws_ - tw + 1, ho = hs - th + 1;
     const int nb = ob.channels == 1 ? 256 : 255 * ob.channels + 1;
-    const int hist_n = FIRST ? hist_n0 : a.tmpl_hist_n[slot];
+    const int hist_n = o == 0 ? hist_n0 : a.tmpl_hist_n[slot];
     const int twp = ssd_twp(tw);
     // ---- LDS carve: [T | S | X] with X = max(hist + cum + lut + keys, Z + LU).  The template CDF (cq | cv) lies at the
     //      head of S: it is read while the LUT is made, the search tile is written after that -- 4 KB that decide whether
@@ -1001,7 +1036,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
     const double* fw_g = a.lu + a.lu_off[wo];
-    if (FIRST && tmpl_early)
+    if (o == 0 && tmpl_early)
       tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
     else
       load_template(o, !wide);
@@ -1028,7 +1063,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       // point instead of four comparisons per particle
       if (!(s_uvbb[o][0] >= sb[0] && s_uvbb[o][2] <= sb[2] && s_uvbb[o][1] >= sb[1] && s_uvbb[o][3] <= sb[3]))
         outside = true;
-      if constexpr (FIRST) {
+      if (o == 0) {
         auto sample_one = [&](double2 q) -> double {
           const double term = eval(q.x, q.y) * scale;
           const double ll = 0.0 + term;  // same rounding as accumulating into a zeroed c[i]
@@ -1282,11 +1317,6 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     if (cells) sample_all(reinterpret_cast<const double*>(r2), std::true_type{});  // one instance for every branch
     __syncthreads();  // region 2 is free for the next observer
-  };
-  observer_pass(std::true_type{}, 0);
-  if constexpr (NOBS > 1) {
-#pragma unroll 1
-    for (int o = 1; o < NOBS; ++o) observer_pass(std::false_type{}, o);
   }
   if (!c_ready) {  // every observer skipped (same-thread indices)
     if (SURF && !motion_term) {

@@ -281,6 +281,16 @@ extern "C" int glh_device_count(int* count) {
   return GLH_OK;
 }
 
+extern "C" int glh_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(GLH_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(device_id));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  *free_bytes = (uint64_t)f;
+  *total_bytes = (uint64_t)t;
+  return GLH_OK;
+}
+
 extern "C" int glh_destroy(glh_ctx* c) {
   if (!c) return GLH_OK;
   (void)hipSetDevice(c->cfg.device_id);

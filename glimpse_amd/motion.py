@@ -8,9 +8,15 @@ evolves the particles on the device.  Their methods are host NumPy code with the
 loop (`Tracker._track_custom`: residual resampling on the np.random stream); the batched Tracker does
 not use them.  `Motion` is the reference's minimal model / interface statement (motion.py:13-89).
 """
+import itertools
+import operator
+
 import numpy as np
 
 from .raster import Raster
+
+_CARTESIAN_VECTORS = operator.attrgetter("xy", "xy_sigma", "vxyz", "vxyz_sigma", "axyz", "axyz_sigma")
+_CARTESIAN_SURFACES = operator.attrgetter("dem", "dem_sigma")
 
 
 def _surface(value, name, cls):
@@ -46,7 +52,22 @@ def params_table(models):
     concatenation per parameter instead of a dozen slice assignments per model)."""
     P = len(models)
     table = np.zeros((P, 24))
-    if P and all(type(m) in (CartesianMotion, CylindricalMotion) for m in models):
+    kinds = set(map(type, models))
+    if P and kinds == {CartesianMotion}:
+        # the usual batch, thousands of CartesianMotion models over constant surfaces: ONE pass over the models and ONE
+        # concatenation of their 6 P parameter vectors (what NumPy charges per small array is the cost here)
+        try:
+            vectors = list(itertools.chain.from_iterable(map(_CARTESIAN_VECTORS, models)))
+            flat = np.concatenate(vectors)
+            surfaces = np.array(list(map(_CARTESIAN_SURFACES, models)), dtype=np.float64)  # (TypeError: a Raster)
+            if flat.size == 16 * P and surfaces.shape == (P, 2):
+                table[:, 0:16] = flat.reshape(P, 16)
+                table[:, 16:18] = surfaces
+                return table  # (kind 0, no slope sigma, no rasters)
+        except (ValueError, TypeError):
+            pass  # scalars that broadcast, gridded surfaces: the general forms below
+        table[:] = 0.0
+    if P and kinds <= {CartesianMotion, CylindricalMotion}:
         rates = [m._rates() for m in models]
         table[:, 0:2] = _columns([m.xy for m in models], 2)
         table[:, 2:4] = _columns([m.xy_sigma for m in models], 2)

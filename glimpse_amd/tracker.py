@@ -118,7 +118,10 @@ class Tracker:
                  interpolation={"kx": 3, "ky": 3}, device=0, max_search_dim=None):  # noqa: B006
         """tracker.py:52-70 (+ `device`: GPU ordinal; `max_search_dim`: side of the per-point search-tile workspaces in
         pixels -- None sizes them from the prior's projected spread and re-runs the sequence with larger ones if a
-        search tile outgrows them, so the result never depends on the guess)."""
+        search tile outgrows them, up to what the kernels take (2000 pixels; 1117 for 16-bit frames) and half of the
+        device's free memory allows; beyond that, as with a fixed size, the observer is skipped on that frame with a
+        warning.  The per-track step methods (`initialize_template`, `update_weights`, ...) use `max_search_dim or 320`
+        and do not grow)."""
         self.observers = list(observers)
         if viewshed is not None and not isinstance(viewshed, Raster):
             raise TypeError("viewshed must be a glimpse_amd.Raster")
@@ -206,31 +209,66 @@ class Tracker:
         return matches
 
     # ---- device context ---------------------------------------------------------------------
-    def _context(self, n_points, n_particles, n_frames, tile_size, search_dim):
+    def _context(self, n_points, n_particles, n_frames, tile_size, search_dim, keep_old=False):
         O = len(self.observers)
         key = (n_points, n_particles, n_frames, max(tile_size), search_dim)
         if self._ctx is not None and self._ctx_key == key:
             return self._ctx
-        if self._ctx is not None:
-            self._ctx.close()
+        if self._ctx is not None and not keep_old:
+            # (closed first: two contexts of a large batch need not fit side by side; the fields are cleared at once, so
+            # that a failure below cannot leave a destroyed context behind for the next run of this shape)
+            old, self._ctx, self._ctx_key = self._ctx, None, None
+            old.close()
         ctx = _lib.Context(n_points, n_particles, O, device_id=self.device, max_tile=max(31, max(tile_size)),
                            max_search_dim=search_dim, max_frames=n_frames)
-        for o, obs in enumerate(self.observers):
-            first = obs.images[0].read()
-            if first.dtype not in (np.uint8, np.uint16, np.float32, np.float64) or \
-                    (first.ndim == 3 and first.shape[2] not in (1, 3)):
-                raise NotImplementedError("frames must be uint8, uint16, float32 or float64 with one or three channels on "
-                                          f"the GPU path, not {first.dtype} {first.shape}")
-            h, w = first.shape[:2]
-            ch = 1 if first.ndim == 2 else first.shape[2]
-            ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
-            ctx.observer_set_depth(o, first.dtype)
-            ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
-        ctx.set_highpass(self._highpass_size)
-        ctx.set_interpolation(*self._orders)
+        try:
+            for o, obs in enumerate(self.observers):
+                first = obs.images[0].read()
+                if first.dtype not in (np.uint8, np.uint16, np.float32, np.float64) or \
+                        (first.ndim == 3 and first.shape[2] not in (1, 3)):
+                    raise NotImplementedError("frames must be uint8, uint16, float32 or float64 with one or three channels "
+                                              f"on the GPU path, not {first.dtype} {first.shape}")
+                h, w = first.shape[:2]
+                ch = 1 if first.ndim == 2 else first.shape[2]
+                ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
+                ctx.observer_set_depth(o, first.dtype)
+                ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
+            ctx.set_highpass(self._highpass_size)
+            ctx.set_interpolation(*self._orders)
+        except Exception:
+            ctx.close()
+            raise
+        if self._ctx is not None:  # (keep_old: the previous context served until its successor was ready)
+            self._ctx.close()
         self._ctx, self._ctx_key = ctx, key
         self._uploaded = set()
         return ctx
+
+    def _sixteen_bit(self):
+        """Some observer's frames are uint16: the fused step takes those while the workspaces are at most 255 pixels
+        (a tile's pixel count must fit a 16-bit key), and no kernel beyond 1117."""
+        return any(obs.images[0].read().dtype == np.uint16 for obs in self.observers)
+
+    def _dim_limit(self, n_points):
+        """The largest workspace side the automatic growth may ask for: what the kernels take (2000 pixels; 1117 for
+        16-bit frames, glh_observer_set_depth) and what fits a memory budget -- search tile, keys and surface are
+        about 14 dim^2 bytes per point and observer, and half of the device's free memory may go to them."""
+        limit = 1117 if self._sixteen_bit() else 2000
+        try:
+            free, _ = _lib.device_memory(self.device)
+            per = 14.0 * max(1, len(self.observers)) * max(1, n_points)
+            limit = min(limit, int(np.sqrt(0.5 * free / per)))
+        except Exception:  # noqa: BLE001  (no device to ask: the kernels' limits alone)
+            pass
+        return limit
+
+    def _fit_dim(self, need, limit):
+        """Workspace side for a need of `need` pixels: a multiple of 16, except that 16-bit frames stay at 255 while
+        the need allows it (256 would send the whole run to the staged kernels, several times slower)."""
+        dim = int(16 * np.ceil(need / 16))
+        if need <= 255 < dim and self._sixteen_bit():
+            dim = 255
+        return int(min(limit, dim))
 
     def _estimate_search_dim(self, motion_models, matching, taus, tile_size):
         """Side (pixels) of the search-tile workspaces a run is likely to need: the template plus five standard
@@ -271,7 +309,7 @@ class Tracker:
             if seen.any():
                 spread = max(spread, float(sigma_px[seen].max()))
         dim = max(tile_size) + 2 * 5.0 * spread + 8
-        return int(min(2000, max(max(tile_size) + 16, 16 * np.ceil(dim / 16))))
+        return self._fit_dim(max(max(tile_size) + 16, dim), self._dim_limit(len(motion_models)))
 
     def _upload_images(self, ctx, matching):
         """Frames the run will touch -> HBM, once.  Images that still live in files are decoded by a thread pool
@@ -382,8 +420,7 @@ class Tracker:
         if dim is None and self._ctx is not None and self._ctx_key[:4] == (ntracks, n, ntimes, max(tile_size)):
             dim = self._ctx_key[4]  # the workspaces that served the last run of this shape
         elif dim is None:
-            dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), getattr(self, "_grown_dim", 0),
-                      max(31, max(tile_size)) + 16)
+            dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), max(31, max(tile_size)) + 16)
         ctx = self._context(ntracks, n, ntimes, tile_size, dim)
         self._upload_images(ctx, matching)
         outgrown = [False]  # a search tile did not fit the workspaces (this attempt)
@@ -498,13 +535,21 @@ class Tracker:
             outgrown[0] = False
             out_particles, out_weights, status, err_frame = self._attempt(run, rng, state0, ntracks, n, first, last,
                                                                           systematic, motion_models)
-            if not outgrown[0] or self.max_search_dim is not None or dim >= 2000:
+            if not outgrown[0] or self.max_search_dim is not None:
                 break
             # an automatic workspace was too small for some search tile (that observer was skipped on that frame):
-            # nothing of this attempt is kept -- same draws, larger workspaces
-            dim = min(2000, 2 * dim)
-            self._grown_dim = dim
-            ctx = self._context(ntracks, n, ntimes, tile_size, dim)
+            # nothing of this attempt is kept -- same draws, larger workspaces, within what the kernels take and the
+            # device's memory allows (beyond that the run stands as it is, with its 'observer skipped' warnings).  Only
+            # the context of this shape remembers the size: a diverging track does not enlarge later, unrelated runs.
+            grown = self._fit_dim(2 * dim, self._dim_limit(ntracks))
+            if grown <= dim:
+                break
+            try:
+                # (the context in use stays until the larger one exists: if that cannot be made, its results stand)
+                bigger = self._context(ntracks, n, ntimes, tile_size, grown, keep_old=True)
+            except (_lib.GlhError, MemoryError):
+                break
+            ctx, dim = bigger, grown
             self._upload_images(ctx, matching)
 
         means, sigmas = ctx.get_tracks(0, ntimes)  # (P, T, 6) each, laid out on the device

@@ -127,6 +127,10 @@ typedef struct glh_config {
 int glh_version(void);
 const char* glh_last_error(void);
 int glh_device_count(int* count);
+/* Free and total bytes of device `device_id` (hipMemGetInfo): the Python Tracker bounds the growth of its search-tile
+   workspaces by them (it re-runs a sequence with larger workspaces when a tile outgrows them, tracker.py has no such
+   limit: its tiles live in host memory).                                                                              */
+int glh_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes);
 int glh_create(const glh_config* cfg, glh_ctx** out);
 int glh_destroy(glh_ctx* ctx);
 int glh_sync(glh_ctx* ctx);
