@@ -76,6 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frame updates per library call: 0 = all the timed steps in one glh_track call (the frame loop "
                          "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
+    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2),
+                    help="streams of glh_track's frame loop (glh_set_track_streams): 0 = the library's choice (two for "
+                         "batches of at least two rounds of workgroups per half), 1 = one launch per frame, 2 = two "
+                         "half-batches on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the glimpse_amd.Tracker.track() leg (api_ms_per_step)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
@@ -606,12 +610,15 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     stage_ms = ctx.profile_get()
     dom = max(stage_ms, key=lambda k: stage_ms[k][0])
     launch_ms = ctx.profile_launches(dom)
+    span_ms = ctx.profile_span(dom)
+    streams = ctx.last_track_streams()
     ctx.profile_enable(False)
     status = ctx.observer_status()
     boxes = ctx.search_boxes()
     abytes = algorithmic_bytes_per_step(wl.P, wl.N, wl.O, wl.tile, boxes, status, wl.channels * wl.bits // 8)
     dom_ms, dom_n = stage_ms[dom]
     per_launch = dom_ms / max(dom_n, 1)
+    gpu_per_frame = span_ms / (n_frames - 1) if streams > 1 else per_launch  # (two streams: the launches overlap)
     kern = KERNEL_OF_STAGE.get(dom, dom)
     traffic = pmc_traffic(wl, kern) if math == "fast" and wl.channels == 1 and wl.bits == 8 else None
     moments = ctx.get_moments(0, n_frames)
@@ -619,9 +626,9 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
         "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
         "variant": list(ctx.last_variant()),
         "ms_per_frame": 1e3 * wall / (n_frames - 1),
-        "kernel_ms_per_launch": per_launch,
+        "kernel_ms_per_launch": per_launch, "track_streams": streams, "gpu_ms_per_frame": gpu_per_frame,
         "value": wl.P * wl.N * (n_frames - 1) / wall,
-        "roofline_frac": abytes / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "roofline_frac": abytes / (gpu_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": abytes,
         "traffic_ratio": None if traffic is None else traffic / abytes,
         "observer_ok_fraction": float((status == 0).mean()),
@@ -644,6 +651,9 @@ def secondary_legs(args, device, T, rendered, seed):
 
     legs = {}
     plan = [("C3_exact", "C3", None, "exact", T, "C3", 1, 8, "cartesian"),
+            # the headline's configuration with ONE launch per frame (glh_set_track_streams(1)): the per-launch roofline
+            # of rounds 1-3, where a launch has the chip to itself
+            ("C3_one_stream", "C3", None, "fast", T, "C3", 1, 8, "cartesian"),
             ("C4_shard", "C4", None, "fast", T, "C3", 1, 8, "cartesian"),
             ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, "C5", 1, 8, "cartesian"),
             # what each of C5's four GPUs runs: 512 of the 2 048 points
@@ -666,6 +676,7 @@ def secondary_legs(args, device, T, rendered, seed):
                               max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
                 apply_motion(ctx, wl, motion)
+                ctx.set_track_streams(1 if key == "C3_one_stream" else args.streams)
                 legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
                 if motion != "cartesian":
                     legs[key]["motion"] = motion
@@ -755,6 +766,7 @@ def worker(args):
     apply_motion(ctx, wl, args.motion)
     ctx.set_point_offset(point_offset)
     ctx.set_math(args.math)
+    ctx.set_track_streams(args.streams)
     transport = group.attach(ctx, args.transport)
     seed = args.seed
     images = lambda i: [i] * wl.O  # noqa: E731
@@ -811,6 +823,8 @@ def worker(args):
     stage_ms = ctx.profile_get()
     dom = max(stage_ms, key=lambda k: stage_ms[k][0])
     launch_ms = ctx.profile_launches(dom)
+    span_ms = ctx.profile_span(dom)
+    streams = ctx.last_track_streams() if C > 1 else 1
     ctx.profile_enable(False)
     _mark("headline timed")
 
@@ -857,7 +871,7 @@ def worker(args):
             "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
                            math=args.math, untimed_launches=W * F + B, parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K * F / elapsed, burn_in_steps=B, frames_per_call=C,
-                           frame_updates_per_step=F,
+                           frame_updates_per_step=F, track_streams=streams,
                            step=f"{F} consecutive frame update(s) of all {total_points} points",
                            timed_from="the prior: frame 0 initialises, all the later frames are timed "
                                       f"({K} steps x {F} updates)" if B == 0 else f"after {B} untimed updates"),
@@ -876,11 +890,22 @@ def worker(args):
         launches_per_frame = dom_n / (K * F)
         # one launch of the dominant kernel processes P*N particle-frames (SURVEY 8(d) per-unit bytes); `abytes` are
         # the algorithmic bytes of ONE frame update
-        ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         kern = KERNEL_OF_STAGE.get(dom, dom)
+        # `achieved`: algorithmic bytes of the dominant kernel's launches / the GPU time they take.  One launch per frame:
+        # bytes of a launch / its mean duration.  glh_track on two streams (the two halves of the points: while one
+        # half's launch drains, the other's fills the idle compute units): two launches are resident at a time and a
+        # launch's own duration spans its neighbour's work, so the time is the GPU span of the timed launches (start
+        # of the first to end of the last, HIP events on both streams) per frame; what ONE such launch achieves on its
+        # share of the chip is under `per_launch`.
+        span_per_frame_ms = span_ms / (K * F)
+        per_launch_ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
+        ach = abytes / (span_per_frame_ms * 1e-3) / 1e9 if streams > 1 else per_launch_ach
         roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern) if wl.channels == 1 and wl.bits == 8 else None,
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
+                "concurrent_launches": streams, "gpu_span_ms_per_frame": span_per_frame_ms,
+                "per_launch": {"achieved": per_launch_ach, "frac": per_launch_ach / HBM_PEAK_GBS,
+                               "points": wl.P / launches_per_frame},
                 "algorithmic_bytes_per_launch": abytes / launches_per_frame,
                 "algorithmic_bytes_per_particle_frame": abytes / (wl.P * wl.N),
                 "ssd_fp32_tflops": flops / (tot / (K * F) * 1e-3) / 1e12,
@@ -898,8 +923,8 @@ def worker(args):
         if sq is not None:
             insts = sq * wl.P * wl.N / 64.0
             peak_rate = 256 * 4 * 2.4e9 / 4.0
-            roof["valu_issue"] = {"wave_instructions_per_launch": insts, "per_64_particle_frames": sq,
-                                  "frac_of_issue_peak": insts / (peak_rate * per_launch_ms * 1e-3),
+            roof["valu_issue"] = {"wave_instructions_per_frame": insts, "per_64_particle_frames": sq,
+                                  "frac_of_issue_peak": insts / (peak_rate * span_per_frame_ms * 1e-3),
                                   "model": "1 wave-instruction / 4 cycles / SIMD at 2.4 GHz, 1024 SIMDs",
                                   "source": "profiles/" + sq_file,
                                   "source_run": "committed profile, not measured in this run: a separate rocprofv3 "
@@ -912,6 +937,11 @@ def worker(args):
             out["steady_value"] = wl.P * wl.N / (float(tail.mean()) * 1e-3) * world
             out["steady_roofline_frac"] = abytes / (float(tail.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["first_steps_ms"] = [round(float(v), 4) for v in launch_ms[:8]]
+        elif len(launch_ms) == dom_n and streams == 2 and launches_per_frame == 2:
+            # (the launches of a frame overlap: a frame's own time is not separable; the durations of its two
+            # half-launches are listed as they are)
+            out["first_steps_launch_ms"] = [round(float(v), 4) for v in launch_ms[:16]]
+            out["steady_launch_ms"] = float(launch_ms[-min(40, dom_n):].mean())
     ctx_closed = False
     if rank == 0 and world == 1:
         # the side legs must not cost the headline: a failure is reported in the line, the run then exits non-zero

@@ -99,6 +99,7 @@ SIGNATURES = {
     "glh_step": (_I, [_P, _I, _D, _P, _I, _P, _P, _U64]),
     "glh_track": (_I, [_P, _I, _P, _P, _P, _U64]),
     "glh_track_covariances": (_I, [_P, _I]),
+    "glh_set_track_streams": (_I, [_P, _I]),
     "glh_set_fused": (_I, [_P, _I]),
     "glh_set_math": (_I, [_P, _I]),
     "glh_set_highpass": (_I, [_P, _I, _I]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_debug_draws": (_I, [_P, _I, _U64, _U64, _P]),
     "glh_debug_last_variant": (_I, [_P, _P]),
+    "glh_debug_last_track_streams": (_I, [_P, _P]),
     "glh_get_moments": (_I, [_P, _I, _I, _P]),
     "glh_get_tracks": (_I, [_P, _I, _I, _P, _P]),
     "glh_get_moments_device": (_I, [_P, _P, _P]),
@@ -120,6 +122,7 @@ SIGNATURES = {
     "glh_stage_name": (C.c_char_p, [_I]),
     "glh_profile_get": (_I, [_P, _P, _P]),
     "glh_profile_get_launches": (_I, [_P, _I, _P, _I, _P]),
+    "glh_profile_get_span": (_I, [_P, _I, _P]),
     "glh_comm_unique_id": (_I, [_P]),
     "glh_comm_init": (_I, [_P, _P, _I, _I]),
     "glh_comm_destroy": (_I, [_P]),
@@ -452,6 +455,15 @@ class Context:
         """`track` also records the covariances of every frame it runs (glh_track_covariances)."""
         check(self.lib.glh_track_covariances(self.handle, int(bool(on))))
 
+    def set_track_streams(self, n):
+        """Streams of `track`'s frame loop: 0 automatic, 1 one, 2 two (glh_set_track_streams)."""
+        check(self.lib.glh_set_track_streams(self.handle, int(n)))
+
+    def last_track_streams(self):
+        n = C.c_int(0)
+        check(self.lib.glh_debug_last_track_streams(self.handle, C.byref(n)))
+        return n.value
+
     def set_fused(self, mode=1):
         """0 staged kernels, 1 fused per-point kernel (default), 2 fused with tiles forced to HBM (test)."""
         check(self.lib.glh_set_fused(self.handle, int(mode)))
@@ -582,6 +594,13 @@ class Context:
         if n.value:
             check(self.lib.glh_profile_get_launches(self.handle, k, _ptr(out), n.value, C.byref(n)))
         return out
+
+    def profile_span(self, stage):
+        """GPU time (ms) from the start of the first timed launch of `stage` to the end of its last one since the last
+        reset (launches on two streams overlap: their durations do not add up to it)."""
+        ms = C.c_double(0.0)
+        check(self.lib.glh_profile_get_span(self.handle, stage_names().index(stage), C.byref(ms)))
+        return ms.value
 
     # ---- multi-GPU (RCCL behind the C ABI; glimpse_amd/sharding.py drives it)
     def comm_init(self, comm_id, rank, world):

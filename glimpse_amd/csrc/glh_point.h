@@ -116,6 +116,7 @@ struct PointArgs {
   int32_t cell_cap;  // fast arithmetic: surfaces of up to this many cells are sampled in per-cell form (0: never)
   int32_t r2_bytes;  // bytes of LDS behind c[N] (followed by the pairwise-sum plan, pt_plan_ints() ints)
   int32_t pt_base;   // global index of point 0 (sharding-invariant Philox streams)
+  int32_t pt0;       // first point of this launch (glh_track runs the halves of a large batch on two streams)
   int32_t stop_at;   // diagnostic (tools/phase_counts.sh): every workgroup returns at this stamp (-1: never)
   int32_t nleaves, nnodes, nlevels, nroots;
 };
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
                                           // (and wait for) them on every iteration
   __shared__ double tab32[GLH_EXP_TAB];   // 2^(j/32) for exp_fast
   __shared__ double s_scale;              // FAST: N / sum of the weights (phase D)
-  const int pt = blockIdx.x, tid = threadIdx.x;
+  const int pt = blockIdx.x + a.pt0, tid = threadIdx.x;
   const int lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int N = a.N;
   double* c = reinterpret_cast<double*>(smem);  // [N] log likelihoods -> weights -> cumulative weights

@@ -173,6 +173,12 @@ struct glh_ctx {
   int keys_cap = 0;
   int plan_N = 0;  // the N the pairwise-sum plan on the device was made for (0: none)
   bool track_covariances = false;  // glh_track_covariances
+  // glh_track on two streams (glh_set_track_streams): 0 = automatic (two when the batch is at least two rounds of
+  // workgroups per half), 1 = always one, 2 = two whenever the fused step runs
+  int track_streams = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int last_track_streams = 1;  // streams the last glh_track used
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
@@ -199,6 +205,10 @@ struct glh_ctx {
   double ms[ST_COUNT] = {0};
   int64_t launches[ST_COUNT] = {0};
   std::vector<float> launch_ms[ST_COUNT];  // duration of every timed launch since the last reset (bounded)
+  // GPU time a stage spans since the last reset: from the start of its first timed launch to the end of its last one,
+  // on whichever stream (launches of glh_track's two streams overlap: their durations do not add up to it)
+  hipEvent_t span_a[ST_COUNT] = {nullptr};
+  float span_ms[ST_COUNT] = {0};
   // multi-GPU (glh_comm.h)
   Comm* comm = nullptr;
 };
@@ -227,7 +237,8 @@ struct StageTimer {
   glh_ctx* c;
   int stage;
   hipEvent_t a = nullptr, b = nullptr;
-  StageTimer(glh_ctx* ctx, int st) : c(ctx), stage(st) {
+  hipStream_t s;
+  StageTimer(glh_ctx* ctx, int st, hipStream_t on = nullptr) : c(ctx), stage(st), s(on ? on : ctx->stream) {
     c->launches[st]++;
     if (!c->profiling) return;
     auto get = [&]() {
@@ -242,11 +253,11 @@ struct StageTimer {
     };
     a = get();
     b = get();
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, s);
   }
   ~StageTimer() {
     if (!a) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, s);
     c->pending.push_back({a, b, stage});
   }
 };
@@ -260,7 +271,12 @@ static int drain_profile(glh_ctx* c) {
       c->ms[e.stage] += ms;
       if (c->launch_ms[e.stage].size() < (1u << 16)) c->launch_ms[e.stage].push_back(ms);
     }
-    c->pool.push_back(e.a);
+    if (!c->span_a[e.stage]) {
+      c->span_a[e.stage] = e.a;  // (kept until the next reset)
+    }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, c->span_a[e.stage], e.b) == hipSuccess && t > c->span_ms[e.stage]) c->span_ms[e.stage] = t;
+    if (c->span_a[e.stage] != e.a) c->pool.push_back(e.a);
     c->pool.push_back(e.b);
   }
   c->pending.clear();
@@ -328,6 +344,9 @@ extern "C" int glh_destroy(glh_ctx* c) {
     if (c->stage_done[k]) (void)hipEventDestroy(c->stage_done[k]);
   }
   if (c->upload_done) (void)hipEventDestroy(c->upload_done);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GLH_OK;
@@ -1410,9 +1429,14 @@ static int cell_cap(const glh_ctx* c) {
 }
 
 // The fused frame step (glh_point.h): ONE launch, one workgroup per point.
+// `pt0`, `npts`, `on`: the block of points this launch updates and the stream it is enqueued on (glh_track runs the two
+// halves of a large batch on two streams); `flip`: the last launch of the frame -- the state buffers change roles.
 static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, int rng_mode, const double* u,
-                      uint64_t seed, int r2_bytes) {
+                      uint64_t seed, int r2_bytes, int pt0 = 0, int npts = -1, hipStream_t on = nullptr,
+                      bool flip = true) {
   const int O = c->cfg.n_observers;
+  if (npts < 0) npts = c->P;
+  if (!on) on = c->stream;
   if (rng_mode == GLH_RNG_HOST) {
     if (!u) return fail(GLH_E_INVALID, "GLH_RNG_HOST needs u [P]");
     HIPCHK(hipMemcpyAsync(c->u, u, (size_t)c->P * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1448,7 +1472,8 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     if (!c->uidx[b]) CHK(dalloc(&c->uidx[b], (size_t)c->cfg.max_points * c->cfg.max_particles));
   a.uidx_in = c->compact ? c->uidx[c->cur] : nullptr;
   a.uidx_out = c->uidx[c->cur ^ 1];
-  a.stamps = c->stamps;
+  a.stamps = c->stamps ? c->stamps + (size_t)pt0 * PT_NSTAMP : nullptr;  // (indexed by the launch's own block index)
+  a.pt0 = pt0;
   a.moments = c->moments + (size_t)frame * c->P * 12;
   a.pt_status = c->pt_status;
   a.pt_err_frame = c->pt_err_frame;
@@ -1498,12 +1523,12 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.nlevels = c->nlevels;
   a.nroots = c->nroots;
   {
-    StageTimer t(c, ST_POINT_STEP);
+    StageTimer t(c, ST_POINT_STEP, on);
     // (at least what phase F parks its partial sums in: every plan but fused_plan's small-LDS test hook has more)
     const size_t lds = std::max((size_t)pt_align16(c->N * 8) + r2_bytes +
                                     pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots)),
                                 (size_t)pt_park_bytes());
-    const dim3 grid(c->P);
+    const dim3 grid(npts);
     // N <= 5120: 512 threads, two workgroups per CU; larger N: 1024 threads, one per CU.  u of observer 0 in registers
     // (PPT per thread) and its v in c[] up to 10240 particles, both parked in LDS / the uv scratch beyond that and with
     // three or four observers.  Two observers keep observer 0 in registers as well (round 4: the first observer's pass is
@@ -1540,12 +1565,14 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     const void* kern = pt_kernel(tbv, ppt, nobsv, surf, fast, surf ? common : fast);
     if (!kern) return fail(GLH_E_STATE, "no instantiation of the fused kernel for <%d, %d, %d>", tbv, ppt, nobsv);
     void* kargs[] = {(void*)&a};
-    HIPCHK(hipLaunchKernel(kern, grid, block, kargs, lds, c->stream));
+    HIPCHK(hipLaunchKernel(kern, grid, block, kargs, lds, on));
   }
   HIPCHK(hipGetLastError());
-  c->cur ^= 1;
-  c->compact = true;
-  c->moments_frame = frame;
+  if (flip) {
+    c->cur ^= 1;
+    c->compact = true;
+    c->moments_frame = frame;
+  }
   return GLH_OK;
 }
 
@@ -1628,10 +1655,61 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
       return fail(GLH_E_INVALID, "frame %d outside [0, max_frames)", frames[k]);
     CHK(check_images(c, images + (size_t)k * O));
   }
-  for (int k = 0; k < n_frames; ++k) {
-    CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
-    if (c->track_covariances) CHK(glh_record_covariances(c, frames[k]));
+  // Two streams (round 4).  A launch of the fused step is rounds of workgroups -- 512 (or 256 of 1 024 threads) at a
+  // time -- and between two launches the chip drains and refills: at C3 t(P) = 0.059 ms + 0.107 us x P, the constant
+  // is 12 % of a frame.  The points are independent, so the batch is cut in two halves whose frame loops run on two
+  // streams: while one half's launch drains, the other half's launch fills the idle compute units (C3 -6 %, C4 shard
+  // -4 %; four ways: worse).  Same kernel, same per-point arithmetic: results are bit for bit those of one stream.
+  int r2_bytes = 0;
+  const bool fused_ok = c->fused && !c->have_active && !c->keep_sse && !c->have_extra && fused_plan(c, &r2_bytes);
+  const int slots = 256 * (c->N > 10 * PT_BLK ? 1 : 2);  // workgroups the chip holds at once
+  bool two = fused_ok && !c->track_covariances && c->P >= 2 &&
+             (c->track_streams == 2 || (c->track_streams == 0 && c->P >= 2 * slots));
+  if (getenv("GLH_TRACK_STREAMS")) two = two && atoi(getenv("GLH_TRACK_STREAMS")) != 1;
+  c->last_track_streams = two ? 2 : 1;
+  if (!two) {
+    for (int k = 0; k < n_frames; ++k) {
+      CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
+      if (c->track_covariances) CHK(glh_record_covariances(c, frames[k]));
+    }
+    return GLH_OK;
   }
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  if (!c->stream2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  // the second stream starts behind everything enqueued so far, and the context's stream ends behind the second
+  HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  const int half = (c->P + 1) / 2;
+  int rc = GLH_OK;
+  for (int k = 0; k < n_frames && rc == GLH_OK; ++k) {
+    rc = glh_set_frame(c, frames[k]);
+    if (rc == GLH_OK)
+      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, 0, half,
+                      c->stream, false);
+    if (rc == GLH_OK)
+      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, half,
+                      c->P - half, c->stream2, true);
+  }
+  (void)hipEventRecord(c->ev_join, c->stream2);
+  (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+  return rc;
+}
+
+// Streams of glh_track's frame loop: 0 automatic, 1 one stream, 2 two streams whenever the fused step runs.
+extern "C" int glh_set_track_streams(glh_ctx* c, int n) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (n < 0 || n > 2) return fail(GLH_E_INVALID, "streams must be 0 (automatic), 1 or 2");
+  c->track_streams = n;
+  return GLH_OK;
+}
+
+extern "C" int glh_debug_last_track_streams(glh_ctx* c, int* n) {
+  if (!c || !n) return fail(GLH_E_INVALID, "null argument");
+  *n = c->last_track_streams;
   return GLH_OK;
 }
 
@@ -1876,6 +1954,9 @@ extern "C" int glh_profile_reset(glh_ctx* c) {
     c->ms[i] = 0;
     c->launches[i] = 0;
     c->launch_ms[i].clear();
+    if (c->span_a[i]) c->pool.push_back(c->span_a[i]);
+    c->span_a[i] = nullptr;
+    c->span_ms[i] = 0.f;
   }
   return GLH_OK;
 }
@@ -1886,6 +1967,13 @@ extern "C" int glh_profile_get(glh_ctx* c, double* ms, int64_t* launches) {
     if (ms) ms[i] = c->ms[i];
     if (launches) launches[i] = c->launches[i];
   }
+  return GLH_OK;
+}
+
+extern "C" int glh_profile_get_span(glh_ctx* c, int stage, double* ms) {
+  if (!c || !ms || stage < 0 || stage >= ST_COUNT) return fail(GLH_E_INVALID, "bad argument");
+  CHK(drain_profile(c));
+  *ms = (double)c->span_ms[stage];
   return GLH_OK;
 }
 

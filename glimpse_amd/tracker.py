@@ -51,6 +51,7 @@ def _on_device(model):
 
 
 _GET_N = operator.attrgetter("n")
+_GET_TIME_UNIT = operator.attrgetter("time_unit")
 
 
 def _any_raster(models, attr):
@@ -148,8 +149,9 @@ class Tracker:
         self.interpolation = interpolation
         self.device = device
         self.max_search_dim = max_search_dim
-        self.particles = None
-        self.weights = None
+        self._last_state = None
+        self._particles = None
+        self._weights = None
         self.templates = None
         self._ctx = None
         self._ctx_key = None
@@ -160,10 +162,41 @@ class Tracker:
         """tracker.py:84-87."""
         return np.unique(np.concatenate([obs.datetimes for obs in self.observers]))
 
+    # `particles` / `weights`: the single-track state of the reference (tracker.py:61-62).  After a batch run they hold
+    # the LAST track's final particles, like the reference leaves them -- fetched from the device when first read
+    # (nobody reads them after a run of thousands of tracks; the download was 0.5 ms of every call).
+    def _fetch_last_state(self):
+        pending, self._last_state = self._last_state, None
+        if pending is not None:
+            ctx, point = pending
+            if ctx is self._ctx and ctx.handle:
+                self._particles, self._weights = ctx.get_point_state(point)
+
+    @property
+    def particles(self):
+        self._fetch_last_state()
+        return self._particles
+
+    @particles.setter
+    def particles(self, value):
+        self._fetch_last_state()  # (the weights of a pending state are still wanted)
+        self._particles = value
+
+    @property
+    def weights(self):
+        self._fetch_last_state()
+        return self._weights
+
+    @weights.setter
+    def weights(self, value):
+        self._fetch_last_state()
+        self._weights = value
+
     def reset(self):
         """tracker.py:419-423."""
-        self.particles = None
-        self.weights = None
+        self._last_state = None
+        self._particles = None
+        self._weights = None
         self.templates = None
 
     def parse_datetimes(self, datetimes, maxdt=datetime.timedelta(0)):
@@ -360,14 +393,14 @@ class Tracker:
                       observer_mask=observer_mask, return_covariances=return_covariances,
                       return_particles=return_particles, reduce_particles=reduce_particles, parallel=parallel)
         time_unit = motion_models[0].time_unit
-        for model in motion_models[1:]:
-            if model.time_unit != time_unit:
-                raise ValueError("Motion models must have equal time units")
-        for model in motion_models:
-            if not _on_device(model) and not (callable(getattr(model, "initialize_particles", None))
-                                              and callable(getattr(model, "evolve_particles", None))):
-                raise TypeError(f"{type(model).__name__} is not a motion model: it needs initialize_particles() and "
-                                "evolve_particles(particles, dt) (motion.py:13-89)")
+        if len(set(map(_GET_TIME_UNIT, motion_models))) > 1:  # (equal timedeltas hash alike: one pass at C speed)
+            raise ValueError("Motion models must have equal time units")
+        if not set(map(type, motion_models)) <= set(_DEVICE_MODELS):
+            for model in motion_models:
+                if not _on_device(model) and not (callable(getattr(model, "initialize_particles", None))
+                                                  and callable(getattr(model, "evolve_particles", None))):
+                    raise TypeError(f"{type(model).__name__} is not a motion model: it needs initialize_particles() "
+                                    "and evolve_particles(particles, dt) (motion.py:13-89)")
         self.reset()
         ntracks = len(motion_models)
         raise_errors = ntracks < 2 if _catch_errors is None else not _catch_errors
@@ -426,7 +459,7 @@ class Tracker:
         outgrown = [False]  # a search tile did not fit the workspaces (this attempt)
         uniform = bool(observer_mask.all()) and bool((first == first[0]).all()) and bool((last == last[0]).all())
 
-        warn_log = [[] for _ in range(ntracks)]
+        warn_log = {}  # track -> its warnings (most tracks have none)
         images_of = lambda i: [m if m is not None else -1 for m in matching[i]]  # noqa: E731
 
         def set_active(mask):
@@ -446,17 +479,16 @@ class Tracker:
             # device-RNG runs have no reference stream to be bit-exact with: fast arithmetic (GLH_MATH_FAST)
             ctx.set_math("fast" if draws is None else "exact")
             ctx.track_covariances(bool(return_covariances))  # (runs of frames in one call record them on the way)
-            for w in warn_log:
-                w.clear()
+            warn_log.clear()
             out_p = np.full((ntracks, ntimes, n, 6), np.nan) if return_particles else None
             out_w = np.full((ntracks, ntimes, n), np.nan) if return_particles else None
             def note_skips(running, status):
                 for o in range(nobs):
                     for p in np.nonzero(running & (status[o] == _lib.OBS_OUT_OF_BOUNDS))[0]:
-                        warn_log[p].append(UserWarning(_OOB_WARNING))
+                        warn_log.setdefault(int(p), []).append(UserWarning(_OOB_WARNING))
                     for p in np.nonzero(running & (status[o] == _lib.OBS_TILE_TOO_LARGE))[0]:
                         outgrown[0] = True
-                        warn_log[p].append(RuntimeWarning(
+                        warn_log.setdefault(int(p), []).append(RuntimeWarning(
                             f"search tile exceeds max_search_dim={dim}; observer {o} skipped"))
 
             def common(i):
@@ -574,13 +606,17 @@ class Tracker:
         if raise_errors and errors[0] is not None:
             raise errors[0]
         # single-track state, like the reference leaves it after the last track
-        self.particles, self.weights = ctx.get_point_state(ntracks - 1)
+        self._particles = self._weights = None
+        self._last_state = (ctx, ntracks - 1)  # fetched when `particles` / `weights` are first read
+        warnings = [None] * ntracks
+        for p_, w_ in warn_log.items():
+            warnings[p_] = tuple(w_)
         kwargs = dict(time_unit=time_unit, datetimes=datetimes, means=means,
                       sigmas=None if return_covariances else sigmas, covariances=covariances,
                       particles=None if reduce_particles else out_particles,
                       weights=None if reduce_particles else out_weights, tracker=self, images=matching,
                       params=params, errors=errors,
-                      warnings=[tuple(w) if w else None for w in warn_log])
+                      warnings=warnings)
         tracks = Tracks(**kwargs)
         if reduce_particles:
             tracks.reduced = [reduce_particles(out_particles[p], out_weights[p]) for p in range(ntracks)]

@@ -271,6 +271,12 @@ int glh_track(glh_ctx* ctx, int n_frames, const int32_t* frames, const double* t
 /* on = 1: glh_track also records the covariance of the particles after every frame it runs (glh_record_covariances:
  * Tracker.track(return_covariances=True), track/tracker.py:307-308, :352), so that such a run is still one call.   */
 int glh_track_covariances(glh_ctx* ctx, int on);
+/* Streams of glh_track's frame loop.  The tracks of the reference are independent (track/tracker.py:381-387 hands them
+ * to a process pool); here the two halves of a large batch run their frame loops on two HIP streams, so that one
+ * half's launch fills the compute units the other half's launch leaves idle while it drains and refills (bit for bit
+ * the results of one stream).  0 (default) = automatic: two streams when each half is at least one full round of
+ * workgroups; 1 = one stream; 2 = two streams whenever the fused step runs.                                           */
+int glh_set_track_streams(glh_ctx* ctx, int n);
 
 /* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +
  * re-evolving gather + moments in one launch, evolved state never round-trips through HBM)
@@ -306,6 +312,8 @@ int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
  * arithmetic, bit 1: the general code (gridded surfaces, every motion model), bit 2: the compile-time contract of long
  * device-RNG runs; flags == 5 is the common instantiation bench.py times).  Zeros before any.                    */
 int glh_debug_last_variant(glh_ctx* ctx, int32_t* variant);
+/* Streams the last glh_track call ran on (1 or 2). */
+int glh_debug_last_track_streams(glh_ctx* ctx, int* n);
 
 /* ---- results --------------------------------------------------------------------------- */
 /* means/sigmas for frames [frame0, frame0 + n_frames): out [n_frames][P][12].              */
@@ -345,6 +353,9 @@ const char* glh_stage_name(int stage);
 int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /* [stages] */);
 /* Duration (ms) of every timed launch of `stage` since the last reset, in launch order: up to `cap` values
  * into ms, *n = how many there are (the first frames after the wide prior run longer than the steady state). */
+/* GPU time (ms) a stage spans since the last reset: start of its first timed launch to the end of its last, on whichever
+ * stream (the launches of glh_track's two streams overlap, so their durations do not add up to the time they take).  */
+int glh_profile_get_span(glh_ctx* ctx, int stage, double* ms);
 int glh_profile_get_launches(glh_ctx* ctx, int stage, double* ms, int cap, int* n);
 /* Measured device-copy ceiling of this GPU: `iters` device-to-device copies of `bytes`
  * bytes on the context's stream between two HIP events; *gbps = bytes read + bytes written per second / 1e9. */
