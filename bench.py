@@ -76,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="frame updates per library call: 0 = all the timed steps in one glh_track call (the frame loop "
                          "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
-    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2),
+    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="streams of glh_track's frame loop (glh_set_track_streams): 0 = the library's choice (two for "
                          "batches of at least two rounds of workgroups per half), 1 = one launch per frame, 2 = two "
                          "half-batches on two streams")

@@ -1561,53 +1561,101 @@ __host__ __device__ __forceinline__ size_t ssd_lds_bytes(int tw, int th) {
 // One strip of SSD_W outputs: template rows i = g, g + G, ... of the (s - t)^2 sum; float32
 // FMA along a template row, float64 across rows.  S row stride ld (floats, multiple of 4,
 // readable up to column cc + twp + 3), T [th][twp] zero padded.
+//
+// Round 4: written on explicit float pairs.  The arithmetic is the one of rounds 1-3 -- per output and tap
+// d = s - t, acc = fma(d, d, acc), taps in order j = 0 .. tw - 1 (oracle/ssd.c: oracle_ssd_f32_rows) -- but the
+// instructions around it are chosen here instead of left to the vectoriser: (1) the template value of an odd tap is
+// the HIGH half of its register pair and is selected by the packed subtract itself (op_sel), where the compiler built
+// a (t, t) pair with a move per odd tap; (2) the partial last block of a row (tw = 31: its fourth) ends at a uniform
+// branch after its last tap, where the compiler computed all eight taps and kept or dropped each with four selects;
+// (3) two blocks per loop iteration, so the sliding window changes registers instead of being moved.  Per 8 taps x 4
+// outputs: 32 packed operations + 16 others before, + 9 now; the partial block 75 -> ~40.
+typedef float glh_f2 __attribute__((ext_vector_type(2)));
+// (w.x - t.x, w.y - t.x) and (w.x - t.y, w.y - t.y): one v_pk_add_f32 each, IEEE subtraction
+__device__ __forceinline__ glh_f2 ssd_sub_lo(glh_f2 w, glh_f2 t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  glh_f2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(w), "v"(t));
+  return d;
+#else
+  return glh_f2{w.x - t.x, w.y - t.x};  // (the host pass only parses this)
+#endif
+}
+__device__ __forceinline__ glh_f2 ssd_sub_hi(glh_f2 w, glh_f2 t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  glh_f2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(w), "v"(t));
+  return d;
+#else
+  return glh_f2{w.x - t.y, w.y - t.y};
+#endif
+}
+
+// Taps 0 .. NV-1 (NV = 8: a whole block; otherwise `nv` of them, uniform) of one 8-tap block on the four outputs.
+// W[0..5]: the window s[0..11] as aligned pairs; odd[0]: (s[1], s[2]) (carried over from the previous block);
+// T[0..3]: the block's template values.  Leaves odd[0] = (s[9], s[10]) for the next block.
+template <bool WHOLE>
+__device__ __forceinline__ void ssd_block8(const glh_f2* W, const glh_f2* T, glh_f2& odd0, glh_f2& a01, glh_f2& a23, int nv) {
+  glh_f2 od[5];
+  od[0] = odd0;
+#pragma unroll
+  for (int m = 1; m < 5; ++m) od[m] = glh_f2{W[m].y, W[m + 1].x};  // (s[2m + 1], s[2m + 2])
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (!WHOLE && j >= nv) break;  // uniform: a scalar branch (the inline assembly below is not speculated)
+    const glh_f2 w01 = (j & 1) ? od[j >> 1] : W[j >> 1];
+    const glh_f2 w23 = (j & 1) ? od[(j >> 1) + 1] : W[(j >> 1) + 1];
+    const glh_f2 d01 = (j & 1) ? ssd_sub_hi(w01, T[j >> 1]) : ssd_sub_lo(w01, T[j >> 1]);
+    const glh_f2 d23 = (j & 1) ? ssd_sub_hi(w23, T[j >> 1]) : ssd_sub_lo(w23, T[j >> 1]);
+    a01 = __builtin_elementwise_fma(d01, d01, a01);
+    a23 = __builtin_elementwise_fma(d23, d23, a23);
+  }
+  odd0 = od[4];
+}
+
 __device__ __forceinline__ void ssd_strip_rows(const float* S, int ld, const float* T, int tw, int th, int twp,
                                                int rr, int cc, int g, int G, double* acc64) {
+  static_assert(SSD_W == 4, "the strip code is written for four outputs");
   for (int i = g; i < th; i += G) {
     const float* rowp = S + (rr + i) * ld + cc;
     const float* trow = T + i * twp;
-    float acc[SSD_W];
-#pragma unroll
-    for (int k = 0; k < SSD_W; ++k) acc[k] = 0.0f;
-    float w[12];
+    glh_f2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+    glh_f2 p0, p1;  // s[0..3] of the next block
     {
-      float4 a0 = *reinterpret_cast<const float4*>(rowp);
-      w[0] = a0.x; w[1] = a0.y; w[2] = a0.z; w[3] = a0.w;
+      const float4 a0 = *reinterpret_cast<const float4*>(rowp);
+      p0 = glh_f2{a0.x, a0.y};
+      p1 = glh_f2{a0.z, a0.w};
     }
-    for (int jj = 0; jj < tw; jj += 8) {
-      float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 4);
-      float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 8);
-      w[4] = b0.x; w[5] = b0.y; w[6] = b0.z; w[7] = b0.w;
-      w[8] = b1.x; w[9] = b1.y; w[10] = b1.z; w[11] = b1.w;
-      float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
-      float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
-      const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-      if (jj + 8 <= tw) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-          for (int k = 0; k < SSD_W; ++k) {
-            float d = w[j + k] - tv[j];
-            acc[k] = fmaf(d, d, acc[k]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (jj + j < tw) {
-#pragma unroll
-            for (int k = 0; k < SSD_W; ++k) {
-              float d = w[j + k] - tv[j];
-              acc[k] = fmaf(d, d, acc[k]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = w[k + 8];
+    glh_f2 odd0 = glh_f2{p0.y, p1.x};
+    // one 8-tap block at taps jj ..: `nv` < 8 of them when !WHOLE
+    auto block = [&](int jj, auto whole_tag, int nv) {
+      constexpr bool WHOLE = decltype(whole_tag)::value;
+      glh_f2 W[6], Tv[4];
+      const float4 b0 = *reinterpret_cast<const float4*>(rowp + jj + 4);
+      const float4 b1 = *reinterpret_cast<const float4*>(rowp + jj + 8);
+      const float4 t0 = *reinterpret_cast<const float4*>(trow + jj);
+      const float4 t1 = *reinterpret_cast<const float4*>(trow + jj + 4);
+      W[0] = p0; W[1] = p1;
+      W[2] = glh_f2{b0.x, b0.y}; W[3] = glh_f2{b0.z, b0.w}; W[4] = glh_f2{b1.x, b1.y}; W[5] = glh_f2{b1.z, b1.w};
+      Tv[0] = glh_f2{t0.x, t0.y}; Tv[1] = glh_f2{t0.z, t0.w}; Tv[2] = glh_f2{t1.x, t1.y}; Tv[3] = glh_f2{t1.z, t1.w};
+      ssd_block8<WHOLE>(W, Tv, odd0, a01, a23, nv);
+      p0 = W[4];
+      p1 = W[5];
+    };
+    int jj = 0;
+    for (; jj + 16 <= tw; jj += 16) {  // two blocks per iteration: the window changes registers, not places
+      block(jj, std::true_type{}, 8);
+      block(jj + 8, std::true_type{}, 8);
     }
-#pragma unroll
-    for (int k = 0; k < SSD_W; ++k) acc64[k] += (double)acc[k];
+    if (jj + 8 <= tw) {  // uniform
+      block(jj, std::true_type{}, 8);
+      jj += 8;
+    }
+    if (jj < tw) block(jj, std::false_type{}, tw - jj);  // uniform
+    acc64[0] += (double)a01.x;
+    acc64[1] += (double)a01.y;
+    acc64[2] += (double)a23.x;
+    acc64[3] += (double)a23.y;
   }
 }
 

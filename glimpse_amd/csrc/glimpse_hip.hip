@@ -176,8 +176,8 @@ struct glh_ctx {
   // glh_track on two streams (glh_set_track_streams): 0 = automatic (two when the batch is at least two rounds of
   // workgroups per half), 1 = always one, 2 = two whenever the fused step runs
   int track_streams = 0;
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t extra_streams[3] = {nullptr, nullptr, nullptr};  // streams 2 .. 4 of glh_track
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int last_track_streams = 1;  // streams the last glh_track used
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
@@ -344,9 +344,11 @@ extern "C" int glh_destroy(glh_ctx* c) {
     if (c->stage_done[k]) (void)hipEventDestroy(c->stage_done[k]);
   }
   if (c->upload_done) (void)hipEventDestroy(c->upload_done);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  for (int q = 0; q < 3; ++q) {
+    if (c->extra_streams[q]) (void)hipStreamDestroy(c->extra_streams[q]);
+    if (c->ev_join[q]) (void)hipEventDestroy(c->ev_join[q]);
+  }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GLH_OK;
@@ -1663,11 +1665,15 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
   int r2_bytes = 0;
   const bool fused_ok = c->fused && !c->have_active && !c->keep_sse && !c->have_extra && fused_plan(c, &r2_bytes);
   const int slots = 256 * (c->N > 10 * PT_BLK ? 1 : 2);  // workgroups the chip holds at once
-  bool two = fused_ok && !c->track_covariances && c->P >= 2 &&
-             (c->track_streams == 2 || (c->track_streams == 0 && c->P >= 2 * slots));
-  if (getenv("GLH_TRACK_STREAMS")) two = two && atoi(getenv("GLH_TRACK_STREAMS")) != 1;
-  c->last_track_streams = two ? 2 : 1;
-  if (!two) {
+  int ns = 1;
+  if (fused_ok && !c->track_covariances) {
+    if (c->track_streams >= 2) ns = c->track_streams;
+    else if (c->track_streams == 0 && c->P >= 2 * slots) ns = 2;
+    if (const char* e = getenv("GLH_TRACK_STREAMS")) ns = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : ns;
+    ns = std::min(ns, c->P);
+  }
+  c->last_track_streams = ns;
+  if (ns == 1) {
     for (int k = 0; k < n_frames; ++k) {
       CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
       if (c->track_covariances) CHK(glh_record_covariances(c, frames[k]));
@@ -1675,34 +1681,38 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
     return GLH_OK;
   }
   HIPCHK(hipSetDevice(c->cfg.device_id));
-  if (!c->stream2) {
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  hipStream_t on[4] = {c->stream, nullptr, nullptr, nullptr};
+  for (int q = 1; q < ns; ++q) {
+    if (!c->extra_streams[q - 1]) {
+      HIPCHK(hipStreamCreateWithFlags(&c->extra_streams[q - 1], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_join[q - 1], hipEventDisableTiming));
+    }
+    on[q] = c->extra_streams[q - 1];
   }
-  // the second stream starts behind everything enqueued so far, and the context's stream ends behind the second
+  // the other streams start behind everything enqueued so far, and the context's stream ends behind them
   HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-  HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  const int half = (c->P + 1) / 2;
+  for (int q = 1; q < ns; ++q) HIPCHK(hipStreamWaitEvent(on[q], c->ev_fork, 0));
   int rc = GLH_OK;
   for (int k = 0; k < n_frames && rc == GLH_OK; ++k) {
     rc = glh_set_frame(c, frames[k]);
-    if (rc == GLH_OK)
-      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, 0, half,
-                      c->stream, false);
-    if (rc == GLH_OK)
-      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, half,
-                      c->P - half, c->stream2, true);
+    for (int q = 0; q < ns && rc == GLH_OK; ++q) {
+      const int p0 = (int)((int64_t)c->P * q / ns), p1 = (int)((int64_t)c->P * (q + 1) / ns);
+      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, p0, p1 - p0,
+                      on[q], q == ns - 1);
+    }
   }
-  (void)hipEventRecord(c->ev_join, c->stream2);
-  (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+  for (int q = 1; q < ns; ++q) {
+    (void)hipEventRecord(c->ev_join[q - 1], on[q]);
+    (void)hipStreamWaitEvent(c->stream, c->ev_join[q - 1], 0);
+  }
   return rc;
 }
 
 // Streams of glh_track's frame loop: 0 automatic, 1 one stream, 2 two streams whenever the fused step runs.
 extern "C" int glh_set_track_streams(glh_ctx* c, int n) {
   if (!c) return fail(GLH_E_INVALID, "null context");
-  if (n < 0 || n > 2) return fail(GLH_E_INVALID, "streams must be 0 (automatic), 1 or 2");
+  if (n < 0 || n > 4) return fail(GLH_E_INVALID, "streams must be 0 (automatic) or 1 .. 4");
   c->track_streams = n;
   return GLH_OK;
 }

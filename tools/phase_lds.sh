@@ -11,12 +11,13 @@ for k in 16 17 19 2 3 4 5 7 8 full; do
     -d gpurun_out/pl_$k -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-api --no-secondary --burn-in 6 --steps 4 --warmup 2 "$@" > gpurun_out/pl_$k.log 2>&1
 done
 python3 - <<'PY'
-import csv, glob
+import csv, glob, json
 from collections import defaultdict
 ORDER = ["16", "17", "19", "2", "3", "4", "5", "7", "8", "full"]
 WHAT = {"16": "prologue", "17": "A particle loop", "19": "A reductions + box", "2": "B tile prep", "3": "B SSD", "4": "B fit", "5": "C sampling",
         "7": "D", "8": "E gather", "full": "F"}
 prev = defaultdict(float)
+out = []
 print(f"{'cut':>5} {'LDS instr':>10} {'idx active':>11} {'bank confl':>11} {'share':>6} {'addr confl':>11}  phase")
 for k in ORDER:
     vals = defaultdict(list)
@@ -31,5 +32,13 @@ for k in ORDER:
     act = d.get("SQ_LDS_IDX_ACTIVE", 0.0)
     print(f"{k:>5} {d.get('SQ_INSTS_LDS', 0)/1e6:10.2f} {act/1e6:11.2f} {d.get('SQ_LDS_BANK_CONFLICT', 0)/1e6:11.2f} "
           f"{(d.get('SQ_LDS_BANK_CONFLICT', 0)/act if act else 0):6.2f} {d.get('SQ_LDS_ADDR_CONFLICT', 0)/1e6:11.2f}  {WHAT[k]}")
+    out.append({"cut": k, "phase": WHAT[k], "lds_instructions": d.get("SQ_INSTS_LDS", 0), "idx_active_cycles": act,
+                "bank_conflict_cycles": d.get("SQ_LDS_BANK_CONFLICT", 0), "addr_conflict_cycles": d.get("SQ_LDS_ADDR_CONFLICT", 0),
+                "bank_conflict_share": (d.get("SQ_LDS_BANK_CONFLICT", 0) / act if act else 0)})
     prev = defaultdict(float, cur)
+tot_a = sum(o["idx_active_cycles"] for o in out); tot_c = sum(o["bank_conflict_cycles"] for o in out)
+json.dump({"unit": "cycles / instructions per launch (last k_point_step launch of a short steady-state sequence, cut at every "
+                   "phase stamp: differences of successive cuts), rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ...",
+           "total_idx_active_cycles": tot_a, "total_bank_conflict_cycles": tot_c,
+           "bank_conflict_share": tot_c / tot_a if tot_a else 0, "phases": out}, open("gpurun_out/phase_lds.json", "w"), indent=1)
 PY
