@@ -1645,6 +1645,9 @@ __device__ __forceinline__ void ssd_strip_rows(const float* S, int ld, const flo
     int jj = 0;
     for (; jj + 16 <= tw; jj += 16) {  // two blocks per iteration: the window changes registers, not places
       block(jj, std::true_type{}, 8);
+      // (the second block's loads stay behind the first block's arithmetic: hoisted above it they cost 16 more live
+      // registers, which the 1 024-thread and the two-observer instantiations do not have)
+      asm volatile("" ::: "memory");
       block(jj + 8, std::true_type{}, 8);
     }
     if (jj + 8 <= tw) {  // uniform
