@@ -1615,7 +1615,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) K[k] = s_K[k];
   double s0 = 0.0, s1[6] = {0, 0, 0, 0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-  constexpr int GU = 2;  // records in flight per thread
+#ifndef GLH_PT_GU
+#define GLH_PT_GU 2
+#endif
+  constexpr int GU = GLH_PT_GU;  // records in flight per thread
   // The record index of a survivor, uin[source], is a memory load the record loads depend on: the words of the NEXT
   // iteration (source | copies from the rank table, record index from memory) are fetched while this iteration's
   // records are evolved (C4, whose 16-wave workgroup has its CU to itself: -0.8 %; C3 / C5: -0.2 .. -0.4 %).
@@ -1632,41 +1635,38 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   fetch_next(tid);
   for (int h0 = tid; h0 < U; h0 += GU * TB) {
     int lo[GU], cnt[GU];
-    double x[GU][6], w[GU];
-    {
-      double2 v[GU][3];
-#pragma unroll
-      for (int g = 0; g < GU; ++g) {
-        lo[g] = (int)(sc_n[g] & 0xffffu);
-        cnt[g] = (int)(sc_n[g] >> 16);
-        const double2* src = Pin2 + (size_t)rec_n[g] * rec_stride;
-        v[g][0] = src[0]; v[g][1] = src[chunk_stride]; v[g][2] = src[2 * chunk_stride];
-      }
-      fetch_next(h0 + GU * TB);  // (beyond U: slot 0 of the tables, a valid address; never used)
-#pragma unroll
-      for (int g = 0; g < GU; ++g) {
-        x[g][0] = v[g][0].x; x[g][1] = v[g][0].y; x[g][2] = v[g][1].x; x[g][3] = v[g][1].y; x[g][4] = v[g][2].x; x[g][5] = v[g][2].y;
-        evolve_loaded(lo[g], x[g]);
-        w[g] = c[lo[g]];
-      }
-    }
+    double2 v[GU][3];
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
+      lo[g] = (int)(sc_n[g] & 0xffffu);
+      cnt[g] = (int)(sc_n[g] >> 16);
+      const double2* src = Pin2 + (size_t)rec_n[g] * rec_stride;
+      v[g][0] = src[0]; v[g][1] = src[chunk_stride]; v[g][2] = src[2 * chunk_stride];
+    }
+    fetch_next(h0 + GU * TB);  // (beyond U: slot 0 of the tables, a valid address; never used)
+    // the records are evolved, stored and summed ONE AFTER ANOTHER (compiler barrier): only the loads overlap, the
+    // Philox / Box-Muller temporaries of one record at a time are live
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      if (g) asm volatile("" ::: "memory");
+      double x[6] = {v[g][0].x, v[g][0].y, v[g][1].x, v[g][1].y, v[g][2].x, v[g][2].y};
+      evolve_loaded(lo[g], x);
+      const double w = c[lo[g]];
       const int h = h0 + g * TB;
       if (h < U) {
         typedef double pt_d2 __attribute__((ext_vector_type(2)));
         pt_d2* dst = reinterpret_cast<pt_d2*>(Pout) + h;  // planar: chunk c of record h at c N + h
         // streaming stores: the new state is not read again before the next launch, and should not displace
         // the pre-evolve records that the other workgroups' gathers are about to re-read from L2 / Infinity Cache
-        __builtin_nontemporal_store(pt_d2{x[g][0], x[g][1]}, dst);
-        __builtin_nontemporal_store(pt_d2{x[g][2], x[g][3]}, dst + N);
-        __builtin_nontemporal_store(pt_d2{x[g][4], x[g][5]}, dst + 2 * N);
-        __builtin_nontemporal_store(w[g], Wout + h);
-        const double cw = (double)cnt[g] * w[g];  // the record stands for cnt identical particles
+        __builtin_nontemporal_store(pt_d2{x[0], x[1]}, dst);
+        __builtin_nontemporal_store(pt_d2{x[2], x[3]}, dst + N);
+        __builtin_nontemporal_store(pt_d2{x[4], x[5]}, dst + 2 * N);
+        __builtin_nontemporal_store(w, Wout + h);
+        const double cw = (double)cnt[g] * w;  // the record stands for cnt identical particles
         s0 += cw;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          double d = x[g][k] - K[k];
+          double d = x[k] - K[k];
           double wd = cw * d;
           if constexpr (FAST) {
             s1[k] = glh_fma(cw, d, s1[k]);

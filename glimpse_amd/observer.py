@@ -56,14 +56,29 @@ class Observer:
         return self.images[img].read(box=box, cache=self.cache)
 
     def sample_tile(self, uv, tile, box, grid=False, **kwargs):
-        """observer.py:178-214 for grid=False, kx=ky=3: bicubic spline sampling on the GPU."""
-        if grid or kwargs.get("kx", 3) != 3 or kwargs.get("ky", 3) != 3:
-            raise NotImplementedError("only pointwise bicubic sampling (kx=ky=3) is on the tracking path")
-        values, outside = _lib.stage_sample(np.asarray(tile, dtype=np.float32), np.asarray(box, dtype=float),
-                                            np.asarray(uv, dtype=float))
+        """observer.py:178-214: the interpolating `RectBivariateSpline` of the tile sampled on the GPU -- at points
+        (n, [u, v]), or with `grid=True` at every pair of the coordinate vectors `uv = (u values, v values)`, returned
+        like scipy returns it, (len(v), len(u)).  `kx` / `ky` in 1..5 (the spline's degree along the rows / columns);
+        a smoothing factor or a bounding box (another spline than the interpolating one) is not served."""
+        extra = set(kwargs) - {"kx", "ky"}
+        if extra and not (kwargs.get("s", 0) == 0 and kwargs.get("bbox", [None] * 4) == [None] * 4 and extra <= {"s", "bbox"}):
+            raise NotImplementedError(f"RectBivariateSpline arguments {sorted(extra)}: only the interpolating spline "
+                                      "(s = 0, default bbox) is on the tracking path")
+        kx, ky = int(kwargs.get("kx", 3)), int(kwargs.get("ky", 3))
+        if not (1 <= kx <= 5 and 1 <= ky <= 5):
+            raise ValueError("kx, ky must be in 1..5")  # (what FITPACK accepts)
+        if grid:
+            u, v = (np.asarray(a, dtype=float).ravel() for a in uv)
+            if (np.diff(u) < 0).any() or (np.diff(v) < 0).any():
+                raise ValueError("x and y must be sorted to increasing order")  # (scipy's own check for grid=True)
+            points = np.stack(np.meshgrid(u, v), axis=-1).reshape(-1, 2)  # rows: v, columns: u
+        else:
+            points = np.asarray(uv, dtype=float)
+        values, outside = _lib.stage_sample(np.asarray(tile, dtype=np.float32), np.asarray(box, dtype=float), points,
+                                            orders=None if (kx, ky) == (3, 3) else (kx, ky))
         if outside.any():
             raise ValueError("Some sampling points are outside box")
-        return values
+        return values.reshape(len(v), len(u)) if grid else values
 
     def shift_tile(self, tile, duv, **kwargs):
         """observer.py:146-176: resample a tile at pixel centres moved by (du, dv), each at most half a pixel

@@ -827,3 +827,30 @@ def test_reference_base_motion_model(golden):
     np.testing.assert_allclose(tracks.sigmas, g["sigmas"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(tracks.particles, g["particles"], rtol=RTOL, atol=1e-8)
     np.testing.assert_allclose(tracks.weights, g["weights"], rtol=RTOL, atol=1e-290)
+
+
+def test_sample_tile_on_a_grid_and_with_other_orders(golden):
+    """Observer.sample_tile(grid=True) and its kx / ky arguments (observer.py:178-214 passes them to
+    scipy.interpolate.RectBivariateSpline, which is what this test calls directly)."""
+    import scipy.interpolate
+
+    obs = observers_from(golden("g8_c1.npz"))[0]
+    rng = np.random.default_rng(11)
+    tile = rng.normal(size=(13, 17)).astype(np.float32)
+    box = np.array([100.0, 40.0, 117.0, 53.0])
+    cu, cv = np.arange(box[0] + 0.5, box[2]), np.arange(box[1] + 0.5, box[3])
+    u, v = np.sort(rng.uniform(box[0], box[2], 9)), np.sort(rng.uniform(box[1], box[3], 7))
+    for kw in ({}, {"kx": 1, "ky": 1}, {"kx": 2, "ky": 4}, {"kx": 5, "ky": 5}, {"s": 0}):
+        f = scipy.interpolate.RectBivariateSpline(cv, cu, tile.astype(float), **kw)
+        got = obs.sample_tile((u, v), tile, box, grid=True, **kw)
+        assert got.shape == (7, 9)
+        np.testing.assert_allclose(got, f(v, u, grid=True), rtol=0, atol=5e-12)
+        pts = np.column_stack((rng.uniform(box[0], box[2], 25), rng.uniform(box[1], box[3], 25)))
+        np.testing.assert_allclose(obs.sample_tile(pts, tile, box, **kw), f(pts[:, 1], pts[:, 0], grid=False), rtol=0,
+                                   atol=5e-12)
+    with pytest.raises(ValueError, match="outside box"):
+        obs.sample_tile((u + 100.0, v), tile, box, grid=True)
+    with pytest.raises(ValueError, match="sorted"):
+        obs.sample_tile((u[::-1], v), tile, box, grid=True)
+    with pytest.raises(NotImplementedError):
+        obs.sample_tile((u, v), tile, box, grid=True, s=2.0)
