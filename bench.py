@@ -662,7 +662,9 @@ def secondary_legs(args, device, T, rendered, seed):
             # TangentCartesianMotion, the model of real glacier runs (motion.py:339-430): the general instantiation
             ("C3_tangent", "C3", None, "fast", T, "C3", 1, 8, "tangent_cartesian"),
             ("C3_rgb", "C3", None, "fast", T, "C3_rgb", 3, 8, "cartesian"),
-            ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16, "cartesian")]
+            ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16, "cartesian"),
+            # float32 frames (an orthophoto / reflectance observer): the C3 frames scaled to [0, 1]
+            ("C3_f32", "C3", None, "fast", T, "C3", 1, 32, "cartesian")]
     for key, name, points, math, n_frames, frames_of, channels, bits, motion in plan:
         frames = rendered.get(frames_of)
         if frames is None:
@@ -670,6 +672,8 @@ def secondary_legs(args, device, T, rendered, seed):
         try:
             wl = workloads.Workload(name, n_frames=T, n_points=points, shard=0, seed=0)
             wl.channels, wl.bits = channels, bits
+            if bits == 32:
+                frames = [[np.asarray(f, dtype=np.float32) * np.float32(1.0 / 255.0) for f in fo] for fo in frames]
             # (uint16 frames take the fused step while a tile's pixel count fits a 16-bit key: workspaces up to 255 px)
             dim = min(args.max_search_dim, 255) if bits == 16 else args.max_search_dim
             with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=dim,

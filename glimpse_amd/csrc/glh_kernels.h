@@ -68,6 +68,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // Sum over the block; result valid in every thread.  `red` holds >= NWAVES doubles.
+template <int NT = BLK>
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
   __syncthreads();
@@ -75,7 +76,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   __syncthreads();
   double t = red[0];
 #pragma unroll
-  for (int w = 1; w < NWAVES; ++w) t += red[w];
+  for (int w = 1; w < NT / WAVE; ++w) t += red[w];
   return t;
 }
 
@@ -759,6 +760,7 @@ __device__ __forceinline__ int pixel_key16(const uint8_t* frame, int width, int 
 }
 
 // exclusive prefix of `v` over the block (all threads call); `tmp` holds NWAVES words; *total = block sum
+template <int NT = BLK>
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* tmp, uint32_t* total) {
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   uint32_t incl = v;
@@ -771,12 +773,30 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* tm
   if (lane == WAVE - 1) tmp[tid / WAVE] = incl;
   __syncthreads();
   uint32_t base = 0, all = 0;
-  for (int w = 0; w < NWAVES; ++w) {
+  for (int w = 0; w < NT / WAVE; ++w) {
     if (w < tid / WAVE) base += tmp[w];
     all += tmp[w];
   }
   *total = all;
   return base + incl - v;
+}
+
+// The same median by bisection over the key range [0, key_max]: no private array (median_window32 below gathers the
+// window into 49 ints with dynamic indices -- scratch memory, which the fused kernel must not reserve)
+__device__ __forceinline__ int median_window32_bisect(const uint32_t* keys, int ld, int w, int h, int r, int c, int rx, int ry,
+                                                      int key_max) {
+  const int need = ((2 * rx + 1) * (2 * ry + 1) + 1) / 2;
+  int lo = 0, hi = key_max;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int cnt = 0;
+    for (int dr = -ry; dr <= ry; ++dr) {
+      const uint32_t* row = keys + (size_t)reflect_index(r + dr, h) * ld;
+      for (int dc = -rx; dc <= rx; ++dc) cnt += (int)row[reflect_index(c + dc, w)] <= mid;
+    }
+    if (cnt >= need) hi = mid; else lo = mid + 1;
+  }
+  return lo;
 }
 
 // median of the window around (r, c) of a w x h tile of 32-bit keys (row stride ld, tile row `row0` first)
@@ -899,10 +919,12 @@ __device__ __forceinline__ float np_pairwise_leaf_f32(const float* a, int n) {  
   for (; i < n; ++i) res += a[i];
   return res;
 }
-__device__ float np_pairwise_f32(const float* a, int n) {
-  // the recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2) on an explicit stack (depth <= log2(n / 128) + 1)
-  int off[24], len[24], state[24];
-  float left[24];
+__device__ __forceinline__ float np_pairwise_f32(const float* a, int n) {
+  // the recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2) on an explicit stack (depth <= log2(n / 128) + 1).
+  // ONE thread of the block runs this (normalize_box_float): the stack lives in LDS -- as private arrays with dynamic
+  // indices it was 400 bytes of scratch memory, which every kernel that can reach this code then reserves
+  __shared__ int off[24], len[24], state[24];
+  __shared__ float left[24];
   int sp = 0;
   off[0] = 0; len[0] = n; state[0] = 0; left[0] = 0.0f;
   float ret = 0.0f;
@@ -932,7 +954,7 @@ __device__ float np_pairwise_f32(const float* a, int n) {
 }
 // ... over a whole contiguous array: the reduction hands the inner loop chunks of 8192 items (np.getbufsize()) and adds
 // their sums to the running total in order (oracle/resample.py: numpy_pairwise_sum states the same for float64)
-__device__ float np_sum_flat_f32(const float* a, int n) {
+__device__ __forceinline__ float np_sum_flat_f32(const float* a, int n) {
   float acc = 0.0f;
   for (int s0 = 0; s0 < n; s0 += 8192) acc += np_pairwise_f32(a + s0, min(8192, n - s0));
   return acc;
@@ -943,13 +965,14 @@ __device__ float np_sum_flat_f32(const float* a, int n) {
 // with NumPy's own summation order, on thread 0 -- a one-channel tile is a strided view of the frame, which NumPy sums
 // row by row (out += pairwise(row)); the channel mean of a three-channel tile is a new contiguous array, summed flat;
 // (a - mean)^2 is contiguous either way.  `tmp`: 2 n floats of scratch that may overlap y (not each other).
+template <int NT = BLK>
 __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int width, int channels, int bits, const int* box,
                                                     double* y, float* tmp_g, float* tmp_x2, double* red, bool* const_tile) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   if (bits == 32) {
     __shared__ float s_mean, s_inv;
-    for (int idx = tid; idx < n; idx += BLK) {
+    for (int idx = tid; idx < n; idx += NT) {
       const int r = idx / w, c = idx - r * w;
       tmp_g[idx] = (float)pixel_float(frame, width, channels, 32, box[1] + r, box[0] + c);
     }
@@ -964,7 +987,7 @@ __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int wi
     }
     __syncthreads();
     const float mean = s_mean;
-    for (int idx = tid; idx < n; idx += BLK) {
+    for (int idx = tid; idx < n; idx += NT) {
       const float d = tmp_g[idx] - mean;
       tmp_x2[idx] = d * d;
     }
@@ -977,27 +1000,27 @@ __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int wi
     __syncthreads();
     const float inv = s_inv;
     // (y may overlap tmp_x2: every thread reads its g before anybody writes y -- g and y do not overlap)
-    for (int idx = tid; idx < n; idx += BLK) y[idx] = (double)((tmp_g[idx] - mean) * inv);
+    for (int idx = tid; idx < n; idx += NT) y[idx] = (double)((tmp_g[idx] - mean) * inv);
     __syncthreads();
     return;
   }
   double sx = 0.0;
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     const int r = idx / w, c = idx - r * w;
     const double x = pixel_float(frame, width, channels, 64, box[1] + r, box[0] + c);
     y[idx] = x;
     sx += x;
   }
-  const double mean = block_sum(sx, red) / (double)n;
+  const double mean = block_sum<NT>(sx, red) / (double)n;
   double sq = 0.0;
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     const double d = y[idx] - mean;
     sq += d * d;
   }
-  const double var = block_sum(sq, red) / (double)n;
+  const double var = block_sum<NT>(sq, red) / (double)n;
   const double inv_std = 1.0 / sqrt(var);
   if (tid == 0 && const_tile) *const_tile = !(var > 0.0);
-  for (int idx = tid; idx < n; idx += BLK) y[idx] = (y[idx] - mean) * inv_std;
+  for (int idx = tid; idx < n; idx += NT) y[idx] = (y[idx] - mean) * inv_std;
   __syncthreads();
 }
 
@@ -1067,16 +1090,19 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, int channels
 // into bucket order (over the matched-value array, which is written afterwards), a pixel's count = its bucket's offset
 // + the members of its bucket at or below it.  (Rounds 2-3a counted over the whole tile for
 // every pixel: O(n^2 / BLK) per thread.)
-__device__ void search_tile_from_values(int w, int h, const double* hist_v, const double* hist_q, int hist_n, double* work,
+// NT: threads of the block; NBK: buckets (>= NT, a multiple of it; `tab` holds NBK words); `out_ld`: row stride of the
+// search tile (0: dense, w) -- the fused kernel's tiles carry padding columns, which are zeroed.
+template <int NT = BLK, int NBK = NBINS>
+__device__ __forceinline__ void search_tile_from_values(int w, int h, const double* hist_v, const double* hist_q, int hist_n, double* work,
                                         float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
-                                        unsigned char* lds, int lds_bytes) {
-  __shared__ double s_mm[NWAVES][2];
+                                        unsigned char* lds, int lds_bytes, int out_ld = 0) {
+  __shared__ double s_mm[NT / WAVE][2];
   const int tid = threadIdx.x;
   const int n = w * h;
   if (2 * hist_n * (int)sizeof(double) <= lds_bytes) {
     // the template CDF into LDS (np.interp searches it twice per pixel)
     double* cdf_lds = reinterpret_cast<double*>(lds);
-    for (int k = tid; k < hist_n; k += BLK) {
+    for (int k = tid; k < hist_n; k += NT) {
       cdf_lds[k] = hist_q[k];
       cdf_lds[hist_n + k] = hist_v[k];
     }
@@ -1087,11 +1113,10 @@ __device__ void search_tile_from_values(int w, int h, const double* hist_v, cons
   double* matched = work + n;
   double* sorted = matched;                          // values in bucket order, until `matched` is made
   uint32_t* leq = reinterpret_cast<uint32_t*>(out);  // counts, until `out` is made
-  constexpr int NBK = NBINS;
-  static_assert(NBK % BLK == 0, "whole buckets per thread");
-  for (int b = tid; b < NBK; b += BLK) tab[b] = 0;
+  static_assert(NBK % NT == 0, "whole buckets per thread");
+  for (int b = tid; b < NBK; b += NT) tab[b] = 0;
   double xmin = INFINITY, xmax = -INFINITY;
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     const double x = work[idx];
     xmin = fmin(xmin, x);
     xmax = fmax(xmax, x);
@@ -1105,7 +1130,7 @@ __device__ void search_tile_from_values(int w, int h, const double* hist_v, cons
   __syncthreads();
   xmin = s_mm[0][0];
   xmax = s_mm[0][1];
-  for (int wv = 1; wv < NWAVES; ++wv) {
+  for (int wv = 1; wv < NT / WAVE; ++wv) {
     xmin = fmin(xmin, s_mm[wv][0]);
     xmax = fmax(xmax, s_mm[wv][1]);
   }
@@ -1114,29 +1139,29 @@ __device__ void search_tile_from_values(int w, int h, const double* hist_v, cons
   // normalised tile in half a dozen buckets)
   const double scale = xmax > xmin ? (double)(NBK - 1) / (xmax - xmin) : 0.0;
   auto bucket = [&](double x) -> int { return min(NBK - 1, max(0, (int)((x - xmin) * scale))); };
-  for (int idx = tid; idx < n; idx += BLK) atomicAdd(&tab[bucket(work[idx])], 1u);
+  for (int idx = tid; idx < n; idx += NT) atomicAdd(&tab[bucket(work[idx])], 1u);
   __syncthreads();
   {
-    constexpr int PER = NBK / BLK;
+    constexpr int PER = NBK / NT;
     uint32_t cnt[PER], local = 0;
     for (int k = 0; k < PER; ++k) {
       cnt[k] = tab[PER * tid + k];
       local += cnt[k];
     }
     uint32_t total;
-    uint32_t run = block_excl_scan_u32(local, scan_tmp, &total);  // (barriers inside)
+    uint32_t run = block_excl_scan_u32<NT>(local, scan_tmp, &total);  // (barriers inside)
     for (int k = 0; k < PER; ++k) {
       tab[PER * tid + k] = run;
       run += cnt[k];
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     const double x = work[idx];
     sorted[atomicAdd(&tab[bucket(x)], 1u)] = x;
   }
   __syncthreads();  // (tab[b] is now the END of bucket b; the scattered values are visible to the block)
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     const double x = work[idx];
     const int b = bucket(x);
     const uint32_t lo = b ? tab[b - 1] : 0u, hi = tab[b];
@@ -1150,29 +1175,40 @@ __device__ void search_tile_from_values(int w, int h, const double* hist_v, cons
   // the count, so the median of the matched window is the matched value of the median count (integers in registers for
   // the 5 x 5 window, where a window of doubles lived in scratch memory: 6.7 -> ms per frame at 1 024 points).
   uint32_t* rank = reinterpret_cast<uint32_t*>(work);
-  for (int idx = tid; idx < n; idx += BLK) {
+  for (int idx = tid; idx < n; idx += NT) {
     matched[idx] = np_interp((double)leq[idx] / (double)n, hist_q, hist_v, hist_n);
     rank[idx] = leq[idx];
   }
   __syncthreads();
-  for (int idx = tid; idx < n; idx += BLK) {
+  const int ld = out_ld ? out_ld : w;
+  for (int idx = tid; idx < n; idx += NT) {
     const int r = idx / w, c = idx - r * w;
-    const int med = median_window32(rank, w, 0, w, h, r, c, hp_rx, hp_ry);
-    out[idx] = (float)(matched[idx] - np_interp((double)med / (double)n, hist_q, hist_v, hist_n));
+    // (NT != BLK: inside the fused kernel -- no private arrays there; the counts are in [1, n])
+    const int med = NT == BLK ? median_window32(rank, w, 0, w, h, r, c, hp_rx, hp_ry)
+                              : median_window32_bisect(rank, w, w, h, r, c, hp_rx, hp_ry, n);
+    out[(size_t)r * ld + c] = (float)(matched[idx] - np_interp((double)med / (double)n, hist_q, hist_v, hist_n));
+  }
+  if (ld > w) {  // (padding columns are only read for outputs that are discarded; keep them finite)
+    __syncthreads();  // (with a stride, `out` held the counts `leq` at other places than the values now written)
+    for (int idx = tid; idx < h * (ld - w); idx += NT) {
+      const int r = idx / (ld - w), c = w + idx - r * (ld - w);
+      out[(size_t)r * ld + c] = 0.0f;
+    }
   }
 }
 
 // float frames: the tile normalised in the frame's dtype (helpers.normalize), then the ranking above
-__device__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
+template <int NT = BLK, int NBK = NBINS>
+__device__ __forceinline__ void search_tile_from_boxf(const uint8_t* frame, int width, int channels, int bits, const int* box,
                                       const double* hist_v, const double* hist_q, int hist_n, double* work, double* red,
                                       float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
-                                      unsigned char* lds, int lds_bytes) {
+                                      unsigned char* lds, int lds_bytes, int out_ld = 0) {
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   // the float32 scratch of the normalisation (2 n floats; a float32 frame is summed in NumPy's order by ONE thread, whose
   // 4 n dependent loads should not be cache misses): LDS when it fits, else behind the values (the matched ones go there)
   float* scratch = 2 * n * (int)sizeof(float) <= lds_bytes ? reinterpret_cast<float*>(lds) : reinterpret_cast<float*>(work + n);
-  normalize_box_float(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
-  search_tile_from_values(w, h, hist_v, hist_q, hist_n, work, out, hp_rx, hp_ry, tab, scan_tmp, lds, lds_bytes);
+  normalize_box_float<NT>(frame, width, channels, bits, box, work, scratch, scratch + n, red, nullptr);
+  search_tile_from_values<NT, NBK>(w, h, hist_v, hist_q, hist_n, work, out, hp_rx, hp_ry, tab, scan_tmp, lds, lds_bytes, out_ld);
 }
 
 // 16-bit frames: the keys themselves are the values (any increasing function of the key ranks the same; the template's

@@ -29,7 +29,7 @@ namespace glh {
 
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
-constexpr int PT_MAX_TILE = 48;  // largest template side the fused kernel handles
+constexpr int PT_MAX_TILE = 63;  // largest template side the fused kernel handles (rows padded to 64 floats)
 constexpr int PT_NSTAMP = 20;
 constexpr int PT_MAX_OBS = 4;    // observers per point in the fused kernel (= MAX_OBS of the library)
 
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   constexpr int NREG = PPT > 0 ? PPT : 1;
   TmplRegs tmpl0{};
   // (16-bit frames: the template CDF has up to tw x th entries; the tile stage places it itself)
-  const bool tmpl_early = live[0] && tmpl_small(hist_n0) && !(SURF && a.obs[0].bits == 16);  // uniform
+  const bool tmpl_early = live[0] && tmpl_small(hist_n0) && !(SURF && a.obs[0].bits >= 16);  // uniform
   const int rounds = (N + TB - 1) / TB;  // <= PPT when PPT > 0 (the host picks the variant)
   double* V0 = a.uv + (size_t)pt * N * 2;
   double u0[NREG];
@@ -1032,7 +1032,8 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const bool inv_lds = dense;  // (ninv <= 512 <= TB)
     const int l2 = dense ? 2 * zb + (inv_lds ? pt_align16(ninv * 8) : 0) : zb + pt_align16(5 * (ho + wo) * 8);
     const bool wide = SURF && ob.bits == 16;  // uniform: 16-bit frames (pt_tile_prep_wide), through the workspace branch
-    const bool fits = !wide && off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
+    const bool flt = SURF && ob.bits >= 32;   // uniform: float32 / float64 frames (glh_kernels.h: search_tile_from_boxf), likewise
+    const bool fits = !wide && !flt && off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
     const double* fh_g = a.lu + a.lu_off[ho];
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (o == 0 && tmpl_early)
       tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
     else
-      load_template(o, !wide);
+      load_template(o, !wide && !flt);
     // ---- C: sample at every particle's uv (observer.py:178-214), scaled by 1/(2 sigma^2); called
     //      once per branch below so that the coefficient loads keep their address space
     auto sample_all = [&](const double* Z, auto cells_tag) {
@@ -1268,6 +1269,22 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           jt = reinterpret_cast<uint16_t*>(raw);
         pt_tile_prep_wide<TB>(ob, box, hist_n, ws, tab, raw, low, cdf_l, jt, scan_tmp, a.hp_rx, a.hp_ry,
                               (unsigned long long*)a.stamps);
+      } else if (flt) {
+        // Float frames (round 4; rounds 2-3: staged kernels only): the tile stage of the staged kernels on this
+        // workgroup's threads -- the tile normalised in the frame's dtype with NumPy's summation order, the two-level
+        // ranking over the normalised values, the median on the counts -- into the search workspace with this kernel's
+        // row stride; values and matched values in the observer's float workspace, the bucket table, the float32
+        // scratch and the template CDF in region 2 while they fit.
+        if constexpr (SURF) {
+          uint32_t* tab = reinterpret_cast<uint32_t*>(X);
+          constexpr int NBK = 1024;
+          unsigned char* lds = X + NBK * 4;
+          const int lds_bytes = a.r2_bytes - offT - NBK * 4;
+          search_tile_from_boxf<TB, NBK>(ob.frame, ob.width, ob.channels, ob.bits, box, hv_g, hq_g, hist_n,
+                                         ob.fwork + (size_t)pt * ob.fwork_cap, wave_tot, ws.S, a.hp_rx, a.hp_ry, tab,
+                                         scan_tmp, lds, lds_bytes, ws.ld);
+          __syncthreads();
+        }
       } else if (offT + hcl + pt_align16(pt_keys_count(ws_, hs) * 2) <= a.r2_bytes) {
         // only the float32 search tile is too large: the key tile stays in LDS (its own call, so that the
         // median's window loads keep their address space)

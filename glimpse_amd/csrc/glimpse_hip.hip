@@ -1396,8 +1396,9 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
     // 16-bit frames: ranked in LDS (glh_point.h: pt_tile_prep_wide) while a tile's pixel count fits a 16-bit key;
     // float frames and wider workspaces: staged kernels
     if (c->obs[o].bits == 16 && c->cfg.max_search_dim > 255) return false;
-    if (c->obs[o].bits != 8 && c->obs[o].bits != 16) return false;
-    if (c->obs[o].channels == 3 || c->obs[o].bits == 16) nb = 766;  // (16-bit: the bucket table is no larger)
+    // float32 / float64 frames (round 4): the staged tile stage run by the point's own workgroup
+    // (glh_kernels.h: search_tile_from_boxf): 1 024 buckets + scratch in the region the 766 bins would take
+    if (c->obs[o].channels == 3 || c->obs[o].bits >= 16) nb = 766;  // (16-bit / float: the bucket table is no larger)
   }
   // c[N] and, behind region 2, the pairwise-sum plan
   const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
@@ -1488,6 +1489,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
   a.step = (uint64_t)frame;
   a.tau = tau;
   for (int o = 0; o < O; ++o) {
+    if (c->obs[o].bits >= 32) CHK(prepare_bins16(c, o, true));  // (the float workspace, on first use)
     fill_obs(c, o, images[o], &a.obs[o]);
     if ((int)c->obs[o].cams_host.size() != c->obs[o].n_images)
       return fail(GLH_E_STATE, "observer %d: cameras have not been set", o);

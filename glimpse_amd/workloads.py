@@ -110,7 +110,7 @@ class Workload:
         return sub
 
     channels = 1  # 3: RGB frames (what a time-lapse JPEG decodes to)
-    bits = 8      # 16: the same scene on a 16-bit sensor (uint16 frames)
+    bits = 8      # 16: the same scene on a 16-bit sensor (uint16 frames); 32 / 64: the caller brings float frames
 
     @property
     def scene(self):
@@ -132,7 +132,7 @@ class Workload:
                 "tangent_cartesian": "TangentCartesianMotion", "tangent_cylindrical": "TangentCylindricalMotion"}[motion]
         return {
             "workload": f"{self.name}: {self.P} points x {self.N} particles x {self.T} frames "
-                        f"{self.imgsz[0]}x{self.imgsz[1]} uint{self.bits}{' RGB' if self.channels == 3 else ''}, tile {self.tile[0]}x{self.tile[1]}, "
+                        f"{self.imgsz[0]}x{self.imgsz[1]} {'uint' if self.bits <= 16 else 'float'}{self.bits}{' RGB' if self.channels == 3 else ''}, tile {self.tile[0]}x{self.tile[1]}, "
                         f"{self.O} observer(s), {name}, radial k={tuple(self.cfg['k'])}",
             "points_per_gpu": self.P,
             "particles": self.N,
@@ -147,8 +147,8 @@ def setup_context(ctx, wl, frames=None, channels=None):
     channels = wl.channels if channels is None else channels
     for o in range(wl.O):
         ctx.observer_init(o, wl.T, wl.imgsz[0], wl.imgsz[1], channels, wl.sigmas[o])
-        if wl.bits == 16:
-            ctx.observer_set_depth(o, np.uint16)
+        if wl.bits != 8:  # (uint16 frames, or the scene as float32 / float64 reflectances)
+            ctx.observer_set_depth(o, {16: np.uint16, 32: np.float32, 64: np.float64}[wl.bits])
         ctx.observer_set_cameras(o, np.tile(wl.cams[o], (wl.T, 1)))
         for t in range(wl.T):
             f = frames[o][t] if frames is not None else wl.frame(o, t)

@@ -626,3 +626,97 @@ def test_covariances_of_the_compact_state_equal_those_of_the_expanded_state(lib)
         assert np.isfinite(compact).all() and (np.einsum("pii->pi", compact)[:, [0, 1, 3, 4]] > 0).all()  # (z does not vary)
         mom = ctx.get_moments(T - 1, 1)[0]
         np.testing.assert_allclose(np.sqrt(np.einsum("pii->pi", compact)), mom[:, 6:], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+@pytest.mark.parametrize("dtype,channels", [(np.float32, 1), (np.float64, 1), (np.float32, 3), (np.float64, 3)])
+def test_float_frames_on_the_fused_kernel(lib, dtype, channels, math):
+    """float32 / float64 frames, one channel and three, on the general instantiations of the fused kernel (rounds 2-3:
+    staged kernels only): the point's own workgroup runs the staged tile stage (glh_kernels.h: search_tile_from_boxf --
+    normalisation in the frame's dtype with NumPy's summation order, two-level ranking, median on the counts) into the
+    search workspace -- bit for bit the staged kernels, host-fed and device draws, one observer and two."""
+    from glimpse_amd import workloads
+
+    T = 5
+    for name, P, N in (("C2", 5, 1500), ("C5", 3, 2000), ("C3", 3, 4000)):
+        wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
+        wl.channels = channels
+        # a reflectance-like image: the uint8 scene scaled into (0.1, 0.9), with a little structure below one grey level
+        frames = [[(f.astype(np.float64) / 255.0 * 0.8 + 0.1 + 1e-4 * np.sin(np.arange(f.size).reshape(f.shape) * 0.37))
+                   .astype(dtype) for f in wl.frames(o)] for o in range(wl.O)]
+        rng = np.random.default_rng(7)
+        ev, us = rng.standard_normal((P, N, 3)), rng.random(P)
+        res = []
+        for mode in (1, 0):
+            with lib.Context(wl.P, wl.N, wl.O, max_tile=max(wl.tile), max_search_dim=160, max_frames=T) as ctx:
+                for o in range(wl.O):
+                    ctx.observer_init(o, T, wl.imgsz[0], wl.imgsz[1], channels, wl.sigmas[o])
+                    ctx.observer_set_depth(o, dtype)
+                    ctx.observer_set_cameras(o, np.tile(wl.cams[o], (T, 1)))
+                    for t in range(T):
+                        ctx.observer_upload_frame(o, t, frames[o][t])
+                ctx.begin_sequence(wl.P, wl.N, wl.tile)
+                ctx.set_motion_cartesian(wl.params)
+                ctx.set_math(math)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=11)
+                for o in range(wl.O):
+                    ctx.init_templates(o, 0)
+                ctx.record_moments(0)
+                idx = []
+                for i in range(1, T):
+                    if i == 2:
+                        ctx.step(i, 1.0, [i] * wl.O, normals=ev, u=us)  # (one step on host-fed draws)
+                    else:
+                        ctx.step(i, 1.0, [i] * wl.O, seed=11)
+                    idx.append(ctx.resample_indices())
+                    if mode:
+                        assert ctx.last_variant()[3] & 2  # the general code
+                assert (ctx.observer_status() == lib.OBS_OK).all() and (ctx.point_status() == 0).all()
+                stages = {k for k, v in ctx.profile_get().items() if v[1] > 0}
+                assert ("point_step" in stages) == bool(mode)
+                res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T), np.stack(idx)))
+        np.testing.assert_array_equal(res[0][3], res[1][3])
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
+        assert abs(np.median(res[0][2][-1, :, 3]) - 0.15) < 0.06
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_templates_up_to_63_pixels_on_the_fused_kernel(lib, math):
+    """Templates beyond 48 pixels (rounds 1-3: staged kernels): the fused kernel takes sides up to 63 -- the template rows
+    are padded to 64 floats, the search tile of such a template no longer fits beside it at two workgroups per CU and
+    goes through the workspaces, the plan falls back to one workgroup per CU.  Bit for bit the staged kernels."""
+    from glimpse_amd import workloads
+
+    T = 4
+    for tile, N in (((63, 63), 1500), ((55, 49), 3000)):
+        wl = workloads.Workload("C3", n_frames=T, n_points=3, n_particles=N, imgsz=(768, 768))
+        wl.tile = tile
+        frames = [wl.frames(o) for o in range(wl.O)]
+        res = []
+        for mode in (1, 0):
+            with lib.Context(wl.P, wl.N, wl.O, max_tile=max(tile), max_search_dim=192, max_frames=T) as ctx:
+                workloads.setup_context(ctx, wl, frames)
+                ctx.set_math(math)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=5)
+                ctx.init_templates(0, 0)
+                ctx.record_moments(0)
+                idx = []
+                for i in range(1, T):
+                    ctx.step(i, 1.0, [i], seed=5)
+                    idx.append(ctx.resample_indices())
+                assert (ctx.observer_status() == lib.OBS_OK).all() and (ctx.point_status() == 0).all()
+                stages = {k for k, v in ctx.profile_get().items() if v[1] > 0}
+                assert ("point_step" in stages) == bool(mode)
+                res.append((ctx.get_particles(), ctx.get_weights(), ctx.get_moments(0, T), np.stack(idx)))
+        np.testing.assert_array_equal(res[0][3], res[1][3])
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
