@@ -766,9 +766,10 @@ extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, in
                               double ymax) {
   if (!c) return fail(GLH_E_INVALID, "null context");
   if (which < GLH_RASTER_DEM || which > GLH_RASTER_VIEWSHED) return fail(GLH_E_INVALID, "unknown raster slot %d", which);
+  auto& r = c->rasters[which];
+  if (!z && !r.z) return GLH_OK;  // (no raster before, none now: nothing to wait for -- the usual call of every run)
   HIPCHK(hipSetDevice(c->cfg.device_id));
   HIPCHK(hipStreamSynchronize(c->stream));
-  auto& r = c->rasters[which];
   dfree(r.z); dfree(r.gx); dfree(r.gy);
   r.dev = RasterDev{};
   if (!z) return GLH_OK;

@@ -1,7 +1,7 @@
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from glimpse_amd import _lib as lib, workloads
-T = 12
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 PTS = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 wl = workloads.Workload("C3", n_frames=T, n_points=PTS, n_particles=5000)
 DT = np.float64 if len(sys.argv) > 1 and sys.argv[1] == "64" else np.float32
@@ -15,6 +15,7 @@ with lib.Context(wl.P, wl.N, 1, max_search_dim=160, max_frames=T) as ctx:
     ctx.begin_sequence(wl.P, wl.N, wl.tile)
     ctx.set_motion_cartesian(wl.params)
     ctx.set_math("fast")
+    ctx.set_fused(int(sys.argv[3]) if len(sys.argv) > 3 else 1)  # (1: the fused kernel, 0: the staged kernels)
     ctx.set_frame(0); ctx.init_particles(seed=3); ctx.init_templates(0, 0); ctx.record_moments(0)
     ctx.profile_enable(True)
     for i in range(1, T):
