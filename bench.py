@@ -675,7 +675,7 @@ def secondary_legs(args, device, T, rendered, seed):
             if bits == 32:
                 frames = [[np.asarray(f, dtype=np.float32) * np.float32(1.0 / 255.0) for f in fo] for fo in frames]
             # (uint16 frames take the fused step while a tile's pixel count fits a 16-bit key: workspaces up to 255 px)
-            dim = min(args.max_search_dim, 255) if bits == 16 else args.max_search_dim
+            dim = min(args.max_search_dim, 255) if bits >= 16 else args.max_search_dim  # (uint16 / float: ranked keys)
             with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=dim,
                               max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)

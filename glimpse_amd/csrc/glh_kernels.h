@@ -919,18 +919,35 @@ __device__ __forceinline__ float np_pairwise_leaf_f32(const float* a, int n) {  
   for (; i < n; ++i) res += a[i];
   return res;
 }
-__device__ __forceinline__ float np_pairwise_f32(const float* a, int n) {
-  // the recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2) on an explicit stack (depth <= log2(n / 128) + 1).
-  // ONE thread of the block runs this (normalize_box_float): the stack lives in LDS -- as private arrays with dynamic
-  // indices it was 400 bytes of scratch memory, which every kernel that can reach this code then reserves
-  __shared__ int off[24], len[24], state[24];
-  __shared__ float left[24];
+// The recursion pairwise(n) = pairwise(n2) + pairwise(n - n2), n2 = n / 2 rounded down to a multiple of 8, down to leaves of
+// at most 128 items, on an explicit stack (depth <= log2(n / 128) + 1): `leaf(off, len)` is called for every leaf in order
+// and its results are added as NumPy adds them.  ONE thread of the block runs this; the stack lives in LDS -- as private
+// arrays with dynamic indices it was 400 bytes of scratch memory, which every kernel that can reach this code reserves.
+// `k`: the ordinal of the next leaf, counted on (leaf(off, len, ordinal)).
+struct NpWalk {
+  float sum;
+  int k;
+};
+struct NpStack {  // (a walk never exceeds 8192 items -- NumPy's buffer -- or a tile's row: depth <= 8)
+  int off[16], len[16], state[16];
+  float left[16];
+};
+__device__ __forceinline__ NpStack* np_stack() {  // (ONE stack for every instantiation of the walk)
+  __shared__ NpStack s;
+  return &s;
+}
+template <typename LEAF>
+__device__ __forceinline__ NpWalk np_pairwise_walk(int off0, int n, int k, LEAF leaf) {
+  NpStack* st = np_stack();
+  int *off = st->off, *len = st->len, *state = st->state;
+  float* left = st->left;
   int sp = 0;
-  off[0] = 0; len[0] = n; state[0] = 0; left[0] = 0.0f;
+  off[0] = off0; len[0] = n; state[0] = 0; left[0] = 0.0f;
   float ret = 0.0f;
   while (sp >= 0) {
     if (len[sp] <= 128) {
-      ret = np_pairwise_leaf_f32(a + off[sp], len[sp]);
+      ret = leaf(off[sp], len[sp], k);
+      ++k;
       --sp;
       continue;
     }
@@ -950,7 +967,10 @@ __device__ __forceinline__ float np_pairwise_f32(const float* a, int n) {
       --sp;
     }
   }
-  return ret;
+  return NpWalk{ret, k};
+}
+__device__ __forceinline__ float np_pairwise_f32(const float* a, int n) {
+  return np_pairwise_walk(0, n, 0, [&](int o, int l, int) { return np_pairwise_leaf_f32(a + o, l); }).sum;
 }
 // ... over a whole contiguous array: the reduction hands the inner loop chunks of 8192 items (np.getbufsize()) and adds
 // their sums to the running total in order (oracle/resample.py: numpy_pairwise_sum states the same for float64)
@@ -960,6 +980,68 @@ __device__ __forceinline__ float np_sum_flat_f32(const float* a, int n) {
   return acc;
 }
 
+// The same sums by the whole block (round 4; the serial form was a third of a float32 frame's tile stage): the LEAVES of
+// the recursion are independent, and so are the 8 interleaved accumulators inside a leaf.  Thread 0 walks the recursion
+// once to list the leaves (no data touched), 8 lanes per leaf then form its sum exactly as np_pairwise_leaf_f32 does --
+// lane j the accumulator r[j], ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) by three exchange-adds (float addition
+// commutes, so both lanes of a pair hold the same bits), the tail by lane 0 -- and thread 0 walks the recursion again,
+// taking the leaf sums in order.  row_len > 0: the sum of a 2-D strided view as np.add.reduce forms it, out += pairwise(row)
+// row by row; row_len == 0: a flat array in chunks of 8192.  `list`: `cap` words of LDS (a leaf = offset | length << 16:
+// offsets below 65 536).  Returns false (nothing done) when the leaves may not fit -- the caller sums serially.
+template <int NT>
+__device__ __forceinline__ bool np_sum_f32_block(const float* a, int n, int row_len, uint32_t* list, int cap, float* result) {
+  __shared__ int s_nleaf;
+  const int tid = threadIdx.x, sub = tid & 7;
+  const int unit = row_len > 0 ? row_len : 8192;
+  const int units = (n + unit - 1) / unit;
+  if (!list || n >= 65536 || (long long)units * (unit <= 128 ? 1 : (min(unit, n) + 63) / 64) > cap) return false;  // (uniform)
+  if (tid == 0) {
+    int k = 0;
+    for (int o = 0; o < n; o += unit)
+      k = np_pairwise_walk(o, min(unit, n - o), k, [list](int off, int len, int at) {
+            list[at] = (uint32_t)off | ((uint32_t)len << 16);
+            return 0.0f;
+          }).k;
+    s_nleaf = k;
+  }
+  __syncthreads();
+  const int nleaf = s_nleaf;
+  for (int k0 = 0; k0 < nleaf; k0 += NT / 8) {  // (whole groups of 8 lanes stay together: the exchanges below need them)
+    const int k = k0 + (tid >> 3);
+    const bool live = k < nleaf;
+    const uint32_t e = live ? list[k] : 0u;
+    const int off = (int)(e & 0xffffu), len = (int)(e >> 16);
+    float res = 0.0f;
+    if (len >= 8) {
+      const int body = len - (len % 8);
+      float r = a[off + sub];
+      for (int i = 8; i < body; i += 8) r += a[off + i + sub];
+      r += __shfl_xor(r, 1, WAVE);
+      r += __shfl_xor(r, 2, WAVE);
+      r += __shfl_xor(r, 4, WAVE);
+      res = r;
+      if (sub == 0)
+        for (int i = body; i < len; ++i) res += a[off + i];
+    } else if (sub == 0) {
+      for (int i = 0; i < len; ++i) res += a[off + i];
+    }
+    if (live && sub == 0) list[k] = __float_as_uint(res);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0;
+    float acc = 0.0f;
+    for (int o = 0; o < n; o += unit) {
+      const NpWalk part = np_pairwise_walk(o, min(unit, n - o), k, [list](int, int, int at) { return __uint_as_float(list[at]); });
+      acc += part.sum;
+      k = part.k;
+    }
+    *result = acc;
+  }
+  __syncthreads();
+  return true;
+}
+
 // normalize (helpers.py:344) of the box into y[n]: (a - a.mean()) * (1 / a.std()); all threads; ends with a barrier.
 // float64 frames: block reductions (the last bits of a float64 mean decide nothing).  float32 frames: float32 arithmetic
 // with NumPy's own summation order, on thread 0 -- a one-channel tile is a strided view of the frame, which NumPy sums
@@ -967,22 +1049,28 @@ __device__ __forceinline__ float np_sum_flat_f32(const float* a, int n) {
 // (a - mean)^2 is contiguous either way.  `tmp`: 2 n floats of scratch that may overlap y (not each other).
 template <int NT = BLK>
 __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int width, int channels, int bits, const int* box,
-                                                    double* y, float* tmp_g, float* tmp_x2, double* red, bool* const_tile) {
+                                                    double* y, float* tmp_g, float* tmp_x2, double* red, bool* const_tile,
+                                                    uint32_t* list = nullptr, int list_cap = 0) {
   const int tid = threadIdx.x;
   const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
   if (bits == 32) {
-    __shared__ float s_mean, s_inv;
+    __shared__ float s_mean, s_inv, s_sum;
     for (int idx = tid; idx < n; idx += NT) {
       const int r = idx / w, c = idx - r * w;
       tmp_g[idx] = (float)pixel_float(frame, width, channels, 32, box[1] + r, box[0] + c);
     }
     __syncthreads();
+    // (the sums by the whole block when the leaves of NumPy's recursion fit `list`, by thread 0 otherwise: same bits)
+    const bool par_g = np_sum_f32_block<NT>(tmp_g, n, channels == 1 ? w : 0, list, list_cap, &s_sum);
     if (tid == 0) {
-      float acc = 0.0f;
-      if (channels == 1)
-        for (int r = 0; r < h; ++r) acc += np_pairwise_f32(tmp_g + (size_t)r * w, w);
-      else
-        acc = np_sum_flat_f32(tmp_g, n);
+      float acc = s_sum;
+      if (!par_g) {
+        acc = 0.0f;
+        if (channels == 1)
+          for (int r = 0; r < h; ++r) acc += np_pairwise_f32(tmp_g + (size_t)r * w, w);
+        else
+          acc = np_sum_flat_f32(tmp_g, n);
+      }
       s_mean = acc / (float)n;
     }
     __syncthreads();
@@ -992,8 +1080,9 @@ __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int wi
       tmp_x2[idx] = d * d;
     }
     __syncthreads();
+    const bool par_x = np_sum_f32_block<NT>(tmp_x2, n, 0, list, list_cap, &s_sum);
     if (tid == 0) {
-      const float var = np_sum_flat_f32(tmp_x2, n) / (float)n;
+      const float var = (par_x ? s_sum : np_sum_flat_f32(tmp_x2, n)) / (float)n;
       s_inv = 1.0f / sqrtf(var);
       if (const_tile) *const_tile = !(var > 0.0f);
     }
@@ -1082,37 +1171,18 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, int channels
   }
 }
 
-// search tile from values: work [2 n] doubles of memory (the values -- any increasing function of the pixel --, behind them
-// the matched ones); the template CDF
-// `tab`: >= NBINS words of LDS, `scan_tmp`: NWAVES words.  The pixels at or below every pixel (np.unique's
-// cumsum(counts)[inverse]) by the two-level ranking of the fused kernel's 16-bit path (glh_point.h: pt_tile_prep_wide) on
-// the normalised values: buckets over the tile's own value range, a block scan for their offsets, the values scattered
-// into bucket order (over the matched-value array, which is written afterwards), a pixel's count = its bucket's offset
-// + the members of its bucket at or below it.  (Rounds 2-3a counted over the whole tile for
-// every pixel: O(n^2 / BLK) per thread.)
-// NT: threads of the block; NBK: buckets (>= NT, a multiple of it; `tab` holds NBK words); `out_ld`: row stride of the
-// search tile (0: dense, w) -- the fused kernel's tiles carry padding columns, which are zeroed.
-template <int NT = BLK, int NBK = NBINS>
-__device__ __forceinline__ void search_tile_from_values(int w, int h, const double* hist_v, const double* hist_q, int hist_n, double* work,
-                                        float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
-                                        unsigned char* lds, int lds_bytes, int out_ld = 0) {
+// np.unique's cumsum(counts)[inverse] for n values (any doubles): `emit(idx, count)` receives, for every value, the number
+// of values at or below it.  Two-level ranking: NBK buckets LINEAR in the value over the values' own range (a
+// floating-point map that is monotone non-decreasing: x <= y implies bucket(x) <= bucket(y), which is all the ranking
+// needs; the bit pattern of a double would be logarithmic in it -- nearly all of a normalised tile in half a dozen
+// buckets), a block scan for the bucket offsets, the values scattered into bucket order (`sorted`, n doubles), a value's
+// count = its bucket's offset + the members of its bucket at or below it.  `tab`: NBK words of LDS, `scan_tmp`: NT / WAVE
+// words.  All threads; ends with a barrier.
+template <int NT, int NBK, typename EMIT>
+__device__ __forceinline__ void rank_values(const double* work, double* sorted, int n, uint32_t* tab, uint32_t* scan_tmp,
+                                            EMIT emit) {
   __shared__ double s_mm[NT / WAVE][2];
   const int tid = threadIdx.x;
-  const int n = w * h;
-  if (2 * hist_n * (int)sizeof(double) <= lds_bytes) {
-    // the template CDF into LDS (np.interp searches it twice per pixel)
-    double* cdf_lds = reinterpret_cast<double*>(lds);
-    for (int k = tid; k < hist_n; k += NT) {
-      cdf_lds[k] = hist_q[k];
-      cdf_lds[hist_n + k] = hist_v[k];
-    }
-    hist_q = cdf_lds;
-    hist_v = cdf_lds + hist_n;
-    // (visible after the barriers of the ranking below)
-  }
-  double* matched = work + n;
-  double* sorted = matched;                          // values in bucket order, until `matched` is made
-  uint32_t* leq = reinterpret_cast<uint32_t*>(out);  // counts, until `out` is made
   static_assert(NBK % NT == 0, "whole buckets per thread");
   for (int b = tid; b < NBK; b += NT) tab[b] = 0;
   double xmin = INFINITY, xmax = -INFINITY;
@@ -1134,9 +1204,6 @@ __device__ __forceinline__ void search_tile_from_values(int w, int h, const doub
     xmin = fmin(xmin, s_mm[wv][0]);
     xmax = fmax(xmax, s_mm[wv][1]);
   }
-  // buckets LINEAR in the value (a floating-point map that is monotone non-decreasing: x <= y implies bucket(x) <=
-  // bucket(y), which is all the ranking needs; the bit pattern of a double would be logarithmic in it -- nearly all of a
-  // normalised tile in half a dozen buckets)
   const double scale = xmax > xmin ? (double)(NBK - 1) / (xmax - xmin) : 0.0;
   auto bucket = [&](double x) -> int { return min(NBK - 1, max(0, (int)((x - xmin) * scale))); };
   for (int idx = tid; idx < n; idx += NT) atomicAdd(&tab[bucket(work[idx])], 1u);
@@ -1144,12 +1211,14 @@ __device__ __forceinline__ void search_tile_from_values(int w, int h, const doub
   {
     constexpr int PER = NBK / NT;
     uint32_t cnt[PER], local = 0;
+#pragma unroll
     for (int k = 0; k < PER; ++k) {
       cnt[k] = tab[PER * tid + k];
       local += cnt[k];
     }
     uint32_t total;
     uint32_t run = block_excl_scan_u32<NT>(local, scan_tmp, &total);  // (barriers inside)
+#pragma unroll
     for (int k = 0; k < PER; ++k) {
       tab[PER * tid + k] = run;
       run += cnt[k];
@@ -1167,9 +1236,42 @@ __device__ __forceinline__ void search_tile_from_values(int w, int h, const doub
     const uint32_t lo = b ? tab[b - 1] : 0u, hi = tab[b];
     uint32_t c = lo;
     for (uint32_t j = lo; j < hi; ++j) c += sorted[j] <= x;
-    leq[idx] = c;
+    emit(idx, c);
   }
   __syncthreads();
+}
+
+// search tile from values: work [2 n] doubles of memory (the values -- any increasing function of the pixel --, behind them
+// the matched ones); the template CDF
+// `tab`: >= NBINS words of LDS, `scan_tmp`: NWAVES words.  The pixels at or below every pixel (np.unique's
+// cumsum(counts)[inverse]) by the two-level ranking of the fused kernel's 16-bit path (glh_point.h: pt_tile_prep_wide) on
+// the normalised values: buckets over the tile's own value range, a block scan for their offsets, the values scattered
+// into bucket order (over the matched-value array, which is written afterwards), a pixel's count = its bucket's offset
+// + the members of its bucket at or below it.  (Rounds 2-3a counted over the whole tile for
+// every pixel: O(n^2 / BLK) per thread.)
+// NT: threads of the block; NBK: buckets (>= NT, a multiple of it; `tab` holds NBK words); `out_ld`: row stride of the
+// search tile (0: dense, w) -- the fused kernel's tiles carry padding columns, which are zeroed.
+template <int NT = BLK, int NBK = NBINS>
+__device__ __forceinline__ void search_tile_from_values(int w, int h, const double* hist_v, const double* hist_q, int hist_n, double* work,
+                                        float* out, int hp_rx, int hp_ry, uint32_t* tab, uint32_t* scan_tmp,
+                                        unsigned char* lds, int lds_bytes, int out_ld = 0) {
+  const int tid = threadIdx.x;
+  const int n = w * h;
+  if (2 * hist_n * (int)sizeof(double) <= lds_bytes) {
+    // the template CDF into LDS (np.interp searches it twice per pixel)
+    double* cdf_lds = reinterpret_cast<double*>(lds);
+    for (int k = tid; k < hist_n; k += NT) {
+      cdf_lds[k] = hist_q[k];
+      cdf_lds[hist_n + k] = hist_v[k];
+    }
+    hist_q = cdf_lds;
+    hist_v = cdf_lds + hist_n;
+    // (visible after the barriers of the ranking below)
+  }
+  double* matched = work + n;
+  double* sorted = matched;                          // values in bucket order, until `matched` is made
+  uint32_t* leq = reinterpret_cast<uint32_t*>(out);  // counts, until `out` is made
+  rank_values<NT, NBK>(work, sorted, n, tab, scan_tmp, [&](int idx, uint32_t c) { leq[idx] = c; });
   // helpers.match_cdf: quantile of every pixel = (pixels at or below it) / size, through np.interp of the template CDF.
   // The counts move over the normalised values (dead): the high-pass takes its median on them -- the match is monotone in
   // the count, so the median of the matched window is the matched value of the median count (integers in registers for

@@ -475,6 +475,53 @@ __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
   }
 }
 
+// The second half of the tile stage when the keys ARE the counts (16-bit and float frames): the key tile's borders, the
+// template CDF into LDS, the interval of every occurring count in the CDF (jt), the median high-pass into ws.S.
+// tab: the bucket table (dead: reused as the 257-entry index of the quantiles); cdf_lds / jt: see pt_tile_prep_wide.
+template <int TB>
+__device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, const TileWs& ws, uint32_t* tab, double* cdf_lds,
+                                                 uint16_t* jt, int hp_rx, int hp_ry, unsigned long long* stp = nullptr) {
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  const int wp = pt_keys_stride(w);
+  uint16_t* keys = ws.keys + 2 * wp + 2;
+  const UDiv by_w = udiv_make(w);
+  pt_border_cols<TB>(keys, wp, w, h);
+  const double *cq = ws.cdf_q, *cv = ws.cdf_v;
+  if (cdf_lds) {  // (raw / low are dead)
+    double* lv = cdf_lds + pt_align16(hist_n * 8) / 8;
+    pt_stage<TB>(cdf_lds, ws.cdf_q, hist_n);
+    pt_stage<TB>(lv, ws.cdf_v, hist_n);
+    cq = cdf_lds;
+    cv = lv;
+  }
+  __syncthreads();
+  pt_border_rows<TB>(keys, wp, h);
+  // helpers.match_cdf (helpers.py:489-493) = np.interp(count / n, template quantiles, template values) for a pixel and
+  // for its median: the interval search is made once per pixel, into jt[count] (equal counts write equal intervals), and
+  // starts from an index of the quantiles by 1/256 steps (acc, over the bucket table: dead)
+  uint16_t* acc = reinterpret_cast<uint16_t*>(tab);
+  for (int i = tid; i <= 256; i += TB) {
+    const int j = np_interp_find((double)i * (1.0 / 256.0), cq, hist_n);
+    acc[i] = (uint16_t)(j < 0 ? 0 : j);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n; idx += TB) {
+    const int r = udiv(by_w, idx), c = idx - r * w;
+    const int k = keys[r * wp + c];
+    const double x = (double)k / (double)n;  // np.cumsum(counts) / a.size
+    const int s256 = min(255, (int)(x * 256.0));
+    // xp[acc[s]] <= s / 256 <= x < (s + 1) / 256 < xp[acc[s + 1] + 1]: the interval of x lies between them
+    jt[k] = (uint16_t)np_interp_find(x, cq, hist_n, acc[s256], min(hist_n - 1, acc[s256 + 1] + 1));
+  }
+  __syncthreads();
+  if (stp && tid == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + 14] = __builtin_amdgcn_s_memtime();
+  pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, [&](int k) -> double {
+    const int j = jt[k];
+    return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, (double)k / (double)n, cq, cv, hist_n);
+  });
+}
+
 // 16-bit frames (uint16 gray or RGB; tracker.py:494-534 works on any dtype): a key is the pixel value or the channel sum
 // (<= 3 * 65535), far too many for a histogram in LDS.  What extract_tile needs of np.unique is, per pixel, the number of
 // pixels at or below its key -- cumsum(counts)[inverse] -- and that count IS a key the rest of the stage can work on: it
@@ -589,41 +636,8 @@ __device__ __forceinline__ void pt_tile_prep_wide(const ObsFrame& ob, const int*
   }
   __syncthreads();
   TPW_STAMP(13);
-  pt_border_cols<TB>(keys, wp, w, h);
-  const double *cq = ws.cdf_q, *cv = ws.cdf_v;
-  if (cdf_lds) {  // (raw / low are dead)
-    double* lv = cdf_lds + pt_align16(hist_n * 8) / 8;
-    pt_stage<TB>(cdf_lds, ws.cdf_q, hist_n);
-    pt_stage<TB>(lv, ws.cdf_v, hist_n);
-    cq = cdf_lds;
-    cv = lv;
-  }
-  __syncthreads();
-  pt_border_rows<TB>(keys, wp, h);
-  // helpers.match_cdf (helpers.py:489-493) = np.interp(count / n, template quantiles, template values) for a pixel and
-  // for its median: the interval search is made once per pixel, into jt[count] (equal counts write equal intervals), and
-  // starts from an index of the quantiles by 1/256 steps (acc, over the bucket table: dead)
-  uint16_t* acc = reinterpret_cast<uint16_t*>(tab);
-  for (int i = tid; i <= 256; i += TB) {
-    const int j = np_interp_find((double)i * (1.0 / 256.0), cq, hist_n);
-    acc[i] = (uint16_t)(j < 0 ? 0 : j);
-  }
-  __syncthreads();
-  for (int idx = tid; idx < n; idx += TB) {
-    const int r = udiv(by_w, idx), c = idx - r * w;
-    const int k = keys[r * wp + c];
-    const double x = (double)k / (double)n;  // np.cumsum(counts) / a.size
-    const int s256 = min(255, (int)(x * 256.0));
-    // xp[acc[s]] <= s / 256 <= x < (s + 1) / 256 < xp[acc[s + 1] + 1]: the interval of x lies between them
-    jt[k] = (uint16_t)np_interp_find(x, cq, hist_n, acc[s256], min(hist_n - 1, acc[s256 + 1] + 1));
-  }
-  __syncthreads();
-  TPW_STAMP(14);
-  pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, [&](int k) -> double {
-    const int j = jt[k];
-    return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, (double)k / (double)n, cq, cv, hist_n);
-  });
 #undef TPW_STAMP
+  pt_counts_finish<TB>(box, hist_n, ws, tab, cdf_lds, jt, hp_rx, hp_ry, stp);
 }
 
 #define PT_STAMP(k)                                                                      \
@@ -1270,20 +1284,42 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         pt_tile_prep_wide<TB>(ob, box, hist_n, ws, tab, raw, low, cdf_l, jt, scan_tmp, a.hp_rx, a.hp_ry,
                               (unsigned long long*)a.stamps);
       } else if (flt) {
-        // Float frames (round 4; rounds 2-3: staged kernels only): the tile stage of the staged kernels on this
-        // workgroup's threads -- the tile normalised in the frame's dtype with NumPy's summation order, the two-level
-        // ranking over the normalised values, the median on the counts -- into the search workspace with this kernel's
-        // row stride; values and matched values in the observer's float workspace, the bucket table, the float32
-        // scratch and the template CDF in region 2 while they fit.
+        // Float frames (round 4; rounds 2-3: staged kernels only).  What extract_tile needs of np.unique is, per pixel,
+        // the number of pixels at or below its NORMALISED value -- and from there on the stage is the 16-bit one: the
+        // count is the key (it fits 16 bits: workspaces up to 255 pixels), the packed median network runs on the
+        // counts, their matched values come from the interval table.  The tile is normalised in the frame's dtype with
+        // NumPy's summation order and ranked by linear buckets exactly as the staged kernels do it (glh_kernels.h:
+        // normalize_box_float, rank_values); values and their bucket order in the observer's float workspace.
+        // (First form of this round: the whole staged stage run by this workgroup, its median by bisection over the
+        // counts in memory -- 0.72 of 0.88 ms per frame at 1 024 points was that median.)
         if constexpr (SURF) {
+          const int npx = ws_ * hs, wp = pt_keys_stride(ws_);
           uint32_t* tab = reinterpret_cast<uint32_t*>(X);
-          constexpr int NBK = 1024;
-          unsigned char* lds = X + NBK * 4;
-          const int lds_bytes = a.r2_bytes - offT - NBK * 4;
-          search_tile_from_boxf<TB, NBK>(ob.frame, ob.width, ob.channels, ob.bits, box, hv_g, hq_g, hist_n,
-                                         ob.fwork + (size_t)pt * ob.fwork_cap, wave_tot, ws.S, a.hp_rx, a.hp_ry, tab,
-                                         scan_tmp, lds, lds_bytes, ws.ld);
-          __syncthreads();
+          int used = offT + pt_align16(pt_wide_tab_bytes());
+          const int kb = pt_align16(pt_keys_count(ws_, hs) * 2);
+          if (used + kb <= a.r2_bytes) {
+            ws.keys = reinterpret_cast<uint16_t*>(r2 + used);
+            used += kb;
+          }
+          double* fw = ob.fwork + (size_t)pt * ob.fwork_cap;  // [values | values in bucket order]: 2 npx doubles
+          // the float32 scratch of the normalisation (2 npx floats, summed by ONE thread in NumPy's order): LDS if it fits
+          float* scratch = used + 8 * npx <= a.r2_bytes ? reinterpret_cast<float*>(r2 + used) : reinterpret_cast<float*>(fw + npx);
+          normalize_box_float<TB>(ob.frame, ob.width, ob.channels, ob.bits, box, fw, scratch, scratch + npx, wave_tot, nullptr,
+                                  tab, PT_WIDE_BUCKETS);  // (the bucket table, not yet in use, lists the sums' leaves)
+          uint16_t* kt = ws.keys + 2 * wp + 2;
+          const UDiv by_w = udiv_make(ws_);
+          rank_values<TB, PT_WIDE_BUCKETS>(fw, fw + npx, npx, tab, scan_tmp, [&](int idx, uint32_t cnt) {
+            const int r = udiv(by_w, idx), c = idx - r * ws_;
+            kt[r * wp + c] = (uint16_t)cnt;  // np.cumsum(counts)[inverse]
+          });
+          double* cdf_l = used + 2 * cdfb <= a.r2_bytes ? reinterpret_cast<double*>(r2 + used) : nullptr;
+          const int jb = pt_align16((npx + 1) * 2);
+          uint16_t* jt = reinterpret_cast<uint16_t*>(ws.Z);  // (the surface's workspace: free until the SSD)
+          if (cdf_l && used + 2 * cdfb + jb <= a.r2_bytes)
+            jt = reinterpret_cast<uint16_t*>(r2 + used + 2 * cdfb);
+          else if (!cdf_l && used + jb <= a.r2_bytes)
+            jt = reinterpret_cast<uint16_t*>(r2 + used);
+          pt_counts_finish<TB>(box, hist_n, ws, tab, cdf_l, jt, a.hp_rx, a.hp_ry, (unsigned long long*)a.stamps);
         }
       } else if (offT + hcl + pt_align16(pt_keys_count(ws_, hs) * 2) <= a.r2_bytes) {
         // only the float32 search tile is too large: the key tile stays in LDS (its own call, so that the

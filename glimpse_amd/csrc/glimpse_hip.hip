@@ -1394,11 +1394,9 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   int nb = 256;
   for (int o = 0; o < O; ++o) {
     if (c->obs[o].channels != 1 && c->obs[o].channels != 3) return false;
-    // 16-bit frames: ranked in LDS (glh_point.h: pt_tile_prep_wide) while a tile's pixel count fits a 16-bit key;
-    // float frames and wider workspaces: staged kernels
-    if (c->obs[o].bits == 16 && c->cfg.max_search_dim > 255) return false;
-    // float32 / float64 frames (round 4): the staged tile stage run by the point's own workgroup
-    // (glh_kernels.h: search_tile_from_boxf): 1 024 buckets + scratch in the region the 766 bins would take
+    // 16-bit and float frames: ranked in LDS / by linear buckets (glh_point.h: pt_tile_prep_wide, the float branch of
+    // the observer pass) while a tile's pixel count fits a 16-bit key; wider workspaces: staged kernels
+    if (c->obs[o].bits >= 16 && c->cfg.max_search_dim > 255) return false;
     if (c->obs[o].channels == 3 || c->obs[o].bits >= 16) nb = 766;  // (16-bit / float: the bucket table is no larger)
   }
   // c[N] and, behind region 2, the pairwise-sum plan

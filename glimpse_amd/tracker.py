@@ -278,9 +278,13 @@ class Tracker:
         return ctx
 
     def _sixteen_bit(self):
-        """Some observer's frames are uint16: the fused step takes those while the workspaces are at most 255 pixels
-        (a tile's pixel count must fit a 16-bit key), and no kernel beyond 1117."""
+        """Some observer's frames are uint16: no kernel takes those beyond 1117-pixel workspaces."""
         return any(obs.images[0].read().dtype == np.uint16 for obs in self.observers)
+
+    def _ranked_keys(self):
+        """Some observer's frames are uint16 or float: the fused step ranks a tile's pixels and takes those frames
+        while the workspaces are at most 255 pixels (the count of a tile's pixels must fit a 16-bit key)."""
+        return any(obs.images[0].read().dtype != np.uint8 for obs in self.observers)
 
     def _dim_limit(self, n_points):
         """The largest workspace side the automatic growth may ask for: what the kernels take (2000 pixels; 1117 for
@@ -296,10 +300,10 @@ class Tracker:
         return limit
 
     def _fit_dim(self, need, limit):
-        """Workspace side for a need of `need` pixels: a multiple of 16, except that 16-bit frames stay at 255 while
-        the need allows it (256 would send the whole run to the staged kernels, several times slower)."""
+        """Workspace side for a need of `need` pixels: a multiple of 16, except that 16-bit and float frames stay at 255
+        while the need allows it (256 would send the whole run to the staged kernels, several times slower)."""
         dim = int(16 * np.ceil(need / 16))
-        if need <= 255 < dim and self._sixteen_bit():
+        if need <= 255 < dim and self._ranked_keys():
             dim = 255
         return int(min(limit, dim))
 
