@@ -630,7 +630,7 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
         "value": wl.P * wl.N * (n_frames - 1) / wall,
         "roofline_frac": abytes / (gpu_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": abytes,
-        "traffic_ratio": None if traffic is None else traffic / abytes,
+        "traffic_ratio": None if traffic is None else traffic * (dom_n / max(n_frames - 1, 1)) / abytes,
         "observer_ok_fraction": float((status == 0).mean()),
         "points_with_error_bits": int((ctx.point_status() != 0).sum()),
         "final_means_finite": bool(np.isfinite(moments[n_frames - 1]).all()),
@@ -873,7 +873,8 @@ def worker(args):
             "dtype": "f64",
             "data": "synthetic",
             "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
-                           math=args.math, untimed_launches=W * F + B, parallelism=f"points sharded x{world}",
+                           math=args.math, untimed_launches=W * F + B, untimed_kernel_launches=(W * F + B) * streams,
+                           parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K * F / elapsed, burn_in_steps=B, frames_per_call=C,
                            frame_updates_per_step=F, track_streams=streams,
                            step=f"{F} consecutive frame update(s) of all {total_points} points",
@@ -901,11 +902,15 @@ def worker(args):
         # launch's own duration spans its neighbour's work, so the time is the GPU span of the timed launches (start
         # of the first to end of the last, HIP events on both streams) per frame; what ONE such launch achieves on its
         # share of the chip is under `per_launch`.
+        # HBM bytes of a frame from the committed PMC passes: per launch x the launches of a frame (like `achieved`, which
+        # is the bytes of a frame over the time of a frame)
+        per_launch_traffic = pmc_traffic(wl, kern) if wl.channels == 1 and wl.bits == 8 else None
+        traffic = None if per_launch_traffic is None else per_launch_traffic * launches_per_frame
         span_per_frame_ms = span_ms / (K * F)
         per_launch_ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         ach = abytes / (span_per_frame_ms * 1e-3) / 1e9 if streams > 1 else per_launch_ach
         roof = {"kernel": kern, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(wl, kern) if wl.channels == 1 and wl.bits == 8 else None,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": per_launch_ms, "launches_per_step": launches_per_step,
                 "concurrent_launches": streams, "gpu_span_ms_per_frame": span_per_frame_ms,
                 "per_launch": {"achieved": per_launch_ach, "frac": per_launch_ach / HBM_PEAK_GBS,
@@ -918,6 +923,8 @@ def worker(args):
                 "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
         if roof["traffic"] is not None:
+            roof["traffic_per"] = f"frame update ({launches_per_frame:g} launch(es) of {wl.P / launches_per_frame:g} points)"
+            roof["traffic_over_algorithmic"] = traffic / abytes
             roof["traffic_source"] = pmc_traffic_source(wl, kern)
         out["roofline"] = roof
         # The other ceiling, for the record: the step is bound by VALU issue, not by memory.  Wave-level

@@ -62,10 +62,18 @@ class Image:
     def read(self, box=None, cache=True):
         """image.py:137-214: the cached array, or the file (decoded once and kept when `cache`), at the camera's image
         size: an array of another size is resampled to it (and the resampled array is what is cached, like the
-        reference caches what GDAL returned).  `box` = (left, top, right, bottom) in camera image coordinates;
-        with `cache=False` the box is read straight from the file's own pixels (image.py:194-201)."""
+        reference caches what GDAL returned; for an image without a file the caller's array is kept and the resampled
+        copy cached beside it).  `box` = (left, top, right, bottom) in camera image coordinates; with `cache=False`
+        the box is read straight from the file's own pixels and resampled to the BOX's size -- the reference hands GDAL
+        buf_xsize / buf_ysize = the camera's whole image size for that window (image.py:192-201), so its output has
+        another shape there; tracking never reads that way (Observer.extract_tile passes the observer's cache flag,
+        and a cached image is sliced)."""
         cw, ch = (int(v) for v in self.cam.imgsz)
         array = self.array
+        kept = getattr(self, "_resized", None)
+        if kept is not None and self.path is None and array is not None and kept[0] == (cw, ch) \
+                and array.shape[1::-1] != (cw, ch):
+            array = kept[1]  # (the copy of an in-memory image resampled to this camera size)
         if array is not None and array.shape[1::-1] != (cw, ch) and self.path is not None:
             array = None  # (a cached read of another size is not reused: image.py:183-187)
         from_file = array is None
@@ -84,8 +92,13 @@ class Image:
             array = array[self._nearest(h, ch)][:, self._nearest(w, cw)]
         if from_file and cache:
             self.array = array
-        elif not from_file and array is not self.array and cache:
+        elif not from_file and array is not self.array and cache and self.path is not None:
             self.array = array  # (image.py:207-209: a cached array of another size is replaced by the resized read)
+        elif not from_file and array is not self.array and cache:
+            # an in-memory image (no file to go back to: the reference would fail on gdal.Open(None) here): the caller's
+            # pixels stay, the resampled copy is kept beside them for this camera size -- a later cam.resize(1) reads the
+            # original again instead of upsampling a decimated copy
+            self._resized = ((cw, ch), array)
         if box is not None:
             return array[box[1]:box[3], box[0]:box[2]]
         return array

@@ -222,6 +222,16 @@ def test_image_reads_files_like_arrays(tmp_path):
     assert glimpse_amd.Image(tmp_path / "g.png", cam=glimpse_amd.Camera(imgsz=(20, 15), f=100), datetime=T0).read().shape[:2] == (15, 20)
     with pytest.raises(ValueError):
         glimpse_amd.Image(cam=cam, datetime=T0)
+    # an in-memory image under a resized camera: the caller's pixels stay, the resampled copy is cached beside them
+    cam2 = glimpse_amd.Camera(imgsz=(40, 30), f=100)
+    mem = glimpse_amd.Image(cam=cam2, datetime=T0, array=gray.copy() if "gray" in dir() else np.arange(1200, dtype=np.uint8).reshape(30, 40))
+    full = mem.read().copy()
+    cam2.resize(0.5)
+    half = mem.read()
+    assert half.shape == (15, 20) and mem.array.shape == (30, 40)
+    np.testing.assert_array_equal(mem.read(), half)
+    cam2.resize(1)
+    np.testing.assert_array_equal(mem.read(), full)
 
 
 def test_nearest_in_sorted_equals_the_distance_matrix_argmin():

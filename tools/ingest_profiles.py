@@ -27,7 +27,7 @@ def main():
         shutil.copy(os.path.join(src, f"{w}_trace", "t_kernel_stats.csv"), os.path.join(prof, f"{tag}_{w}_kernel_stats.csv"))
         line = json.load(open(bench))
         # launches of the dominant kernel before the timed region (warm-up steps + burn-in), as the bench line reports them
-        warm = int(line["config"]["untimed_launches"])
+        warm = int(line["config"].get("untimed_kernel_launches", line["config"]["untimed_launches"]))
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), f"{tag}_{w}", key,
                         os.path.join(src, f"{w}_trace", "t_kernel_trace.csv"),
                         os.path.join(src, f"{w}_fetch", "f_counter_collection.csv"),
@@ -39,6 +39,13 @@ def main():
               f"({k['launches']} launches)  frac {line['roofline']['frac']:.4f}  "
               f"traffic {k.get('hbm_bytes_per_launch', 0) / 1e9:.3f} GB vs algorithmic "
               f"{line['roofline']['algorithmic_bytes_per_launch'] / 1e9:.3f} GB")
+    one = os.path.join(src, "C3s1_bench.json")  # the headline configuration with one launch per frame (--streams 1)
+    if os.path.exists(one):
+        shutil.copy(one, os.path.join(prof, f"{tag}_C3_one_stream_bench.json"))
+        shutil.copy(os.path.join(src, "C3s1_trace", "t_kernel_stats.csv"), os.path.join(prof, f"{tag}_C3_one_stream_kernel_stats.csv"))
+        line = json.load(open(one))
+        print(f"C3 one stream: avg_launch_ms {line['roofline']['avg_launch_ms']:.4f} frac {line['roofline']['frac']:.4f} "
+              f"first steps {line.get('first_steps_ms')}")
     full = os.path.join(src, "C3_full.json")
     if os.path.exists(full):
         shutil.copy(full, os.path.join(prof, f"{tag}_C3_full_bench.json"))
@@ -50,9 +57,18 @@ def main():
                 if "k_point_step" in row["Kernel_Name"]:
                     vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
         n = min(len(v) for v in vals.values())
-        timed = {k: v[-99:] if n > 99 else v for k, v in vals.items()}
-        out = {k: sum(v) / len(v) for k, v in sorted(timed.items())}
-        out["note"] = (f"mean over the {len(next(iter(timed.values())))} timed launches of: rocprofv3 --kernel-trace --pmc "
+        # launches of a frame update (two streams: two launches of half the points each): the figures below are PER FRAME
+        # UPDATE, i.e. the sum over a frame's launches
+        try:
+            line = json.load(open(os.path.join(src, "C3_bench.json")))
+            lpf = int(round(line["roofline"]["launches_per_step"] / line["config"]["frame_updates_per_step"]))
+        except (OSError, ValueError, KeyError):
+            lpf = 1
+        last = 99 * lpf
+        timed = {k: v[-last:] if n > last else v for k, v in vals.items()}
+        out = {k: lpf * sum(v) / len(v) for k, v in sorted(timed.items())}
+        out["launches_per_frame_update"] = lpf
+        out["note"] = (f"per frame update (sum of its {lpf} launch(es)), mean over the {len(next(iter(timed.values())))} timed launches of: rocprofv3 --kernel-trace --pmc "
                        + " ".join(sorted(vals)) + " -- python3 bench.py --no-cpu-baseline --no-api (C3, 100 frames from the "
                        "prior, GLH_MATH_FAST); SQ_*_CYCLES in quad-cycles")
         out["derived"] = {

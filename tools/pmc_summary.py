@@ -71,6 +71,11 @@ def main():
         table = {}
     table[key] = {k: {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json"}
                   for k, e in summary["kernels"].items() if "hbm_bytes_per_launch" in e}
+    # (a launch of k_point_step is what glh_track enqueues: with two streams, half of the points -- bench.py multiplies
+    # by the launches of a frame)
+    import datetime
+    table["_meta"] = {"collected": "round 4, " + datetime.date.today().isoformat(),
+                      "launch": "one k_point_step launch as glh_track enqueues it (two streams: half of the points)"}
     with open(table_path, "w") as f:
         json.dump(table, f, indent=1)
     print(json.dumps(summary, indent=1))
