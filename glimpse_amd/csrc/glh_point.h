@@ -461,17 +461,16 @@ template <int TB, typename T>
 __device__ __forceinline__ void pt_stage(T* dst, const T* src, int n) {
   const int tid = threadIdx.x;
   for (int base = 0; base < n; base += 4 * TB) {
-    T v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      v[q] = src[idx < n ? idx : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      if (idx < n) dst[idx] = v[q];
-    }
+    const int i0 = base + tid, i1 = i0 + TB, i2 = i1 + TB, i3 = i2 + TB;
+    // (four named values: an array here is left in scratch memory by the line below)
+    const T v0 = src[i0 < n ? i0 : 0], v1 = src[i1 < n ? i1 : 0], v2 = src[i2 < n ? i2 : 0], v3 = src[i3 < n ? i3 : 0];
+    // the loads stay above this line: left alone, the compiler sinks each into its guarded store -- load, wait, store,
+    // four times over
+    asm volatile("" ::: "memory");
+    if (i0 < n) dst[i0] = v0;
+    if (i1 < n) dst[i1] = v1;
+    if (i2 < n) dst[i2] = v2;
+    if (i3 < n) dst[i3] = v3;
   }
 }
 
@@ -689,6 +688,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   constexpr bool COMMON = CONTRACT;
   const int rng_mode = COMMON ? (int)GLH_RNG_PHILOX : a.rng_mode;
   PT_STAMP(0);
+  const uint16_t* uin = COMMON || a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
+  int rec_first = 0;  // (common instantiation: the record of this thread's first particle, see below)
+  if constexpr (COMMON) rec_first = (int)uin[tid < N ? tid : 0];
   if (tid == 0) {
     if (rng_mode == GLH_RNG_HOST) {
       s_u = a.u[pt];
@@ -699,17 +701,17 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       s_u = u01_halfopen(r[0], r[1]);
     }
   }
-  for (int k = tid; k < 16 * GLH_NPOLY; k += TB) tab[k] = a.poly[k];
+  // Round 4: every table of the prologue is REQUESTED before the first of them is stored (poly, motion parameters,
+  // cameras, the record indices below).  Written as load-store pairs, each pair waited for its own memory latency before
+  // the next load was issued: four latencies in a row at the head of every workgroup.
+  static_assert(16 * GLH_NPOLY <= 512, "one entry of the basis table per thread");
+  static_assert(sizeof(CamDev) % 8 == 0, "CamDev is copied as doubles");
+  constexpr int CW = sizeof(CamDev) / 8;
+  static_assert(PT_MAX_OBS * CW <= 512, "one camera word per thread");
+  const double pro_poly = tid < 16 * GLH_NPOLY ? a.poly[tid] : 0.0;
+  const double pro_motion = tid < GLH_MOTION_FULL_LEN ? a.motion[(size_t)pt * GLH_MOTION_FULL_LEN + tid] : 0.0;
+  const double pro_cam = tid < NOBS * CW ? reinterpret_cast<const double*>(&a.cam[0])[tid] : 0.0;
   if (FAST) exp_table_fill(tab32);
-  if (tid < GLH_MOTION_FULL_LEN) s_m[tid] = a.motion[(size_t)pt * GLH_MOTION_FULL_LEN + tid];
-  {
-    static_assert(sizeof(CamDev) % 8 == 0, "CamDev is copied as doubles");
-    constexpr int CW = sizeof(CamDev) / 8;
-    if (tid < NOBS * CW) {
-      const int o = tid / CW, k = tid - o * CW;
-      reinterpret_cast<double*>(&s_cam[o])[k] = reinterpret_cast<const double*>(&a.cam[o])[k];
-    }
-  }
   // the pairwise-sum plan (phase D) is read level by level between barriers: from LDS, not from HBM
   int32_t* p_leaf_off = reinterpret_cast<int32_t*>(r2 + a.r2_bytes);
   int32_t* p_leaf_len = p_leaf_off + a.nleaves;
@@ -725,12 +727,50 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if (tid <= a.nlevels) p_level_off[tid] = a.level_off[tid];
     if (tid < a.nroots) p_roots[tid] = a.roots[tid];
   }
+  // record of every particle (compact input state): staged in region 2, which is free until phase B
+  int hist_n0, valid_o;
+  uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
+  {
+    // the record indices as 16-byte words (the rows of uidx are N uint16 apart), up to four per thread (N <= 16 384),
+    // requested with the tables above; THEN everything is stored
+    const bool words = (COMMON || uin) && (N & 7) == 0 && (N >> 3) <= 4 * TB;  // uniform
+    const int nw = N >> 3;
+    const uint4* uw = reinterpret_cast<const uint4*>(uin);
+    uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0, w2 = w0, w3 = w0;
+    if (words) {
+      w0 = uw[tid < nw ? tid : 0];
+      w1 = uw[tid + TB < nw ? tid + TB : 0];
+      if (nw > 2 * TB) {  // uniform (N > 8192 at 512 threads)
+        w2 = uw[tid + 2 * TB < nw ? tid + 2 * TB : 0];
+        w3 = uw[tid + 3 * TB < nw ? tid + 3 * TB : 0];
+      }
+    }
+    // (fetched here, used at the end of phase A: no memory latency between the last particle and the search box -- and
+    // behind the loads above: a uniform value is waited for where it is defined)
+    valid_o = tid < NOBS ? (int)a.tmpl_valid[(size_t)tid * a.P + pt] : 0;
+    hist_n0 = a.tmpl_hist_n[pt];  // (last: uniform, hence waited for at once -- with everything requested above)
+    asm volatile("" : "+v"(valid_o));  // (not examined before this point: its test would wait for it on its own)
+    asm volatile("" ::: "memory");  // (the loads above stay above the stores below)
+    if (tid < 16 * GLH_NPOLY) tab[tid] = pro_poly;
+    if (tid < GLH_MOTION_FULL_LEN) s_m[tid] = pro_motion;
+    if (tid < NOBS * CW) reinterpret_cast<double*>(&s_cam[0])[tid] = pro_cam;
+    if (words) {
+      uint4* sw = reinterpret_cast<uint4*>(s_rec);
+      if (tid < nw) sw[tid] = w0;
+      if (tid + TB < nw) sw[tid + TB] = w1;
+      if (nw > 2 * TB) {
+        if (tid + 2 * TB < nw) sw[tid + 2 * TB] = w2;
+        if (tid + 3 * TB < nw) sw[tid + 3 * TB] = w3;
+      }
+    } else if (COMMON || uin) {
+      pt_stage<TB>(s_rec, uin, N);
+    } else {
+      for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
+    }
+  }
   bool live[NOBS];  // uniform across the block
 #pragma unroll
   for (int o = 0; o < NOBS; ++o) live[o] = COMMON || (a.obs[o].on && (!a.obs_mask || a.obs_mask[(size_t)pt * a.O + o]));
-  // fetched here, used at the end of phase A: no memory latency between the last particle and the search box
-  const int hist_n0 = a.tmpl_hist_n[pt];
-  const int valid_o = tid < NOBS ? (int)a.tmpl_valid[(size_t)tid * a.P + pt] : 0;
   // Template tile (zero padded rows) and template CDF of one observer into the head of region 2: [T | cq | cv].
   // The usual sizes (two entries per thread): every load of this thread is in flight before the first LDS store (one
   // memory latency instead of four) -- and, in two halves, observer 0's loads are issued at the end of phase A, so
@@ -793,19 +833,17 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
   };
-  // record of every particle (compact input state): staged in region 2, which is free until phase B -- together with
-  // the tables above, so that the kernel starts with one memory latency, not two
-  const uint16_t* uin = COMMON || a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
-  uint16_t* s_rec = reinterpret_cast<uint16_t*>(r2);
-  if (COMMON || uin) {
-    if ((N & 7) == 0)  // whole 16-byte words (the rows of uidx are N uint16 apart): every load of a thread in flight at once
-      pt_stage<TB>(reinterpret_cast<uint4*>(s_rec), reinterpret_cast<const uint4*>(uin), N >> 3);
-    else
-      pt_stage<TB>(s_rec, uin, N);
+  // Round 4 (common instantiation): the thread's FIRST record is requested before the barrier -- its index was fetched at
+  // the top of the kernel, straight from memory, not through the staged copy -- and the barrier waits for the LDS
+  // stores only: the kernel starts with ONE memory latency where it had two (tables, then records).
+  double2 pf0, pf1, pf2;
+  if constexpr (COMMON) {
+    const double2* src = reinterpret_cast<const double2*>(Pin) + (size_t)rec_first;
+    pf0 = src[0]; pf1 = src[N]; pf2 = src[2 * N];
+    pt_lds_barrier();
   } else {
-    for (int k = tid; k < N; k += TB) s_rec[k] = (uint16_t)k;
+    __syncthreads();
   }
-  __syncthreads();
   PT_STAMP(15);
 
   // (the tangent models have no log-likelihood term: Motion.compute_log_likelihoods returns None, tracker.py:146)
@@ -857,7 +895,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
     double2 nx0, nx1, nx2;
-    {
+    if constexpr (COMMON) {
+      nx0 = pf0; nx1 = pf1; nx2 = pf2;  // (requested before the prologue's barrier)
+    } else {
       const double2* src = Pin2 + (size_t)s_rec[tid < N ? tid : 0] * rec_stride;
       nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
     }
