@@ -1090,8 +1090,15 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const bool fits = !wide && !flt && off + s_bytes + (l1 > l2 ? l1 : l2) <= a.r2_bytes;
     const double* hv_g = a.tmpl_hist_v + slot * a.tile_cap;
     const double* hq_g = a.tmpl_hist_q + slot * a.tile_cap;
-    const double* fh_g = a.lu + a.lu_off[ho];
-    const double* fw_g = a.lu + a.lu_off[wo];
+    // (the offsets of the banded LU factors are uniform loads from memory, waited for where they are made: only the
+    // surfaces that are fitted by banded solves fetch them -- made here for all, they were a memory latency at the head
+    // of every tile pipeline)
+    const double *fh_g = nullptr, *fw_g = nullptr;
+    const bool need_lu = !(SURF && a.interp_k == 1) && !spline_dense(ho, wo);  // uniform: a banded fit
+    if (need_lu) {
+      fh_g = a.lu + a.lu_off[ho];
+      fw_g = a.lu + a.lu_off[wo];
+    }
     if (o == 0 && tmpl_early)
       tmpl_store(hist_n0, tmpl0);  // (issued at the end of phase A)
     else
@@ -1102,7 +1109,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       constexpr bool CELLS = decltype(cells_tag)::value;  // Z = the per-cell power form, not the coefficients
       // geometry is derived here, not before the tile stages: nothing extra stays live across them
       double sb[4];
-      sse_box_of(box, a.tmpl_duv + slot * 2, tw, th, sb);
+      // (one 16-byte load: as two uniform words each was waited for on its own)
+      const double2 dv = *reinterpret_cast<const double2*>(a.tmpl_duv + slot * 2);
+      const double duv[2] = {dv.x, dv.y};
+      sse_box_of(box, duv, tw, th, sb);
       const double cu0 = cell_origin(sb[0], sb[2], wo), cv0 = cell_origin(sb[1], sb[3], ho);
       const double scale = a.inv2s2[o];
       const double2* uvp = reinterpret_cast<const double2*>(a.uv) + slot * N;
@@ -1251,14 +1261,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.iw = a.inv + spline_inverse_off(wo);
       // X is reused: the histogram / keys are dead once the search tile is written.  The LU factors are
       // fetched before the SSD and parked in LDS after it, so their memory latency hides behind it.
-      const int nfl = dense ? 0 : 5 * (ho + wo);
+      const int nfl = need_lu ? 5 * (ho + wo) : 0;
       double fl_v = 0.0;
       double* park = nullptr;
       if (inv_lds) {
         if (tid < ho * ho) fl_v = ws.ih[tid];
         else if (tid < ninv) fl_v = ws.iw[tid - ho * ho];
         if (tid < ninv) park = invl + tid;
-      } else if (dense) {
+      } else if (!need_lu) {
       } else if (nfl <= TB) {
         if (tid < nfl) park = fl + tid;
         if (tid < 5 * ho) fl_v = fh_g[tid];
@@ -1391,7 +1401,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         double* Zl = reinterpret_cast<double*>(r2);
         double* fl = Zl + zb / 8;
         pt_stage<TB>(Zl, static_cast<const double*>(ws.Z), ho * wo);
-        if (!dense) {
+        if (need_lu) {
           for (int k = tid; k < 5 * ho; k += TB) fl[k] = fh_g[k];
           for (int k = tid; k < 5 * wo; k += TB) fl[5 * ho + k] = fw_g[k];
           ws.fh = fl;
