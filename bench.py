@@ -210,6 +210,20 @@ def pmc_traffic(wl, kernel):
     return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
+def pmc_traffic_per_frame(wl, kernel):
+    """HBM bytes of one frame update of all of `wl`'s points from the committed PMC passes: the per-launch figure scaled
+    by the points a launch of the profiled run held (two streams: half of them), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get(f"{wl.name}:{wl.P}x{wl.N}", {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if entry is None or "hbm_bytes_per_launch" not in entry:
+        return None
+    return entry["hbm_bytes_per_launch"] * wl.P / float(entry.get("points_per_launch", wl.P))
+
+
 def pmc_traffic_source(wl, kernel):
     """Where `roofline.traffic` comes from: NOT this run -- the PMC passes are separate rocprofv3 runs of the same
     command on the builder's GPU box, committed under profiles/."""
@@ -620,7 +634,7 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     per_launch = dom_ms / max(dom_n, 1)
     gpu_per_frame = span_ms / (n_frames - 1) if streams > 1 else per_launch  # (two streams: the launches overlap)
     kern = KERNEL_OF_STAGE.get(dom, dom)
-    traffic = pmc_traffic(wl, kern) if math == "fast" and wl.channels == 1 and wl.bits == 8 else None
+    traffic = pmc_traffic_per_frame(wl, kern) if math == "fast" and wl.channels == 1 and wl.bits == 8 else None
     moments = ctx.get_moments(0, n_frames)
     leg = {
         "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
@@ -630,7 +644,7 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
         "value": wl.P * wl.N * (n_frames - 1) / wall,
         "roofline_frac": abytes / (gpu_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": abytes,
-        "traffic_ratio": None if traffic is None else traffic * (dom_n / max(n_frames - 1, 1)) / abytes,
+        "traffic_ratio": None if traffic is None else traffic / abytes,
         "observer_ok_fraction": float((status == 0).mean()),
         "points_with_error_bits": int((ctx.point_status() != 0).sum()),
         "final_means_finite": bool(np.isfinite(moments[n_frames - 1]).all()),
@@ -904,8 +918,7 @@ def worker(args):
         # share of the chip is under `per_launch`.
         # HBM bytes of a frame from the committed PMC passes: per launch x the launches of a frame (like `achieved`, which
         # is the bytes of a frame over the time of a frame)
-        per_launch_traffic = pmc_traffic(wl, kern) if wl.channels == 1 and wl.bits == 8 else None
-        traffic = None if per_launch_traffic is None else per_launch_traffic * launches_per_frame
+        traffic = pmc_traffic_per_frame(wl, kern) if wl.channels == 1 and wl.bits == 8 else None
         span_per_frame_ms = span_ms / (K * F)
         per_launch_ach = abytes / launches_per_frame / (per_launch_ms * 1e-3) / 1e9
         ach = abytes / (span_per_frame_ms * 1e-3) / 1e9 if streams > 1 else per_launch_ach

@@ -35,6 +35,13 @@ def main():
                        check=True, stdout=subprocess.DEVNULL)
         s = json.load(open(os.path.join(prof, f"{tag}_{w}_summary.json")))
         k = s["kernels"]["k_point_step"]
+        # the points of one launch (two streams: half the batch): bench.py scales the per-launch traffic by it
+        tpath = os.path.join(prof, "pmc_traffic.json")
+        table = json.load(open(tpath))
+        if key in table and "k_point_step" in table[key]:
+            table[key]["k_point_step"]["points_per_launch"] = line["roofline"].get("per_launch", {}).get(
+                "points", line["config"]["points_per_gpu"])
+            json.dump(table, open(tpath, "w"), indent=1)
         print(f"{w}: bench avg_launch_ms {line['roofline']['avg_launch_ms']:.4f}  rocprof mean_ms_timed {k['mean_ms_timed']:.4f} "
               f"({k['launches']} launches)  frac {line['roofline']['frac']:.4f}  "
               f"traffic {k.get('hbm_bytes_per_launch', 0) / 1e9:.3f} GB vs algorithmic "
