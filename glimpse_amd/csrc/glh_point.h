@@ -318,36 +318,25 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   TP_STAMP(13);
   pt_border_cols<TB>(keys, wp, w, h);
   {
-    // inclusive scan of the nb <= 2 * TB bins: two bins per thread + block scan
-    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    // inclusive scan of the nb <= 2 * TB bins -- one bin per thread (gray: 256 bins) or two (RGB: 766) + block scan --
+    // and, with the counts of the own bins still in registers, their LUT entries at once: np.cumsum(counts) / a.size
+    // through np.interp of the template CDF.  (Round 4: the cumulative counts used to be written out, a barrier, and
+    // the LUT made by whoever read them back.)
+    const bool one = nb <= TB;  // uniform
+    const int b0 = one ? tid : 2 * tid, b1 = one ? nb : 2 * tid + 1;
     const uint32_t h0 = b0 < nb ? ws.hist[b0] : 0u, h1 = b1 < nb ? ws.hist[b1] : 0u;
     const uint32_t local = h0 + h1;
     const uint32_t incl = wave_scan_add_u32(local);
     const int lane = tid & (WAVE - 1);
     if (lane == WAVE - 1) scan_tmp[tid / WAVE] = incl;
-    __syncthreads();
+    __syncthreads();  // (also: the column borders are in place)
     uint32_t base = 0;
     for (int wv = 0; wv < tid / WAVE; ++wv) base += scan_tmp[wv];
     const uint32_t excl = base + incl - local;
-    if (b0 < nb) ws.cum[b0] = excl + h0;
-    if (b1 < nb) ws.cum[b1] = excl + local;
-    if (ws.cum == ws.hist) {
-      // cumulative counts in place (pt_cum_in_place): the counts of the own bins are still in registers, so their
-      // LUT entries are made here, from the template CDF -- same operations as the loop below
-      if (h0) ws.lut[b0] = np_interp((double)(excl + h0) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
-      if (h1) ws.lut[b1] = np_interp((double)(excl + local) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
-    }
+    if (h0) ws.lut[b0] = np_interp((double)(excl + h0) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
+    if (h1) ws.lut[b1] = np_interp((double)(excl + local) / (double)n, ws.cdf_q, ws.cdf_v, hist_n);
   }
-  __syncthreads();
-  pt_border_rows<TB>(keys, wp, h);  // (the column borders are in place)
-  if (ws.cum != ws.hist) {
-    for (int b = tid; b < nb; b += TB) {
-      if (ws.hist[b]) {
-        const double q = (double)ws.cum[b] / (double)n;  // np.cumsum(counts) / a.size
-        ws.lut[b] = np_interp(q, ws.cdf_q, ws.cdf_v, hist_n);
-      }
-    }
-  }
+  pt_border_rows<TB>(keys, wp, h);
   __syncthreads();
   TP_STAMP(14);
   pt_highpass_write<TB, GEN>(ws, keys, wp, w, h, hp_rx, hp_ry, nb - 1, [&](int k) -> double { return ws.lut[k]; });
@@ -1547,16 +1536,23 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   PT_STAMP(11);
   // element k's cumulative weight: the running sum of its segment, shifted by the segments before it
   // (thread 0's running sums are used as they are)
-  double* clast = node + a.nnodes;  // [TB] last cumulative weight of every segment
-  clast[tid] = tid > 0 ? excl + run : run;
-  if (FAST && tid == TB - 1) s_scale = (double)N / (excl + run);  // N / sum of the weights
-  PT_STAMP(12);
-  const double u = s_u;  // the point's resample offset (drawn once, in the prologue)
-  const double inv_n = 1.0 / (double)N;
-  // Region 2 once the tree nodes and clast are dead: N uint16 (rank per output) and N uint32 (source and copies per rank).
+  // Region 2 once the tree nodes are dead: N uint16 (rank per output) and N uint32 (source and copies per rank).
   const int n16 = pt_align16(N * 2) / 2;
   uint16_t* ufill = reinterpret_cast<uint16_t*>(r2);  // rank + 1 of the source that serves output j
   uint32_t* usc = reinterpret_cast<uint32_t*>(ufill + n16);  // rank h: its source | copies of it << 16 (one word)
+  // clast [TB]: the last cumulative weight of every segment.  Behind the rank tables when region 2 has the room (all but
+  // the largest particle counts): the rank table can then be cleared here, a barrier earlier than where clast is dead
+  // (round 4: one barrier less); otherwise over the tree nodes, as before.
+  const int tables_bytes = pt_align16(n16 * 2 + N * 4);
+  const bool clast_behind = tables_bytes + TB * (int)sizeof(double) <= a.r2_bytes;  // uniform
+  double* clast = clast_behind ? reinterpret_cast<double*>(r2 + tables_bytes) : node + a.nnodes;
+  clast[tid] = tid > 0 ? excl + run : run;
+  if (FAST && tid == TB - 1) s_scale = (double)N / (excl + run);  // N / sum of the weights
+  if (clast_behind)  // (every thread has read the tree's total before the barrier above)
+    for (int q = tid; q < n16 / 8; q += TB) reinterpret_cast<uint4*>(ufill)[q] = make_uint4(0u, 0u, 0u, 0u);  // (n16: whole 16-byte words)
+  PT_STAMP(12);
+  const double u = s_u;  // the point's resample offset (drawn once, in the prologue)
+  const double inv_n = 1.0 / (double)N;
   __shared__ int s_U;
   {
     // f(ck) = #{j : pos_j <= ck}, pos_j = (j + u) * (1 / n) exactly as tracker.py:173 rounds it.  The guess
@@ -1627,11 +1623,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     int rank = incl_s - nsurv;
     for (int w = 0; w < wave; ++w) rank += (int)scan_tmp[w];
     if (tid == TB - 1) s_U = rank + nsurv;
-    for (int q = tid; q < n16 / 8; q += TB) reinterpret_cast<uint4*>(ufill)[q] = make_uint4(0u, 0u, 0u, 0u);  // (n16: whole 16-byte words)
-    pt_lds_barrier();
-    if (s_U == 0 && tid == 0) {  // no comparison succeeded (NaN weights): every output is a copy of source 0
-      usc[0] = (uint32_t)N << 16;
-      ufill[0] = 1;
+    if (!clast_behind) {  // (the rank table lies over clast: cleared only now)
+      for (int q = tid; q < n16 / 8; q += TB) reinterpret_cast<uint4*>(ufill)[q] = make_uint4(0u, 0u, 0u, 0u);
+      pt_lds_barrier();
     }
     // pass 2: survivors take their rank
     {
@@ -1666,6 +1660,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     pt_lds_barrier();
+    if (s_U == 0 && tid == 0) {  // no comparison succeeded (NaN weights): every output is a copy of source 0
+      usc[0] = (uint32_t)N << 16;  // (thread 0 owns the first segment: it reads this entry of ufill itself)
+      ufill[0] = 1;
+    }
     // Whole segments of an even length up to 10 (the benched shapes): the segment as 32-bit words, its prefix
     // maxima kept in registers until the maxima of the segments before it are known -- one read and one write per
     // word instead of two reads and two writes per entry.
@@ -1692,7 +1690,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
     }
     const uint32_t incl_m = wave_scan_max_u32(runmax);
-    pt_lds_barrier();  // scan_tmp is reused: the survivor scan has been consumed
+    // (scan_tmp is reused: every thread consumed the survivor scan before the barrier behind pass 2)
     if (lane == WAVE - 1) scan_tmp[wave] = incl_m;
     uint32_t before = wave_shr1_u32(incl_m);
     pt_lds_barrier();
