@@ -1,8 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export GLH_FRAME_CACHE=/tmp/glhfc
-python -m pytest tests/test_gpu_fused.py tests/test_gpu_pinned.py tests/test_gpu_streams.py tests/test_gpu_fullsize.py tests/test_gpu_benched_instantiations.py tests/test_gpu_fast_math.py -x -q -m gpu > gpurun_out/r4j24_tests.log 2>&1
-tail -3 gpurun_out/r4j24_tests.log
+python -m pytest tests/test_gpu_fused.py tests/test_gpu_pinned.py tests/test_gpu_streams.py tests/test_gpu_fullsize.py tests/test_gpu_benched_instantiations.py tests/test_gpu_fast_math.py -x -q -m gpu > gpurun_out/r4j25_tests.log 2>&1
+tail -3 gpurun_out/r4j25_tests.log
 for w in "" "--workload C4" "--workload C5 --points 2048" "--streams 1" "--workload C2"; do
   echo "--- $w"; AB_ENVS="prev.so" tools/ab.sh --no-secondary $w 2>/dev/null | grep -v "^base"
-done | tee gpurun_out/r4j24_ab_prefetch.txt
+done | tee gpurun_out/r4j25_ab_prefetch.txt
