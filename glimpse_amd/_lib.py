@@ -103,6 +103,7 @@ SIGNATURES = {
     "glh_set_fused": (_I, [_P, _I]),
     "glh_set_math": (_I, [_P, _I]),
     "glh_set_highpass": (_I, [_P, _I, _I]),
+    "glh_set_highpass_mode": (_I, [_P, _I]),
     "glh_set_interpolation": (_I, [_P, _I, _I]),
     "glh_debug_phase_stamps": (_I, [_P, _P]),
     "glh_debug_draws": (_I, [_P, _I, _U64, _U64, _P]),
@@ -137,8 +138,8 @@ SIGNATURES = {
     "glh_stage_unproject": (_I, [_I, _P, _P, _I, _P, _I, _I, _P]),
     "glh_stage_template": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "glh_stage_search_tile": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
-    "glh_stage_template_highpass": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
-    "glh_stage_search_tile_highpass": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "glh_stage_template_highpass": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "glh_stage_search_tile_highpass": (_I, [_I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "glh_stage_ssd": (_I, [_I, _P, _I, _I, _P, _I, _I, _P]),
     "glh_stage_sample": (_I, [_I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "glh_stage_sample_orders": (_I, [_I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
@@ -472,10 +473,12 @@ class Context:
         """"exact" (NumPy rounding; default) or "fast" (FMA / reciprocal arithmetic for device-RNG runs)."""
         check(self.lib.glh_set_math(self.handle, {"exact": MATH_EXACT, "fast": MATH_FAST}[mode]))
 
-    def set_highpass(self, size=(5, 5)):
-        """Window of the median high-pass filter, scipy order (rows, columns); odd sizes up to 7."""
+    def set_highpass(self, size=(5, 5), mode="reflect"):
+        """Window of the median high-pass filter, scipy order (rows, columns); odd sizes up to 7.  `mode`: scipy.ndimage's
+        boundary mode -- "reflect" (its default), "nearest", "mirror" or "wrap"."""
         sy, sx = (int(size), int(size)) if np.isscalar(size) else (int(size[0]), int(size[1]))
         check(self.lib.glh_set_highpass(self.handle, sx, sy))
+        check(self.lib.glh_set_highpass_mode(self.handle, HIGHPASS_MODES[mode]))
 
     def set_point_offset(self, offset):
         check(self.lib.glh_set_point_offset(self.handle, int(offset)))
@@ -685,11 +688,16 @@ def _frame_dims(frame):
     return frame, w, h, ch
 
 
+# scipy.ndimage boundary modes of the median high-pass the device implements (glh_set_highpass_mode); the grid-* names are
+# scipy's aliases
+HIGHPASS_MODES = {"reflect": 0, "grid-mirror": 0, "nearest": 1, "mirror": 2, "wrap": 3, "grid-wrap": 3}
+
+
 def _highpass_xy(size):
     return (int(size), int(size)) if np.isscalar(size) else (int(size[1]), int(size[0]))  # scipy: (rows, columns)
 
 
-def stage_template(frame, box, device_id=0, highpass=(5, 5)):
+def stage_template(frame, box, device_id=0, highpass=(5, 5), mode="reflect"):
     frame, w, h, ch = _frame_dims(frame)
     sx, sy = _highpass_xy(highpass)
     box = _arr(box, np.int32, (4,))
@@ -698,12 +706,12 @@ def stage_template(frame, box, device_id=0, highpass=(5, 5)):
     hv = np.empty(tw * th)
     hq = np.empty(tw * th)
     hn = C.c_int32()
-    check(load().glh_stage_template_highpass(device_id, _ptr(frame), w, h, ch, _ptr(box), sx, sy, _ptr(tile), _ptr(hv),
-                                             _ptr(hq), C.byref(hn)))
+    check(load().glh_stage_template_highpass(device_id, _ptr(frame), w, h, ch, _ptr(box), sx, sy, HIGHPASS_MODES[mode],
+                                             _ptr(tile), _ptr(hv), _ptr(hq), C.byref(hn)))
     return tile, (hv[: hn.value].copy(), hq[: hn.value].copy())
 
 
-def stage_search_tile(frame, box, histogram, device_id=0, highpass=(5, 5)):
+def stage_search_tile(frame, box, histogram, device_id=0, highpass=(5, 5), mode="reflect"):
     frame, w, h, ch = _frame_dims(frame)
     sx, sy = _highpass_xy(highpass)
     box = _arr(box, np.int32, (4,))
@@ -711,7 +719,7 @@ def stage_search_tile(frame, box, histogram, device_id=0, highpass=(5, 5)):
     hq = _arr(histogram[1], np.float64)
     out = np.empty((int(box[3] - box[1]), int(box[2] - box[0])), dtype=np.float32)
     check(load().glh_stage_search_tile_highpass(device_id, _ptr(frame), w, h, ch, _ptr(box), _ptr(hv), _ptr(hq),
-                                                len(hv), sx, sy, _ptr(out)))
+                                                len(hv), sx, sy, HIGHPASS_MODES[mode], _ptr(out)))
     return out
 
 

@@ -660,15 +660,16 @@ struct TemplateOut {
 // Tracker(highpass={"size": ...}), tracker.py:59, :530).  Any odd size up to 7 x 7: the smallest key with at least
 // half the window at or below it, by bisection over the key range (the 5 x 5 default has its own network).
 __device__ __forceinline__ int median_window(const uint16_t* keys, int ld, int row0, int w, int h, int r, int c,
-                                             int rx, int ry, int max_key) {
+                                             int rx, int ry_mode, int max_key) {
+  const int ry = GLH_HP_RY(ry_mode), mode = GLH_HP_MODE(ry_mode);  // (the boundary mode rides in the half height)
   const int need = ((2 * rx + 1) * (2 * ry + 1) + 1) / 2;
   int lo = 0, hi = max_key;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     int cnt = 0;
     for (int dr = -ry; dr <= ry; ++dr) {
-      const uint16_t* row = keys + (reflect_index(r + dr, h) - row0) * ld;
-      for (int dc = -rx; dc <= rx; ++dc) cnt += row[reflect_index(c + dc, w)] <= mid;
+      const uint16_t* row = keys + (border_index(r + dr, h, mode) - row0) * ld;
+      for (int dc = -rx; dc <= rx; ++dc) cnt += row[border_index(c + dc, w, mode)] <= mid;
     }
     if (cnt >= need)
       hi = mid;
@@ -783,16 +784,17 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* tm
 
 // The same median by bisection over the key range [0, key_max]: no private array (median_window32 below gathers the
 // window into 49 ints with dynamic indices -- scratch memory, which the fused kernel must not reserve)
-__device__ __forceinline__ int median_window32_bisect(const uint32_t* keys, int ld, int w, int h, int r, int c, int rx, int ry,
-                                                      int key_max) {
+__device__ __forceinline__ int median_window32_bisect(const uint32_t* keys, int ld, int w, int h, int r, int c, int rx,
+                                                      int ry_mode, int key_max) {
+  const int ry = GLH_HP_RY(ry_mode), mode = GLH_HP_MODE(ry_mode);
   const int need = ((2 * rx + 1) * (2 * ry + 1) + 1) / 2;
   int lo = 0, hi = key_max;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     int cnt = 0;
     for (int dr = -ry; dr <= ry; ++dr) {
-      const uint32_t* row = keys + (size_t)reflect_index(r + dr, h) * ld;
-      for (int dc = -rx; dc <= rx; ++dc) cnt += (int)row[reflect_index(c + dc, w)] <= mid;
+      const uint32_t* row = keys + (size_t)border_index(r + dr, h, mode) * ld;
+      for (int dc = -rx; dc <= rx; ++dc) cnt += (int)row[border_index(c + dc, w, mode)] <= mid;
     }
     if (cnt >= need) hi = mid; else lo = mid + 1;
   }
@@ -801,12 +803,13 @@ __device__ __forceinline__ int median_window32_bisect(const uint32_t* keys, int 
 
 // median of the window around (r, c) of a w x h tile of 32-bit keys (row stride ld, tile row `row0` first)
 __device__ __forceinline__ int median_window32(const uint32_t* keys, int ld, int row0, int w, int h, int r, int c,
-                                               int rx, int ry) {
+                                               int rx, int ry_mode) {
+  const int ry = GLH_HP_RY(ry_mode), mode = GLH_HP_MODE(ry_mode);
   int v[49];
   const int nx = 2 * rx + 1, n = nx * (2 * ry + 1);
   for (int dr = -ry; dr <= ry; ++dr) {
-    const uint32_t* row = keys + (reflect_index(r + dr, h) - row0) * ld;
-    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = (int)row[reflect_index(c + dc, w)];
+    const uint32_t* row = keys + (border_index(r + dr, h, mode) - row0) * ld;
+    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = (int)row[border_index(c + dc, w, mode)];
   }
   if (rx == 2 && ry == 2) return median25(v);
   // any other odd window: the smallest element with at least half the window at or below it
@@ -1114,12 +1117,13 @@ __device__ __forceinline__ void normalize_box_float(const uint8_t* frame, int wi
 }
 
 // scipy.ndimage.median_filter(size = (2 ry + 1, 2 rx + 1), mode = 'reflect') of a w x h array of doubles at (r, c)
-__device__ __forceinline__ double median_window_f64(const double* a, int w, int h, int r, int c, int rx, int ry) {
+__device__ __forceinline__ double median_window_f64(const double* a, int w, int h, int r, int c, int rx, int ry_mode) {
+  const int ry = GLH_HP_RY(ry_mode), mode = GLH_HP_MODE(ry_mode);
   double v[49];
   const int nx = 2 * rx + 1, n = nx * (2 * ry + 1);
   for (int dr = -ry; dr <= ry; ++dr) {
-    const double* row = a + (size_t)reflect_index(r + dr, h) * w;
-    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = row[reflect_index(c + dc, w)];
+    const double* row = a + (size_t)border_index(r + dr, h, mode) * w;
+    for (int dc = -rx; dc <= rx; ++dc) v[(dr + ry) * nx + (dc + rx)] = row[border_index(c + dc, w, mode)];
   }
   const int need = (n + 1) / 2;  // the smallest element with at least half the window at or below it
   double best = INFINITY;
@@ -1477,13 +1481,16 @@ __device__ void search_tile_from_box(const uint8_t* frame, int width, int channe
   }
   __syncthreads();
   if (hp_rx != 2 || hp_ry != 2) {
-    // any other odd window up to 7 x 7: bands with a halo of hp_ry rows, median by bisection
+    // any other odd window up to 7 x 7 (or another boundary mode: it rides in hp_ry): bands with a halo of ry rows,
+    // median by bisection
+    const int hp_mode = GLH_HP_MODE(hp_ry);
+    hp_ry = GLH_HP_RY(hp_ry);
     const int max_key = channels == 1 ? 255 : 255 * channels;
     for (int r0 = 0; r0 < h; r0 += BAND_H) {
       const int rows = min(BAND_H, h - r0);
       for (int idx = tid; idx < (rows + 2 * hp_ry) * w; idx += BLK) {
         int br = idx / w, c = idx - br * w;
-        int rr = reflect_index(r0 + br - hp_ry, h);
+        int rr = border_index(r0 + br - hp_ry, h, hp_mode);
         band[idx] = (uint16_t)pixel_key(frame, width, channels, box[1] + rr, box[0] + c);
       }
       __syncthreads();
@@ -1496,7 +1503,7 @@ __device__ void search_tile_from_box(const uint8_t* frame, int width, int channe
           const int mid = (lo + hi) >> 1;
           int cnt = 0;
           for (int dr = 0; dr <= 2 * hp_ry; ++dr)
-            for (int dc = -hp_rx; dc <= hp_rx; ++dc) cnt += band[(br + dr) * w + reflect_index(c + dc, w)] <= mid;
+            for (int dc = -hp_rx; dc <= hp_rx; ++dc) cnt += band[(br + dr) * w + border_index(c + dc, w, hp_mode)] <= mid;
           if (cnt >= need) hi = mid; else lo = mid + 1;
         }
         const int key = band[(br + hp_ry) * w + c];

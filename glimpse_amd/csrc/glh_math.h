@@ -508,6 +508,31 @@ GLH_HD int reflect_index(int i, int n) {
   return i;
 }
 
+// The other boundary modes of scipy.ndimage.median_filter (Tracker(highpass={"size": ..., "mode": ...}), tracker.py:59,
+// :530): 'nearest' (a a a | a b c d | d d d), 'mirror' (d c b | a b c d | c b a), 'wrap' (a b c d | a b c d | a b c d).
+// The library carries the mode IN the window's half height: ry | mode << 4 (GLH_HP_RY / GLH_HP_MODE), so that every test
+// "is this the 5 x 5 default" (ry == 2) also asks for the default boundary, and only the window functions decode it.
+#define GLH_HP_REFLECT 0
+#define GLH_HP_NEAREST 1
+#define GLH_HP_MIRROR 2
+#define GLH_HP_WRAP 3
+#define GLH_HP_RY(packed) ((packed) & 15)
+#define GLH_HP_MODE(packed) ((packed) >> 4)
+GLH_HD int border_index(int i, int n, int mode) {
+  if (mode == GLH_HP_REFLECT) return reflect_index(i, n);
+  if (mode == GLH_HP_NEAREST) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+  if (mode == GLH_HP_MIRROR) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+      if (i < 0) i = -i;
+      if (i >= n) i = 2 * n - 2 - i;
+    }
+    return i;
+  }
+  i %= n;  // GLH_HP_WRAP
+  return i < 0 ? i + n : i;
+}
+
 // ---- not-a-knot bicubic spline (observer.py:210 == FITPACK regrid/bispev with s=0) ------
 // knot i (0 <= i < n+4) in unit-spaced local coordinates: [0]*4, 2..n-3, [n-1]*4
 GLH_HD double knot_local(int i, int n) {

@@ -1814,7 +1814,15 @@ extern "C" int glh_set_highpass(glh_ctx* c, int size_x, int size_y) {
   if (size_x < 1 || size_y < 1 || size_x > 7 || size_y > 7 || !(size_x & 1) || !(size_y & 1))
     return fail(GLH_E_UNSUPPORTED, "high-pass window %d x %d: sizes must be odd and at most 7", size_x, size_y);
   c->hp_rx = size_x / 2;
-  c->hp_ry = size_y / 2;
+  c->hp_ry = size_y / 2 | (GLH_HP_MODE(c->hp_ry) << 4);  // (the boundary mode rides in the half height: glh_math.h)
+  return GLH_OK;
+}
+
+extern "C" int glh_set_highpass_mode(glh_ctx* c, int mode) {
+  if (!c) return fail(GLH_E_INVALID, "null context");
+  if (mode < GLH_HP_REFLECT || mode > GLH_HP_WRAP)
+    return fail(GLH_E_UNSUPPORTED, "high-pass boundary mode %d: 0 reflect, 1 nearest, 2 mirror, 3 wrap", mode);
+  c->hp_ry = GLH_HP_RY(c->hp_ry) | (mode << 4);
   return GLH_OK;
 }
 
@@ -2279,14 +2287,15 @@ static int check_highpass(int size_x, int size_y) {
 
 extern "C" int glh_stage_template(int dev, const uint8_t* frame, int width, int height, int channels,
                                   const int32_t* box, double* tile, double* hv, double* hq, int32_t* hn) {
-  return glh_stage_template_highpass(dev, frame, width, height, channels, box, 5, 5, tile, hv, hq, hn);
+  return glh_stage_template_highpass(dev, frame, width, height, channels, box, 5, 5, GLH_HP_REFLECT, tile, hv, hq, hn);
 }
 
 extern "C" int glh_stage_template_highpass(int dev, const uint8_t* frame, int width, int height, int channels,
-                                           const int32_t* box, int size_x, int size_y, double* tile, double* hv,
+                                           const int32_t* box, int size_x, int size_y, int mode, double* tile, double* hv,
                                            double* hq, int32_t* hn) {
   if (!frame || !tile || !hv || !hq || !hn) return fail(GLH_E_INVALID, "null argument");
   CHK(check_highpass(size_x, size_y));
+  if (mode < GLH_HP_REFLECT || mode > GLH_HP_WRAP) return fail(GLH_E_UNSUPPORTED, "high-pass boundary mode %d", mode);
   if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
   CHK(check_box(box, width, height));
   HIPCHK(hipSetDevice(dev));
@@ -2306,7 +2315,7 @@ extern "C" int glh_stage_template_highpass(int dev, const uint8_t* frame, int wi
   a.out.hist_q = dq.as<double>();
   a.out.hist_n = dn.as<int32_t>();
   a.hp_rx = size_x / 2;
-  a.hp_ry = size_y / 2;
+  a.hp_ry = size_y / 2 | (mode << 4);
   hipLaunchKernelGGL(k_template_from_box, dim3(1), dim3(BLK), n * sizeof(uint16_t), 0, a);
   CHK(finish());
   CHK(dn.down(hn, 4));
@@ -2317,14 +2326,15 @@ extern "C" int glh_stage_template_highpass(int dev, const uint8_t* frame, int wi
 
 extern "C" int glh_stage_search_tile(int dev, const uint8_t* frame, int width, int height, int channels,
                                      const int32_t* box, const double* hv, const double* hq, int hn, float* tile) {
-  return glh_stage_search_tile_highpass(dev, frame, width, height, channels, box, hv, hq, hn, 5, 5, tile);
+  return glh_stage_search_tile_highpass(dev, frame, width, height, channels, box, hv, hq, hn, 5, 5, GLH_HP_REFLECT, tile);
 }
 
 extern "C" int glh_stage_search_tile_highpass(int dev, const uint8_t* frame, int width, int height, int channels,
                                               const int32_t* box, const double* hv, const double* hq, int hn,
-                                              int size_x, int size_y, float* tile) {
+                                              int size_x, int size_y, int mode, float* tile) {
   if (!frame || !tile || !hv || !hq || hn <= 0) return fail(GLH_E_INVALID, "bad argument");
   CHK(check_highpass(size_x, size_y));
+  if (mode < GLH_HP_REFLECT || mode > GLH_HP_WRAP) return fail(GLH_E_UNSUPPORTED, "high-pass boundary mode %d", mode);
   if (channels != 1 && channels != 3) return fail(GLH_E_UNSUPPORTED, "1 or 3 channels");
   CHK(check_box(box, width, height));
   HIPCHK(hipSetDevice(dev));
@@ -2345,7 +2355,7 @@ extern "C" int glh_stage_search_tile_highpass(int dev, const uint8_t* frame, int
   a.hist_q = dq.as<double>();
   a.hist_n = hn;
   a.hp_rx = size_x / 2;
-  a.hp_ry = size_y / 2;
+  a.hp_ry = size_y / 2 | (mode << 4);
   a.out = dout.as<float>();
   hipLaunchKernelGGL(k_search_from_box, dim3(1), dim3(BLK), (size_t)(BAND_H + 6) * w * sizeof(uint16_t), 0, a);
   CHK(finish());

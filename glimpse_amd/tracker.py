@@ -128,14 +128,18 @@ class Tracker:
             raise TypeError("viewshed must be a glimpse_amd.Raster")
         if resample_method not in _lib.RESAMPLE:
             raise ValueError(f"resample_method {resample_method!r}: expected one of {sorted(_lib.RESAMPLE)}")
-        # tracker.py:59, :530: the dict goes to scipy.ndimage.median_filter; `size` (an int or (rows, columns)) is
-        # what the device implements, odd sizes up to 7
+        # tracker.py:59, :530: the dict goes to scipy.ndimage.median_filter; `size` (an int or (rows, columns), odd, up
+        # to 7) and `mode` ("reflect", "nearest", "mirror", "wrap" and scipy's grid-* aliases) are what the device
+        # implements -- a footprint, an origin or the "constant" mode (a fill value in the matched tile's units) are not
         size = highpass.get("size", (5, 5))
         size = (int(size), int(size)) if np.isscalar(size) else tuple(int(v) for v in size)
-        if set(highpass) - {"size"} or len(size) != 2 or any(v < 1 or v > 7 or v % 2 == 0 for v in size):
-            raise NotImplementedError("the high-pass filter is a median with odd size up to (7, 7): "
-                                      f"highpass={highpass!r}")
+        mode = highpass.get("mode", "reflect")
+        if set(highpass) - {"size", "mode"} or len(size) != 2 or any(v < 1 or v > 7 or v % 2 == 0 for v in size) \
+                or mode not in _lib.HIGHPASS_MODES:
+            raise NotImplementedError("the high-pass filter is a median with odd size up to (7, 7) and mode 'reflect', "
+                                      f"'nearest', 'mirror' or 'wrap': highpass={highpass!r}")
         self._highpass_size = size
+        self._highpass_mode = mode
         orders = (int(interpolation.get("kx", 3)), int(interpolation.get("ky", 3)))
         if not all(1 <= k <= 5 for k in orders) or set(interpolation) - {"kx", "ky"}:
             # (tracker.py:60, :623: the dict goes to scipy RectBivariateSpline; its orders kx, ky are what the device
@@ -266,7 +270,7 @@ class Tracker:
                 ctx.observer_init(o, len(obs.images), w, h, ch, obs.sigma)
                 ctx.observer_set_depth(o, first.dtype)
                 ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
-            ctx.set_highpass(self._highpass_size)
+            ctx.set_highpass(self._highpass_size, self._highpass_mode)
             ctx.set_interpolation(*self._orders)
         except Exception:
             ctx.close()
@@ -874,7 +878,7 @@ class Tracker:
                 ctx.observer_set_cameras(o, np.stack([_vector24(img) for img in obs.images]))
             ctx.begin_sequence(1, n, tile)
             ctx.set_motion_cartesian(np.zeros((1, _lib.MOTION_LEN)))
-            ctx.set_highpass(self._highpass_size)
+            ctx.set_highpass(self._highpass_size, self._highpass_mode)
             ctx.set_interpolation(*self._orders)
             self._sctx, self._sctx_key, self._single_tile, self._s_uploaded = ctx, key, tuple(tile), set()
         return self._sctx
@@ -931,13 +935,14 @@ class Tracker:
                                       "prepared on the device inside track()")
         box = np.asarray(box).astype(int)
         if histogram is None:
-            tile, own = _lib.stage_template(frame, box, device_id=self.device, highpass=self._highpass_size)
+            tile, own = _lib.stage_template(frame, box, device_id=self.device, highpass=self._highpass_size,
+                                            mode=self._highpass_mode)
             return (tile, own) if return_histogram else tile
         if return_histogram:
             raise NotImplementedError("extract_tile: histogram= together with return_histogram=True (no caller on "
                                       "the tracking path asks for the histogram of a matched tile)")
-        return _lib.stage_search_tile(frame, box, histogram, device_id=self.device,
-                                      highpass=self._highpass_size).astype(float)
+        return _lib.stage_search_tile(frame, box, histogram, device_id=self.device, highpass=self._highpass_size,
+                                      mode=self._highpass_mode).astype(float)
 
     def initialize_template(self, obs, img, tile_size):
         """tracker.py:536-561."""

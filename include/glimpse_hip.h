@@ -291,6 +291,10 @@ int glh_set_math(glh_ctx* ctx, int mode);
 /* Window of the median high-pass filter of every tile (Tracker(highpass={"size": (size_y, size_x)}), tracker.py:59,
  * :530: scipy.ndimage.median_filter): odd sizes up to 7; 5 x 5 (the reference default) unless set.                                                                                           */
 int glh_set_highpass(glh_ctx* ctx, int size_x, int size_y);
+/* Boundary mode of that filter (Tracker(highpass={"size": ..., "mode": ...}): tracker.py:530 hands the dictionary to
+ * scipy.ndimage.median_filter): 0 'reflect' (scipy's default, and the reference's), 1 'nearest', 2 'mirror', 3 'wrap'.
+ * ('constant' needs a fill value in the matched tile's units: not served.)                                             */
+int glh_set_highpass_mode(glh_ctx* ctx, int mode);
 /* Orders of the spline that samples the SSD surface at the particles (Tracker(interpolation={"kx": .., "ky": ..}),
  * tracker.py:60, :585-590, :623: scipy RectBivariateSpline(kx, ky), s = 0): (3, 3), the reference default, or (1, 1)
  * -- bilinear; any other orders 1 .. 5 (kx: rows axis, ky: columns axis): the interpolating spline of those degrees with
@@ -412,13 +416,13 @@ int glh_stage_template(int device_id, const uint8_t* frame, int width, int heigh
 int glh_stage_search_tile(int device_id, const uint8_t* frame, int width, int height,
                           int channels, const int32_t* box, const double* hist_values,
                           const double* hist_quantiles, int hist_n, float* tile);
-/* The two tile hooks with another high-pass window (odd sizes up to 7).                                          */
+/* The two tile hooks with another high-pass window (odd sizes up to 7) and boundary mode (glh_set_highpass_mode).   */
 int glh_stage_template_highpass(int device_id, const uint8_t* frame, int width, int height, int channels,
-                                const int32_t* box, int size_x, int size_y, double* tile, double* hist_values,
-                                double* hist_quantiles, int32_t* hist_n);
+                                const int32_t* box, int size_x, int size_y, int mode, double* tile,
+                                double* hist_values, double* hist_quantiles, int32_t* hist_n);
 int glh_stage_search_tile_highpass(int device_id, const uint8_t* frame, int width, int height, int channels,
                                    const int32_t* box, const double* hist_values, const double* hist_quantiles,
-                                   int hist_n, int size_x, int size_y, float* tile);
+                                   int hist_n, int size_x, int size_y, int mode, float* tile);
 /* cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614): float32 in, float32 out.   */
 int glh_stage_ssd(int device_id, const float* search, int hs, int ws, const float* templ, int th,
                   int tw, float* sse);

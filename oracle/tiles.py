@@ -42,8 +42,9 @@ def read_box(frame, box):
     return frame[box[1] : box[3], box[0] : box[2]]
 
 
-def extract_tile(frame, box, histogram=None, return_histogram=False, highpass_size=(5, 5)):
-    """tracker.py:522-534."""
+def extract_tile(frame, box, histogram=None, return_histogram=False, highpass_size=(5, 5), highpass_mode="reflect"):
+    """tracker.py:522-534 (`highpass_size` / `highpass_mode`: the entries of Tracker.highpass that :530 hands to
+    scipy.ndimage.median_filter)."""
     tile = read_box(frame, box)
     if tile.ndim > 2:
         tile = tile.mean(axis=2)
@@ -52,7 +53,7 @@ def extract_tile(frame, box, histogram=None, return_histogram=False, highpass_si
         tile = match_cdf(tile, histogram)
     if return_histogram:
         returned_histogram = compute_cdf(tile, return_inverse=False)
-    tile_low = scipy.ndimage.median_filter(tile, size=highpass_size)
+    tile_low = scipy.ndimage.median_filter(tile, size=highpass_size, mode=highpass_mode)
     tile -= tile_low
     if return_histogram:
         return tile, returned_histogram

@@ -584,6 +584,32 @@ def test_tracking_with_another_highpass_window_reproduces_reference(golden, size
         glimpse_amd.Tracker([glimpse_amd.Observer(images)], highpass={"size": (4, 4)})
 
 
+@pytest.mark.parametrize("tag,highpass", [("nearest", {"size": (5, 5), "mode": "nearest"}),
+                                          ("mirror", {"size": 3, "mode": "mirror"})])
+def test_tracking_with_another_highpass_boundary_mode_reproduces_reference(golden, tag, highpass):
+    """Tracker(highpass={"size": .., "mode": ..}) end to end against the reference run with the same np.random seed (g26);
+    the fused kernel takes such runs on its general instantiations."""
+    g = golden("g26_highpass_modes.npz")
+    scene = golden("g15_ragged.npz")
+    cam = camera_from(scene["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f)
+              for i, f in enumerate(scene["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], highpass=highpass, max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=tuple(xy), time_unit=DAY, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in g["e2e_xy"]]
+    np.random.seed(31)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tracks = tracker.track(models, tile_size=(15, 15))
+    np.testing.assert_allclose(tracks.means, g[f"e2e_means_{tag}"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(tracks.sigmas, g[f"e2e_sigmas_{tag}"], rtol=RTOL, atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], highpass={"size": 5, "mode": "constant"})
+    with pytest.raises(NotImplementedError):
+        glimpse_amd.Tracker([glimpse_amd.Observer(images)], highpass={"size": 5, "origin": 1})
+
+
 @pytest.mark.parametrize("name,channels", [("gray", 1), ("rgb", 3)])
 def test_tracking_on_uint16_frames_reproduces_reference(golden, name, channels):
     """16-bit frames, gray and RGB (Tracker.extract_tile works on any dtype, tracker.py:494-534): whole tracks against

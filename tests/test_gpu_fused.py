@@ -466,7 +466,9 @@ def test_three_and_four_observers_on_the_fused_kernel(lib, O, math):
 
 @pytest.mark.parametrize("math", ["exact", "fast"])
 @pytest.mark.parametrize("variant", [dict(highpass=(3, 3)), dict(highpass=(7, 5)), dict(highpass=(1, 3)),
-                                     dict(interpolation=(1, 1)), dict(highpass=(3, 3), interpolation=(1, 1))])
+                                     dict(interpolation=(1, 1)), dict(highpass=(3, 3), interpolation=(1, 1)),
+                                     dict(highpass=(5, 5), hp_mode="nearest"), dict(highpass=(3, 7), hp_mode="wrap"),
+                                     dict(highpass=(5, 5), hp_mode="mirror")])
 def test_other_median_windows_and_bilinear_sampling_on_the_fused_kernel(lib, variant, math):
     """Tracker(highpass={"size": ...}) other than 5 x 5 and Tracker(interpolation={"kx": 1, "ky": 1}) run on the
     general instantiations of the fused kernel (rounds 1-2: staged kernels only): bit for bit the staged kernels, on
@@ -485,7 +487,7 @@ def test_other_median_windows_and_bilinear_sampling_on_the_fused_kernel(lib, var
             with lib.Context(wl.P, wl.N, wl.O, max_search_dim=160, max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
                 if "highpass" in variant:
-                    ctx.set_highpass(variant["highpass"])
+                    ctx.set_highpass(variant["highpass"], variant.get("hp_mode", "reflect"))
                 if "interpolation" in variant:
                     ctx.set_interpolation(*variant["interpolation"])
                 ctx.set_math(math)

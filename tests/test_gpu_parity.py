@@ -235,6 +235,26 @@ def test_highpass_window_sizes_match_reference(lib, golden):
         lib.stage_template(frames["gray"][0], tbox, highpass=(9, 9))
 
 
+def test_highpass_boundary_modes_match_reference(lib, golden):
+    """Tracker(highpass={"size": ..., "mode": ...}) (tracker.py:530 hands the dictionary to scipy.ndimage.median_filter):
+    'nearest', 'mirror' and 'wrap' with the 5 x 5 default and a (3, 7) window, template tiles and search tiles of gray and
+    RGB frames against the reference's extract_tile (g26)."""
+    g = golden("g26_highpass_modes.npz")
+    frames = golden("g2_tiles.npz")
+    tbox, sbox = g["tbox"], g["sbox"]
+    for k, (size, mode) in enumerate(zip(g["sizes"], g["modes"])):
+        size, mode = tuple(int(v) for v in size), str(mode)
+        for name in ("gray", "rgb"):
+            f = frames[name]
+            tile, (hv, hq) = lib.stage_template(f[0], tbox, highpass=size, mode=mode)
+            np.testing.assert_array_equal(hq, g[f"{name}_{k}_hist_q"])
+            np.testing.assert_allclose(hv, g[f"{name}_{k}_hist_v"], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(tile, g[f"{name}_{k}_tile"], rtol=1e-12, atol=1e-13)
+            hist = (g[f"{name}_{k}_hist_v"], g[f"{name}_{k}_hist_q"])
+            search = lib.stage_search_tile(f[1], sbox, hist, highpass=size, mode=mode)
+            np.testing.assert_array_equal(search, g[f"{name}_{k}_search"].astype(np.float32))
+
+
 def test_depth_limits_are_refused_up_front(lib):
     """glh_observer_set_depth refuses the combinations its tile kernels cannot serve (their LDS requests grow with the
     context's limits) instead of failing every launch later: 16-bit frames beyond a 1117-pixel search workspace, float64

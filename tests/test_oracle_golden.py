@@ -380,6 +380,22 @@ def test_oracle_highpass_window_sizes(golden):
             np.testing.assert_allclose(search, g[f"{name}_{k}_search"], rtol=1e-13, atol=1e-14)
 
 
+def test_oracle_highpass_boundary_modes(golden):
+    """oracle.tiles.extract_tile(highpass_mode=...) against the reference's Tracker(highpass={"size": .., "mode": ..})."""
+    from oracle import tiles as otiles
+
+    g = golden("g26_highpass_modes.npz")
+    frames = golden("g2_tiles.npz")
+    for k, (size, mode) in enumerate(zip(g["sizes"], g["modes"])):
+        size, mode = tuple(int(v) for v in size), str(mode)
+        for name in ("gray", "rgb"):
+            f = frames[name]
+            tile, hist = otiles.extract_tile(f[0], g["tbox"], return_histogram=True, highpass_size=size, highpass_mode=mode)
+            np.testing.assert_allclose(tile, g[f"{name}_{k}_tile"], rtol=1e-13, atol=1e-14)
+            search = otiles.extract_tile(f[1], g["sbox"], histogram=hist, highpass_size=size, highpass_mode=mode)
+            np.testing.assert_allclose(search, g[f"{name}_{k}_search"], rtol=1e-13, atol=1e-14)
+
+
 @pytest.mark.parametrize("name,channels", [("gray", 1), ("rgb", 3)])
 def test_oracle_on_uint16_frames(golden, name, channels):
     """uint16 frames (tracker.py:494-534 works on any dtype): the oracle's whole-track loop on np.random against the

@@ -906,6 +906,57 @@ def g17_highpass():
     np.savez_compressed(os.path.join(OUT, "g17_highpass.npz"), **out)
 
 
+def g26_highpass_modes():
+    """Tracker(highpass={"size": ..., "mode": ...}) (tracker.py:59, :530: the dictionary goes to
+    scipy.ndimage.median_filter): the boundary modes 'nearest', 'mirror', 'wrap' -- tiles of the reference's extract_tile
+    on gray and RGB frames for the 5 x 5 default and a (3, 7) window, and whole tracks (the g15 scene) for 'nearest' with
+    the default window and 'mirror' with (3, 3)."""
+    cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0)
+    frames, _ = synth.make_sequence(cam, 2, seed=5)
+    rgb, _ = synth.make_sequence(cam, 2, seed=6, channels=3)
+    t0 = datetime.datetime(2020, 1, 1)
+    day = datetime.timedelta(days=1)
+    g2 = np.load(os.path.join(OUT, "g2_tiles.npz"))  # (the frames are those of g2_tiles.npz: not stored again)
+    assert np.array_equal(g2["gray"], np.stack(frames)) and np.array_equal(g2["rgb"], np.stack(rgb))
+    out = {}
+    bt, bs = (20, 30, 51, 61), (5, 12, 80, 70)
+    out["tbox"], out["sbox"] = np.array(bt), np.array(bs)
+    cases = [((5, 5), "nearest"), ((5, 5), "mirror"), ((5, 5), "wrap"), ((3, 7), "nearest"), ((3, 7), "mirror"),
+             ((3, 7), "wrap")]
+    out["sizes"] = np.array([c[0] for c in cases])
+    out["modes"] = np.array([c[1] for c in cases])
+    for k, (size, mode) in enumerate(cases):
+        tracker = glimpse.Tracker([glimpse.Observer([ref_image(frames[i], cam, t0 + i * day) for i in range(2)]),
+                                   glimpse.Observer([ref_image(rgb[i], cam, t0 + i * day) for i in range(2)])],
+                                  highpass={"size": size, "mode": mode})
+        for o, name in enumerate(["gray", "rgb"]):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tile, hist = tracker.extract_tile(obs=o, img=0, box=np.array(bt), return_histogram=True)
+                search = tracker.extract_tile(obs=o, img=1, box=np.array(bs), histogram=hist)
+            out[f"{name}_{k}_tile"], out[f"{name}_{k}_hist_v"], out[f"{name}_{k}_hist_q"] = tile, hist[0], hist[1]
+            out[f"{name}_{k}_search"] = search
+    cam2 = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
+    seq, _ = synth.make_sequence(cam2, 6, seed=12, velocity=(0.15, 0.0))
+    pts = synth.grid_points(cam2, 3, border_px=70.0, seed=3)
+    g15 = np.load(os.path.join(OUT, "g15_ragged.npz"))
+    assert np.array_equal(g15["frames"], np.stack(seq)) and np.array_equal(g15["cam"], cam2)
+    out["e2e_xy"] = pts
+    for tag, hp in (("nearest", {"size": (5, 5), "mode": "nearest"}), ("mirror", {"size": 3, "mode": "mirror"})):
+        imgs = [ref_image(seq[i], cam2, t0 + i * day) for i in range(6)]
+        tracker = glimpse.Tracker([glimpse.Observer(imgs, sigma=0.3)], highpass=hp)
+        models = [glimpse.CartesianMotion(xy=tuple(xy), time_unit=day, dem=0.0, dem_sigma=0.0, n=200, xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy in pts]
+        np.random.seed(31)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tracks = tracker.track(models, tile_size=(15, 15))
+        out[f"e2e_means_{tag}"], out[f"e2e_sigmas_{tag}"] = tracks.means, tracks.sigmas
+        print("g26", tag, "vx:", tracks.means[:, -1, 3])
+    np.savez_compressed(os.path.join(OUT, "g26_highpass_modes.npz"), **out)
+
+
 def scene16(channels):
     """The 16-bit scene of g18 (tests regenerate it from the same recipe and check `checksum`)."""
     cam = synth.nadir_camera((256, 256), f=1000.0, height=100.0, k=(0.05, -0.01, 0.002))
@@ -1221,6 +1272,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--g18" in sys.argv:
         g18_uint16()
+        sys.exit(0)
+    if "--g26" in sys.argv:
+        g26_highpass_modes()
         sys.exit(0)
     if "--g17" in sys.argv:
         g17_highpass()
