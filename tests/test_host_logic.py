@@ -83,7 +83,8 @@ def test_tracker_guards(golden):
     observers = observers_from(g)
     with pytest.raises(ValueError):
         glimpse_amd.Tracker(observers, resample_method="multinomial")
-    for bad in ({"size": (4, 4)}, {"size": (9, 9)}, {"size": (5, 5), "mode": "nearest"}, {"size": (3, 3, 3)}):
+    for bad in ({"size": (4, 4)}, {"size": (9, 9)}, {"size": (5, 5), "mode": "constant"}, {"size": (5, 5), "origin": 1},
+                {"size": (3, 3, 3)}):
         with pytest.raises(NotImplementedError):
             glimpse_amd.Tracker(observers, highpass=bad)
     assert glimpse_amd.Tracker(observers, highpass={"size": 3})._highpass_size == (3, 3)
