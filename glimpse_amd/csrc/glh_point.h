@@ -125,12 +125,9 @@ __host__ __device__ __forceinline__ int pt_align16(int x) { return (x + 15) & ~1
 // LDS row stride (floats) of the search tile: >= ws + 11 readable columns and == 8 (mod 32), so the
 // row-split lanes of a strip (rows g = 0..7) start in distinct 16-byte bank slots
 __host__ __device__ __forceinline__ int pt_search_ld(int ws) { return ((ws + 3 + 31) / 32) * 32 + 8; }
-// histogram | cumulative counts | LUT of nb bins.  The 766 bins of RGB frames keep their cumulative counts IN the
-// histogram (each thread scans the two bins it owns): 3 KB that keep typical RGB tiles in LDS at two workgroups per CU.
-__host__ __device__ __forceinline__ bool pt_cum_in_place(int nb) { return nb > 256; }
-__host__ __device__ __forceinline__ int pt_hcl_bytes(int nb) {
-  return pt_align16(nb * 4) * (pt_cum_in_place(nb) ? 1 : 2) + pt_align16(nb * 8);
-}
+// histogram | LUT of nb bins (round 4: the cumulative counts are not written out any more -- the thread that owns a bin
+// makes its LUT entry behind the scan, from registers)
+__host__ __device__ __forceinline__ int pt_hcl_bytes(int nb) { return pt_align16(nb * 4) + pt_align16(nb * 8); }
 // bytes of the arrays that always live in LDS: template tile + histogram / cumulative counts / LUT
 __host__ __device__ __forceinline__ int pt_small_bytes(int tw, int th, int nb) {
   return pt_align16(th * ssd_twp(tw) * 4) + pt_hcl_bytes(nb);
@@ -154,7 +151,6 @@ __host__ __device__ __forceinline__ int pt_plan_ints(int nleaves, int nnodes, in
 struct TileWs {
   float* T;         // [th][twp] template, zero padded                         (always LDS)
   uint32_t* hist;   // [nb]                                                     (always LDS)
-  uint32_t* cum;    // [nb]
   double* lut;      // [nb]
   float* S;         // [hs][ld] search tile
   uint16_t* keys;   // [pt_keys_count(ws, hs)] raw pixel keys with their reflected border
@@ -1062,7 +1058,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     const int off = offT;
     const int ld_lds = pt_search_ld(ws_);
     const int s_bytes = max(pt_align16(hs * ld_lds * 4), 2 * cdfb);
-    const int hcl = pt_hcl_bytes(nb), hb = pt_cum_in_place(nb) ? 0 : pt_align16(nb * 4);  // (hb: offset of cum behind hist)
+    const int hcl = pt_hcl_bytes(nb);
     const int l1 = hcl + pt_align16(pt_keys_count(ws_, hs) * 2);
     // Tracker(interpolation={"kx": 1, "ky": 1}) (general code): the surface values are the coefficients -- no fit -- and
     // the sampling is their bilinear interpolant
@@ -1235,8 +1231,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       ws.S = reinterpret_cast<float*>(r2 + off);
       unsigned char* X = r2 + off + s_bytes;
       ws.hist = reinterpret_cast<uint32_t*>(X);
-      ws.cum = reinterpret_cast<uint32_t*>(X + hb);
-      ws.lut = reinterpret_cast<double*>(X + hb + pt_align16(nb * 4));
+      ws.lut = reinterpret_cast<double*>(X + pt_align16(nb * 4));
       ws.keys = reinterpret_cast<uint16_t*>(X + hcl);
       ws.cdf_q = reinterpret_cast<const double*>(r2 + offT);
       ws.cdf_v = ws.cdf_q + cdfb / 8;
@@ -1285,8 +1280,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       unsigned char* X = r2 + offT;
       __syncthreads();  // the CDF copy has landed before the histogram is zeroed over it
       ws.hist = reinterpret_cast<uint32_t*>(X);
-      ws.cum = reinterpret_cast<uint32_t*>(X + hb);
-      ws.lut = reinterpret_cast<double*>(X + hb + pt_align16(nb * 4));
+      ws.lut = reinterpret_cast<double*>(X + pt_align16(nb * 4));
       ws.ld = (ws_ + 14) & ~3;
       ws.S = a.ws_search + slot * (size_t)a.search_cap;
       ws.keys = a.ws_keys + slot * (size_t)a.keys_cap;
