@@ -935,6 +935,14 @@ def worker(args):
                 # hipMemcpyDtoD rate ("a measured device-copy ceiling")
                 "achievable_GBps": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                 "measured_copy_GBps": ctx.copy_bandwidth(1 << 30, 10)}
+        if streams > 1:
+            roof["note"] = (f"{streams} launches of k_point_step are resident at a time (glh_track runs the halves of the "
+                            "points on two HIP streams): the sum of the launch durations of a step exceeds the step's wall "
+                            "time by design; `achieved` = algorithmic bytes of a frame / `gpu_span_ms_per_frame` (first "
+                            "launch start to last launch end over the timed region, HIP events on both streams, per "
+                            "frame); `avg_launch_ms` is one launch of half the points and is what rocprofv3's kernel trace "
+                            "shows; `per_launch` is that launch's own rate; secondary.C3_one_stream is the same "
+                            "configuration with one launch per frame")
         if roof["traffic"] is not None:
             roof["traffic_per"] = f"frame update ({launches_per_frame:g} launch(es) of {wl.P / launches_per_frame:g} points)"
             roof["traffic_over_algorithmic"] = traffic / abytes
