@@ -317,6 +317,10 @@ extern "C" int glh_destroy(glh_ctx* c) {
     (void)hipEventDestroy(e.b);
   }
   for (auto e : c->pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < ST_COUNT; ++i)
+    if (c->span_a[i]) (void)hipEventDestroy(c->span_a[i]);  // (kept out of the pool since the last reset)
+  for (int q = 0; q < 3; ++q)
+    if (c->extra_streams[q]) (void)hipStreamSynchronize(c->extra_streams[q]);
   for (int o = 0; o < MAX_OBS; ++o) {
     dfree(c->obs[o].cams);
     for (auto& p : c->obs[o].owned) dfree(p);
