@@ -54,3 +54,22 @@ def test_ground_map_bands_equal_the_whole_map():
     np.testing.assert_array_equal(rgb[..., 0], g)
     np.testing.assert_array_equal(rgb[..., 1], np.clip(i + ((i * 7) % 5) - 2, 0, 255))
     np.testing.assert_array_equal(rgb[..., 2], np.clip(255 - i // 2, 0, 255))
+
+
+def test_pmc_traffic_is_scaled_to_a_frame_by_the_points_of_the_profiled_launch():
+    """roofline.traffic: the committed PMC figure is per LAUNCH of the profiled run (two streams: half of the points); the
+    bench line reports the bytes of a frame update of all the workload's points, whatever the launches of this run hold."""
+    import json
+
+    import bench
+    from glimpse_amd import workloads
+
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    wl = workloads.Workload("C3", n_frames=3)
+    entry = table["C3:4096x5000"]["k_point_step"]
+    per_frame = bench.pmc_traffic_per_frame(wl, "k_point_step")
+    assert per_frame == entry["hbm_bytes_per_launch"] * wl.P / entry["points_per_launch"]
+    # measured traffic within a few percent of the algorithmic figure at C3 (96 B of state per particle-frame + tiles)
+    assert 0.85 < per_frame / (100.2 * wl.P * wl.N) < 1.1
+    assert "not measured in this run" in bench.pmc_traffic_source(wl, "k_point_step")
+    assert bench.pmc_traffic_per_frame(workloads.Workload("C1", n_frames=3), "k_point_step") is None
