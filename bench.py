@@ -94,7 +94,7 @@ def parse_args(argv=None):
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
-    ap.add_argument("--bits", type=int, default=8, choices=[8, 16],
+    ap.add_argument("--bits", type=int, default=8, choices=[8, 16, 32],
                     help="frame samples: uint8 (BASELINE's configurations) or uint16 (the same scene on a 16-bit sensor)")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
                     help="frame channels: 1 (gray, BASELINE's configurations) or 3 (RGB uint8: what time-lapse JPEGs decode to)")
@@ -710,7 +710,7 @@ def worker(args):
     from glimpse_amd import _lib, sharding, workloads
 
     if args.max_search_dim is None:
-        args.max_search_dim = 255 if args.bits == 16 else 320
+        args.max_search_dim = 255 if args.bits >= 16 else 320
 
     group = sharding.Group.from_env()
     rank, world = group.rank, group.world
@@ -744,7 +744,7 @@ def worker(args):
         point_offset = rank * wl.P
         sizes = [wl.P] * world
 
-    wl.channels, wl.bits = args.channels, args.bits
+    wl.channels, wl.bits = args.channels, (8 if args.bits == 32 else args.bits)  # (float32: the 8-bit scene, scaled below)
     # frames: rendered once per job (rank 0), shared with the other ranks as memory-mapped files -- by forked helpers,
     # hence BEFORE anything loads the HIP library (the device count below does)
     cores = usable_cores()
@@ -772,6 +772,9 @@ def worker(args):
         else:
             frames = [group.store.get_array(f"frames_{o}", mmap=True) for o in range(wl.O)]
 
+    if args.bits == 32:  # float32 frames (an orthophoto / reflectance observer): the scene's gray levels scaled to [0, 1]
+        frames = [[np.asarray(f, dtype=np.float32) * np.float32(1.0 / 255.0) for f in fo] for fo in frames]
+        wl.bits = 32
     # one GPU per rank (LOCAL_RANK); GLH_BENCH_DEVICE is a test hook (several ranks on one GPU)
     device = int(os.environ.get("GLH_BENCH_DEVICE", group.local_rank % max(1, _lib.device_count())))
     _mark("frames rendered")

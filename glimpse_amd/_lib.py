@@ -484,8 +484,8 @@ class Context:
         check(self.lib.glh_set_point_offset(self.handle, int(offset)))
 
     def phase_stamps(self):
-        """Diagnostic: s_memtime stamps (P, 20) of the fused kernel's phase boundaries (first call arms)."""
-        out = np.zeros((self.P, 20), dtype=np.uint64)
+        """Diagnostic: s_memtime stamps (P, 24) of the fused kernel's phase boundaries (first call arms)."""
+        out = np.zeros((self.P, 24), dtype=np.uint64)
         check(self.lib.glh_debug_phase_stamps(self.handle, _ptr(out)))
         return out
 

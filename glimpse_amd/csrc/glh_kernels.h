@@ -21,6 +21,7 @@ constexpr int NWAVES = BLK / WAVE;
 constexpr int MAX_OBS = 4;
 constexpr int NBINS = 768;  // >= 766 = 3 * 255 + 1 channel-sum keys (RGB); 256 for gray
 constexpr int BAND_H = 16;  // rows per median band in k_tileprep
+constexpr int GLH_NSTAMP = 24;  // s_memtime stamps per workgroup of the fused kernel (diagnostic: glh_debug_phase_stamps)
 
 struct ObsFrame {
   const CamDev* cam;     // camera of the image matched to this frame
@@ -64,6 +65,16 @@ __device__ __forceinline__ double wave_min(double v) {
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, WAVE));
   return v;
 }
 
@@ -1045,6 +1056,174 @@ __device__ __forceinline__ bool np_sum_f32_block(const float* a, int n, int row_
   return true;
 }
 
+// Round 4b: the same sums without a serial walk.  ONE call of NumPy's pairwise sum (n <= 8192 items) is a binary tree whose
+// shape depends on n alone: a range longer than 128 splits at n2 = n / 2 rounded down to a multiple of 8 into (off, n2) and
+// (off + n2, n - n2); from 8192 the right halves run 4096 .. 8191 -> 4103 -> 2055 -> 1031 -> 519 -> 263 -> 135 -> 71: no
+// leaf lies deeper than level 7.  Numbered as a heap (root 1, children 2 i and 2 i + 1) the tree fits 256 slots, and thread
+// `id` finds its node by following the bits of `id` down from the root -- registers only, no stack.  Leaves are summed by 8
+// lanes each, exactly as np_pairwise_leaf_f32 does (lane j the accumulator r[j]; float addition commutes, so the three
+// exchange-adds give every lane ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))); the inner nodes are added level by
+// level by one wave (LDS operations of a wave complete in order: a level reads what the level below wrote).
+// `load(i)`: item i of the array (the squares of the normalisation are formed here, not stored); `node`: 256 words,
+// `val`: 256 floats of LDS.  All threads; barriers inside.  (The serial walk above: 35 k and 55 k cycles of a float32 frame's
+// 217 k-cycle tile stage, tools/experiments/r04_jobs/j31_float_split.sh.)
+constexpr uint32_t NP_NODE_INNER = 0xffffffffu;
+template <typename LOAD>
+__device__ __forceinline__ float np_leaf_8lanes(int off, int len, int sub, LOAD load) {
+  float res = 0.0f;
+  if (len >= 8) {
+    const int body = len - (len % 8);
+    float r = load(off + sub);
+    for (int i = 8; i < body; i += 8) r += load(off + i + sub);
+    r += __shfl_xor(r, 1, WAVE);
+    r += __shfl_xor(r, 2, WAVE);
+    r += __shfl_xor(r, 4, WAVE);
+    res = r;
+    if (sub == 0)
+      for (int i = body; i < len; ++i) res += load(off + i);
+  } else if (sub == 0) {
+    for (int i = 0; i < len; ++i) res += load(off + i);
+  }
+  return res;  // (lane 0 of the group holds the leaf's sum)
+}
+template <int NT, typename LOAD>
+__device__ __forceinline__ float np_pairwise_block(int off0, int n, uint32_t* node, float* val, LOAD load) {
+  static_assert(NT >= 256, "one thread per tree slot");
+  const int tid = threadIdx.x, sub = tid & 7;
+  if (tid >= 1 && tid < 256) {
+    int off = off0, len = n;
+    bool exists = true;
+    for (int b = 30 - __clz(tid); b >= 0; --b) {  // (the bits of tid below its leading one, from the top)
+      if (len <= 128) {
+        exists = false;  // an ancestor is a leaf
+        break;
+      }
+      int n2 = len / 2;
+      n2 -= n2 % 8;
+      if ((tid >> b) & 1) {
+        off += n2;
+        len -= n2;
+      } else {
+        len = n2;
+      }
+    }
+    node[tid] = !exists ? 0u : len <= 128 ? ((uint32_t)off | ((uint32_t)len << 16)) : NP_NODE_INNER;  // (len >= 1, off < 65536)
+  }
+  __syncthreads();
+  for (int id0 = 0; id0 < 256; id0 += NT / 8) {
+    const int id = id0 + (tid >> 3);
+    const uint32_t e = id >= 1 && id < 256 ? node[id] : 0u;
+    if (e != 0u && e != NP_NODE_INNER) {  // (the 8 lanes of a group agree)
+      const float res = np_leaf_8lanes((int)(e & 0xffffu), (int)(e >> 16), sub, load);
+      if (sub == 0) val[id] = res;
+    }
+  }
+  __syncthreads();
+  if (tid < WAVE) {
+#pragma unroll
+    for (int d = 6; d >= 0; --d) {
+      asm volatile("" ::: "memory");  // (program order = LDS order inside a wave)
+      const int id = (1 << d) + tid;
+      if (tid < (1 << d) && node[id] == NP_NODE_INNER) val[id] = val[2 * id] + val[2 * id + 1];
+    }
+  }
+  __syncthreads();
+  return val[1];
+}
+// np.add.reduce of a flat float32 array: chunks of 8192 items (np.getbufsize()), their pairwise sums added in order
+template <int NT, typename LOAD>
+__device__ __forceinline__ float np_sum_flat_block(int n, uint32_t* node, float* val, LOAD load) {
+  float acc = 0.0f;
+  for (int s0 = 0; s0 < n; s0 += 8192) {
+    acc += np_pairwise_block<NT>(s0, min(8192, n - s0), node, val, load);
+    __syncthreads();  // (val[1] is read by every thread before the next chunk's tree is written)
+  }
+  return acc;
+}
+// ... of an h x w strided view, w <= 128: out += pairwise(row), row by row, and a row is one leaf.  The rows' sums by 8
+// lanes each into val[h]; their ordered sum by wave 0, the values passed from lane to lane through v_readlane (64 dependent
+// additions, no memory in the chain).  val: >= h floats of LDS; *out: LDS.  All threads; ends with a barrier.
+template <int NT, typename LOAD>
+__device__ __forceinline__ void np_sum_rows_block(int h, int w, float* val, float* out, LOAD load) {
+  const int tid = threadIdx.x, sub = tid & 7;
+  for (int r0 = 0; r0 < h; r0 += NT / 8) {
+    const int r = r0 + (tid >> 3);
+    if (r < h) {
+      const float res = np_leaf_8lanes(r * w, w, sub, load);
+      if (sub == 0) val[r] = res;
+    }
+  }
+  __syncthreads();
+  if (tid < WAVE) {
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < h; c0 += WAVE) {
+      const int v = c0 + tid < h ? __float_as_int(val[c0 + tid]) : 0;
+#pragma unroll
+      for (int k = 0; k < WAVE; ++k) {
+        if (c0 + k >= h) break;  // (uniform)
+        acc += __int_as_float(__builtin_amdgcn_readlane(v, k));
+      }
+    }
+    if (tid == 0) *out = acc;
+  }
+  __syncthreads();
+}
+
+// helpers.normalize (helpers.py:344) of a float32 box by the whole block with the tile in LDS (the fused kernel's float
+// branch): g[n] receives the gray values, then -- in place -- the normalised ones, (g - mean) * (1 / std) in float32, the two
+// sums in NumPy's order as above.  `words`: 512 words of LDS (tree slots / row sums).  Same bits as normalize_box_float
+// below (the staged kernels' form: values as doubles in memory), which it replaces for tiles that fit.  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void normalize_box_f32_block(const uint8_t* frame, int width, int channels, const int* box, float* g,
+                                                        uint32_t* words, unsigned long long* stp = nullptr) {
+  __shared__ float s_rows;
+  const int tid = threadIdx.x;
+  const int w = box[2] - box[0], h = box[3] - box[1], n = w * h;
+  uint32_t* node = words;
+  float* val = reinterpret_cast<float*>(words + 256);
+  const UDiv by_w = udiv_make(w);
+  for (int base = 0; base < n; base += 4 * NT) {  // (four pixel loads in flight per thread)
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = min(base + q * NT + tid, n - 1);
+      const int r = udiv(by_w, idx), c = idx - r * w;
+      v[q] = (float)pixel_float(frame, width, channels, 32, box[1] + r, box[0] + c);
+    }
+    asm volatile("" ::: "memory");  // (the loads stay above the stores)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (base + q * NT + tid < n) g[base + q * NT + tid] = v[q];
+  }
+  __syncthreads();
+  if (stp && tid == 0) stp[(size_t)blockIdx.x * GLH_NSTAMP + 20] = __builtin_amdgcn_s_memtime();
+  auto plain = [g](int i) { return g[i]; };
+  float total;
+  if (channels == 1 && w <= 128 && h <= 256) {  // a strided view of the frame: row by row
+    np_sum_rows_block<NT>(h, w, val, &s_rows, plain);
+    total = s_rows;
+  } else if (channels == 1) {  // (rows that split: one tree per row, in order)
+    total = 0.0f;
+    for (int r = 0; r < h; ++r) {
+      total += np_pairwise_block<NT>(r * w, w, node, val, plain);
+      __syncthreads();
+    }
+  } else {  // the channel mean is a new contiguous array
+    total = np_sum_flat_block<NT>(n, node, val, plain);
+  }
+  const float mean = total / (float)n;
+  if (stp && tid == 0) stp[(size_t)blockIdx.x * GLH_NSTAMP + 21] = __builtin_amdgcn_s_memtime();
+  const float sq = np_sum_flat_block<NT>(n, node, val, [g, mean](int i) {
+    const float d = g[i] - mean;
+    return d * d;  // (-ffp-contract=off: the product is rounded before it is added)
+  });
+  const float var = sq / (float)n;
+  const float inv = 1.0f / sqrtf(var);
+  for (int idx = tid; idx < n; idx += NT) g[idx] = (g[idx] - mean) * inv;
+  __syncthreads();
+  if (stp && tid == 0) stp[(size_t)blockIdx.x * GLH_NSTAMP + 22] = __builtin_amdgcn_s_memtime();
+}
+
 // normalize (helpers.py:344) of the box into y[n]: (a - a.mean()) * (1 / a.std()); all threads; ends with a barrier.
 // float64 frames: block reductions (the last bits of a float64 mean decide nothing).  float32 frames: float32 arithmetic
 // with NumPy's own summation order, on thread 0 -- a one-channel tile is a strided view of the frame, which NumPy sums
@@ -1182,16 +1361,17 @@ __device__ void template_from_boxf(const uint8_t* frame, int width, int channels
 // buckets), a block scan for the bucket offsets, the values scattered into bucket order (`sorted`, n doubles), a value's
 // count = its bucket's offset + the members of its bucket at or below it.  `tab`: NBK words of LDS, `scan_tmp`: NT / WAVE
 // words.  All threads; ends with a barrier.
-template <int NT, int NBK, typename EMIT>
-__device__ __forceinline__ void rank_values(const double* work, double* sorted, int n, uint32_t* tab, uint32_t* scan_tmp,
-                                            EMIT emit) {
-  __shared__ double s_mm[NT / WAVE][2];
+// (T: double -- values in memory, the staged kernels -- or float: a float32 tile in LDS, the fused kernel; the counts do
+// not depend on the bucket map, only on its being monotone, which the float32 form of it is as well)
+template <int NT, int NBK, typename T, typename EMIT>
+__device__ __forceinline__ void rank_values(const T* work, T* sorted, int n, uint32_t* tab, uint32_t* scan_tmp, EMIT emit) {
+  __shared__ T s_mm[NT / WAVE][2];
   const int tid = threadIdx.x;
   static_assert(NBK % NT == 0, "whole buckets per thread");
   for (int b = tid; b < NBK; b += NT) tab[b] = 0;
-  double xmin = INFINITY, xmax = -INFINITY;
+  T xmin = (T)INFINITY, xmax = (T)-INFINITY;
   for (int idx = tid; idx < n; idx += NT) {
-    const double x = work[idx];
+    const T x = work[idx];
     xmin = fmin(xmin, x);
     xmax = fmax(xmax, x);
   }
@@ -1208,8 +1388,8 @@ __device__ __forceinline__ void rank_values(const double* work, double* sorted, 
     xmin = fmin(xmin, s_mm[wv][0]);
     xmax = fmax(xmax, s_mm[wv][1]);
   }
-  const double scale = xmax > xmin ? (double)(NBK - 1) / (xmax - xmin) : 0.0;
-  auto bucket = [&](double x) -> int { return min(NBK - 1, max(0, (int)((x - xmin) * scale))); };
+  const T scale = xmax > xmin ? (T)(NBK - 1) / (xmax - xmin) : (T)0;
+  auto bucket = [&](T x) -> int { return min(NBK - 1, max(0, (int)((x - xmin) * scale))); };
   for (int idx = tid; idx < n; idx += NT) atomicAdd(&tab[bucket(work[idx])], 1u);
   __syncthreads();
   {
@@ -1230,12 +1410,12 @@ __device__ __forceinline__ void rank_values(const double* work, double* sorted, 
   }
   __syncthreads();
   for (int idx = tid; idx < n; idx += NT) {
-    const double x = work[idx];
+    const T x = work[idx];
     sorted[atomicAdd(&tab[bucket(x)], 1u)] = x;
   }
   __syncthreads();  // (tab[b] is now the END of bucket b; the scattered values are visible to the block)
   for (int idx = tid; idx < n; idx += NT) {
-    const double x = work[idx];
+    const T x = work[idx];
     const int b = bucket(x);
     const uint32_t lo = b ? tab[b - 1] : 0u, hi = tab[b];
     uint32_t c = lo;

@@ -30,7 +30,7 @@ namespace glh {
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 63;  // largest template side the fused kernel handles (rows padded to 64 floats)
-constexpr int PT_NSTAMP = 20;
+constexpr int PT_NSTAMP = GLH_NSTAMP;
 constexpr int PT_MAX_OBS = 4;    // observers per point in the fused kernel (= MAX_OBS of the library)
 
 template <int TB>
@@ -1334,17 +1334,29 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
             ws.keys = reinterpret_cast<uint16_t*>(r2 + used);
             used += kb;
           }
-          double* fw = ob.fwork + (size_t)pt * ob.fwork_cap;  // [values | values in bucket order]: 2 npx doubles
-          // the float32 scratch of the normalisation (2 npx floats, summed by ONE thread in NumPy's order): LDS if it fits
-          float* scratch = used + 8 * npx <= a.r2_bytes ? reinterpret_cast<float*>(r2 + used) : reinterpret_cast<float*>(fw + npx);
-          normalize_box_float<TB>(ob.frame, ob.width, ob.channels, ob.bits, box, fw, scratch, scratch + npx, wave_tot, nullptr,
-                                  tab, PT_WIDE_BUCKETS);  // (the bucket table, not yet in use, lists the sums' leaves)
+          double* fw = ob.fwork + (size_t)pt * ob.fwork_cap;  // 2 npx doubles of memory
           uint16_t* kt = ws.keys + 2 * wp + 2;
           const UDiv by_w = udiv_make(ws_);
-          rank_values<TB, PT_WIDE_BUCKETS>(fw, fw + npx, npx, tab, scan_tmp, [&](int idx, uint32_t cnt) {
+          auto emit = [&](int idx, uint32_t cnt) {
             const int r = udiv(by_w, idx), c = idx - r * ws_;
             kt[r * wp + c] = (uint16_t)cnt;  // np.cumsum(counts)[inverse]
-          });
+          };
+          if (ob.bits == 32 && used + 8 * npx <= a.r2_bytes) {
+            // a float32 tile that fits: [values | values in bucket order] as floats in LDS, the sums by the whole block
+            // (round 4b: 1.29 -> 0.88 ms per frame at C3; the form below -- values as doubles in memory, the sums' trees
+            // walked by one thread -- spent 175 k of the stage's 217 k cycles on the sums and the ranking)
+            float* g = reinterpret_cast<float*>(r2 + used);
+            normalize_box_f32_block<TB>(ob.frame, ob.width, ob.channels, box, g, tab, (unsigned long long*)a.stamps);
+            rank_values<TB, PT_WIDE_BUCKETS>(g, g + npx, npx, tab, scan_tmp, emit);
+          } else {
+            // float64 frames and tiles beyond LDS: [values | values in bucket order] in the workspace; the float32
+            // scratch of the normalisation (2 npx floats) over the second half
+            float* scratch = reinterpret_cast<float*>(fw + npx);
+            normalize_box_float<TB>(ob.frame, ob.width, ob.channels, ob.bits, box, fw, scratch, scratch + npx, wave_tot, nullptr,
+                                    tab, PT_WIDE_BUCKETS);  // (the bucket table, not yet in use, lists the sums' leaves)
+            rank_values<TB, PT_WIDE_BUCKETS>(fw, fw + npx, npx, tab, scan_tmp, emit);
+          }
+          PT_STAMP(13);
           double* cdf_l = used + 2 * cdfb <= a.r2_bytes ? reinterpret_cast<double*>(r2 + used) : nullptr;
           const int jb = pt_align16((npx + 1) * 2);
           uint16_t* jt = reinterpret_cast<uint16_t*>(ws.Z);  // (the surface's workspace: free until the SSD)

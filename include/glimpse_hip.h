@@ -308,7 +308,7 @@ int glh_set_interpolation(glh_ctx* ctx, int kx, int ky);
  * randn(n,2) | randn(n) | randn(n,3); kind 1: the evolve normals of frame `step`, out [P][N][3]; kind 2: the
  * systematic resampling offset of frame `step`, out [P].  `step` is the frame index passed to glh_step.          */
 int glh_debug_draws(glh_ctx* ctx, int kind, uint64_t seed, uint64_t step, double* out);
-/* Diagnostic: s_memtime stamps [P][20] at the phase boundaries of the fused kernel during the
+/* Diagnostic: s_memtime stamps [P][24] at the phase boundaries of the fused kernel during the
  * last fused glh_step (the first call only arms them and returns zeros).                      */
 int glh_debug_phase_stamps(glh_ctx* ctx, uint64_t* stamps);
 /* Diagnostic: which instantiation of the fused kernel took the last fused glh_step / glh_track frame:

@@ -18,10 +18,16 @@ wl = workloads.Workload(name, n_frames=T, n_points=P, n_particles=N)
 wl.bits = int(os.environ.get("GLH_BITS", "8"))          # 16: uint16 frames (pt_tile_prep_wide)
 wl.channels = int(os.environ.get("GLH_CHANNELS", "1"))
 HP = os.environ.get("GLH_HP")                            # e.g. 3: a 3 x 3 median, i.e. the general instantiation
-frames = [wl.frames(o) for o in range(wl.O)]
+if wl.bits >= 32:  # float frames as bench.py's C3_f32 leg makes them: the 8-bit scene scaled to [0, 1]
+    wl.bits = 8
+    ft = np.float32 if os.environ["GLH_BITS"] == "32" else np.float64
+    frames = [[np.asarray(f, dtype=ft) * ft(1.0 / 255.0) for f in wl.frames(o)] for o in range(wl.O)]
+    wl.bits = int(os.environ["GLH_BITS"])
+else:
+    frames = [wl.frames(o) for o in range(wl.O)]
 NAMES = ["", "A evolve+project", "B tile_prep", "B ssd", "B spline_fit", "C sample", "C exp", "D resample",
          "E gather", "F moments"]
-with _lib.Context(wl.P, wl.N, wl.O, max_frames=T, max_search_dim=255 if wl.bits == 16 else 320) as ctx:
+with _lib.Context(wl.P, wl.N, wl.O, max_frames=T, max_search_dim=255 if wl.bits >= 16 else 320) as ctx:
     workloads.setup_context(ctx, wl, frames)
     if HP:
         ctx.set_highpass((int(HP), int(HP)))
@@ -45,6 +51,10 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T, max_search_dim=255 if wl.bits 
     print('  tile_prep split (median ticks): fetch+hist', np.median(tp[:,0]-st[:,1]), 'scan+lut', np.median(tp[:,1]-tp[:,0]), 'median+write', np.median(st[:,2]-tp[:,1]))
     asub = st[:, 15:20]
     print('  A split (median ticks): prologue', np.median(asub[:,0]-st[:,0]), 'record staging', np.median(asub[:,1]-asub[:,0]), 'particle loop', np.median(asub[:,2]-asub[:,1]), 'wait for the other waves + reduce', np.median(asub[:,3]-asub[:,2]), 'box (thread 0)', np.median(asub[:,4]-asub[:,3]), 'barrier', np.median(st[:,1]-asub[:,4]))
+    if wl.bits == 32:  # the float32 branch stamps 20..22 (normalize_box_f32_block) and 13 (ranked)
+        fs = st[:, 20:23]
+        print('  float split (median ticks): fetch', np.median(fs[:,0]-st[:,1]), 'sum', np.median(fs[:,1]-fs[:,0]), 'squares + sum + write', np.median(fs[:,2]-fs[:,1]),
+              'rank', np.median(tp[:,0]-fs[:,2]), 'matched values', np.median(tp[:,1]-tp[:,0]), 'highpass', np.median(st[:,2]-tp[:,1]))
     st = st[:, :10]
     d = np.diff(st, axis=1)  # (P, 9)
     tot = d.sum(axis=1)
