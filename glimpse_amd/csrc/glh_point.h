@@ -24,6 +24,7 @@
 // the reference's public step methods) and are bit-identical on the same inputs.
 #pragma once
 #include "glh_kernels.h"
+#include <type_traits>
 
 namespace glh {
 
@@ -190,11 +191,21 @@ __device__ __forceinline__ void pt_border_rows(uint16_t* keys, int wp, int h) {
 // tile - median_filter(tile) (tracker.py:530-531) of the CDF-matched tile into ws.S, from the bordered key tile: the match
 // is monotone in the key, so the median is taken on the keys and `value_of` (key -> matched value, float64) is applied
 // to the pixel and to its median.  Ends with a barrier.
+// MAP = PtPackPair: the slot of ws.S receives the pixel's key and its median's, packed (key | median << 16), for a caller
+// that maps them afterwards with every thread at work (pt_counts_finish).
+struct PtPackPair {};
 template <int TB, bool GEN, typename MAP>
 __device__ __forceinline__ void pt_highpass_write(const TileWs& ws, const uint16_t* keys, int wp, int w, int h, int hp_rx,
                                                   int hp_ry, int key_max, MAP value_of) {
+  constexpr bool PACK = std::is_same<MAP, PtPackPair>::value;
   const int tid = threadIdx.x, n = w * h;
   const int ld = ws.ld;
+  auto put = [&](int at, int key, int med) {
+    if constexpr (PACK)
+      reinterpret_cast<uint32_t*>(ws.S)[at] = (uint32_t)key | ((uint32_t)med << 16);
+    else
+      ws.S[at] = (float)(value_of(key) - value_of(med));
+  };
   // pad columns [w, ld) are only read for outputs that are discarded; keep them finite
   for (int idx = tid; idx < h * (ld - w); idx += TB) {
     const int r = idx / (ld - w), c = w + idx - r * (ld - w);
@@ -213,7 +224,7 @@ __device__ __forceinline__ void pt_highpass_write(const TileWs& ws, const uint16
       const int r = udiv(by_w2, idx), c = idx - r * w;
       const int key = keys[r * wp + c];
       const int med = median_window(keys, wp, 0, w, h, r, c, hp_rx, hp_ry, key_max);
-      ws.S[r * ld + c] = (float)(value_of(key) - value_of(med));
+      put(r * ld + c, key, med);
     }
     __syncthreads();
     return;
@@ -247,8 +258,8 @@ __device__ __forceinline__ void pt_highpass_write(const TileWs& ws, const uint16
       const int r = r0 + j;
       if (r < h) {
         const glh_us2 key = __builtin_bit_cast(glh_us2, centre[j]);
-        ws.S[r * ld + c0] = (float)(value_of(key.x) - value_of(med.x));
-        if (c0 + 1 < w) ws.S[r * ld + c0 + 1] = (float)(value_of(key.y) - value_of(med.y));
+        put(r * ld + c0, key.x, med.x);
+        if (c0 + 1 < w) put(r * ld + c0 + 1, key.y, med.y);
       }
     };
     glh_us2 ra[5], rb5[5], r2[5], m12[10], m34[10], x[6];
@@ -500,10 +511,21 @@ __device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, con
   }
   __syncthreads();
   if (stp && tid == 0) stp[(size_t)blockIdx.x * PT_NSTAMP + 14] = __builtin_amdgcn_s_memtime();
-  pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, [&](int k) -> double {
+  // The median on the counts, with every pixel's (count, median count) left in its slot of the tile; then the matched values
+  // of the two and their difference by the pixel's own thread: eight evaluations of np.interp (two float64 divisions each)
+  // on every thread, where the median's 220 tasks made sixteen each.
+  pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, PtPackPair{});
+  auto value_of = [&](int k) -> double {
     const int j = jt[k];
     return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, (double)k / (double)n, cq, cv, hist_n);
-  });
+  };
+  const int ld = ws.ld;
+  for (int idx = tid; idx < n; idx += TB) {
+    const int r = udiv(by_w, idx), c = idx - r * w;
+    const uint32_t pair = reinterpret_cast<const uint32_t*>(ws.S)[r * ld + c];
+    ws.S[r * ld + c] = (float)(value_of((int)(pair & 0xffffu)) - value_of((int)(pair >> 16)));
+  }
+  __syncthreads();
 }
 
 // 16-bit frames (uint16 gray or RGB; tracker.py:494-534 works on any dtype): a key is the pixel value or the channel sum
