@@ -91,6 +91,9 @@ def parse_args(argv=None):
                     choices=["cartesian", "cylindrical", "tangent_cartesian", "tangent_cylindrical"],
                     help="motion model of every tracked point (motion.py:92-522); the configurations of BASELINE.json "
                          "use CartesianMotion, real glacier runs TangentCartesianMotion")
+    ap.add_argument("--dem", default="constant", choices=["constant", "gridded"],
+                    help="surfaces of the motion models: the configuration's constants (BASELINE) or a gridded DEM + DEM "
+                         "uncertainty (glimpse.Raster, what real runs bring): the same ground, sampled bilinearly per particle")
     ap.add_argument("--math", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the device-RNG run: fast (GLH_MATH_FAST: FMA / reciprocal forms, what "
                          "Tracker.track(rng='philox') uses) or exact (NumPy rounding, what the host-RNG parity mode uses)")
@@ -569,16 +572,25 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
             "api_tracks_ok": ok, "api_last_means_finite": finite}
 
 
-def apply_motion(ctx, wl, motion):
-    """The workload's points under another motion model than CartesianMotion (motion.py:207-522)."""
-    from glimpse_amd import _lib, workloads
+def apply_motion(ctx, wl, motion, dem="constant"):
+    """The workload's points under another motion model than CartesianMotion (motion.py:207-522), and / or over gridded
+    surfaces: a DEM raster of the scene's ground (z = 0 with centimetre relief, 2 m cells) and a DEM-uncertainty raster."""
+    from glimpse_amd import Raster, _lib, workloads
 
-    if motion == "cartesian":
+    if motion == "cartesian" and dem == "constant":
         return
     full = np.zeros((wl.P, _lib.MOTION_FULL_LEN))
     full[:, :_lib.MOTION_LEN] = wl.params
     full[:, 18] = _lib.MOTION_KINDS[motion]
     full[:, 19] = 0.05  # slope_sigma (tangent models)
+    if dem == "gridded":
+        lo, hi = wl.xy.min(axis=0) - 200.0, wl.xy.max(axis=0) + 200.0
+        nx, ny = (np.ceil((hi - lo) / 2.0)).astype(int)
+        gx, gy = np.meshgrid(np.linspace(0, 6.0, nx), np.linspace(0, 4.0, ny))
+        ctx.set_raster(0, Raster(0.02 * np.sin(gx) * np.cos(gy), x=(lo[0], hi[0]), y=(hi[1], lo[1])))
+        ctx.set_raster(1, Raster(np.full((ny, nx), max(float(wl.params[0, 17]), 0.05)), x=(lo[0], hi[0]), y=(hi[1], lo[1])))
+        full[:, 16:18] = 0.0
+        full[:, 20:22] = 1.0
     if "cylindrical" in motion:  # (speed, direction, dz/dt) and their sigmas
         full[:, 4:7] = (workloads.VELOCITY[0], 0.0, 0.0)
         full[:, 7:10] = (workloads.SIGMA, 0.5, 0.0)
@@ -749,7 +761,7 @@ def worker(args):
     # hence BEFORE anything loads the HIP library (the device count below does)
     cores = usable_cores()
     secondary = (world == 1 and not args.no_secondary and args.workload == "C3" and args.points is None
-                 and args.particles is None and args.motion == "cartesian" and B == 0 and args.channels == 1
+                 and args.particles is None and args.motion == "cartesian" and args.dem == "constant" and B == 0 and args.channels == 1
                  and args.bits == 8)
     rendered = {}
     if world == 1:
@@ -784,7 +796,7 @@ def worker(args):
     _mark("context ready, frames uploaded")
     # one seed for the whole job: the device RNG is keyed on the GLOBAL point index, so the
     # sharded run draws what a single-GPU run of all points would draw
-    apply_motion(ctx, wl, args.motion)
+    apply_motion(ctx, wl, args.motion, args.dem)
     ctx.set_point_offset(point_offset)
     ctx.set_math(args.math)
     ctx.set_track_streams(args.streams)
@@ -889,7 +901,7 @@ def worker(args):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": dict(wl.describe(args.motion), rng="device Philox4x32-7",
+            "config": dict(wl.describe(args.motion), dem=args.dem, rng="device Philox4x32-7",
                            math=args.math, untimed_launches=W * F + B, untimed_kernel_launches=(W * F + B) * streams,
                            parallelism=f"points sharded x{world}",
                            total_points=total_points, frames_per_s=K * F / elapsed, burn_in_steps=B, frames_per_call=C,

@@ -658,8 +658,12 @@ __device__ __forceinline__ void pt_tile_prep_wide(const ObsFrame& ob, const int*
 // surfaces only and carries none of the other code or its registers.
 // FAST: fast arithmetic (GLH_MATH_FAST, glh_math.h): fused multiply-adds, Newton reciprocals, table exp, and a
 // resampling that scans the raw weights and scales the positions instead of normalising (no NumPy-exact sum tree).
-template <int TB, int PPT, int MINW, int NOBS, bool SURF, bool FAST, bool CONTRACT>
+// SC (the surface / generality code): 0 the plain code, 1 the general code over constant surfaces, 2 the general code with
+// the context's rasters (gridded dem / dem_sigma, viewshed).  The raster samples are compiled into code 2 only: in one
+// instantiation with the rest they cost every run of the general code registers (spills inside phase A's loop).
+template <int TB, int PPT, int MINW, int NOBS, int SC, bool FAST, bool CONTRACT>
 __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
+  constexpr bool SURF = SC != 0, GRID = SC == 2;
   constexpr int PT_WAVES = TB / WAVE;
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double tab[16 * GLH_NPOLY];
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
-      evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &oob);
+      evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob);
     } else {
       evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
     }
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     bool bad = false, raster_oob = false;
     uint32_t view_bits = 0u;
     const double zs = motion_term ? m[17] : 0.0;
-    const bool gridded = SURF && motion_term && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
+    const bool gridded = GRID && motion_term && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
 #pragma unroll
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #endif
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
         if constexpr (SURF)
-          evolve_particle<FAST>(x, m, n, tau, tau2, a.surf, &raster_oob);
+          evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &raster_oob);
         else
           evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
         if (i == 0) {
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         if (a.has_dem && motion_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
-          if (SURF && gridded) {
+          if (GRID && gridded) {
             ll = dem_log_likelihood(m, a.surf, x[0], x[1], x[2], &raster_oob);
           } else if (zs != 0.0) {
             const double d = m[16] - x[2];
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           }
           W[i] = ll;
         }
-        if (SURF && a.surf.viewshed.z) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
+        if (GRID && a.surf.viewshed.z) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
 #pragma unroll
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;

@@ -17,6 +17,6 @@
 
 namespace glh {
 const void* GLH_PT_NAME_X(PT_TB, PT_PPT, PT_NOBS, PT_SURF, PT_FAST, PT_CON)() {
-  return (const void*)k_point_step<PT_TB, PT_PPT, 4, PT_NOBS, (bool)PT_SURF, (bool)PT_FAST, (bool)PT_CON>;
+  return (const void*)k_point_step<PT_TB, PT_PPT, 4, PT_NOBS, PT_SURF, (bool)PT_FAST, (bool)PT_CON>;
 }
 }  // namespace glh

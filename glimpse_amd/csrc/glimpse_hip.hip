@@ -29,9 +29,9 @@ GLH_PT_SHAPES(GLH_PT_DECL_SHAPE)
 #undef GLH_PT_DECL
 }  // namespace glh
 
-static const void* pt_kernel(int tb, int ppt, int nobs, bool surf, bool fast, bool con) {
+static const void* pt_kernel(int tb, int ppt, int nobs, int surf, bool fast, bool con) {
 #define GLH_PT_PICK(TB, PPT, NOBS, S, F, C) \
-  if (tb == TB && ppt == PPT && nobs == NOBS && surf == (bool)S && fast == (bool)F && con == (bool)C) \
+  if (tb == TB && ppt == PPT && nobs == NOBS && surf == S && fast == (bool)F && con == (bool)C) \
     return GLH_PT_NAME(TB, PPT, NOBS, S, F, C)();
 #define GLH_PT_PICK_SHAPE(TB, PPT, NOBS) GLH_PT_CODES(GLH_PT_PICK, TB, PPT, NOBS)
   GLH_PT_SHAPES(GLH_PT_PICK_SHAPE)
@@ -764,6 +764,14 @@ static int check_raster_args(int nx, int ny, const double* gx, const double* gy,
     if (!(gy[i] > gy[i - 1])) return fail(GLH_E_INVALID, "gy must be strictly ascending");
   return GLH_OK;
 }
+// (the kernels find a sample's cell from the cell size: glh_math.h, raster_interval)
+static int check_raster_uniform(int nx, int ny, const double* gx, const double* gy, double xmin, double xmax, double ymin,
+                                double ymax) {
+  if (!raster_coordinates_uniform(gx, nx, xmin, xmax) || !raster_coordinates_uniform(gy, ny, ymin, ymax))
+    return fail(GLH_E_UNSUPPORTED, "raster coordinates must be the cell centres of a uniform grid over the outer limits "
+                                   "(glimpse.Grid.x / .y); these are further than a quarter cell from it");
+  return GLH_OK;
+}
 
 extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, int ny, const double* gx,
                               const double* gy, int sx, int sy, double xmin, double xmax, double ymin,
@@ -778,13 +786,14 @@ extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, in
   r.dev = RasterDev{};
   if (!z) return GLH_OK;
   CHK(check_raster_args(nx, ny, gx, gy, sx, sy));
+  CHK(check_raster_uniform(nx, ny, gx, gy, xmin, xmax, ymin, ymax));
   CHK(dalloc(&r.z, (size_t)nx * ny));
   CHK(dalloc(&r.gx, (size_t)nx));
   CHK(dalloc(&r.gy, (size_t)ny));
   HIPCHK(hipMemcpy(r.z, z, (size_t)nx * ny * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(r.gx, gx, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(r.gy, gy, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
-  r.dev = RasterDev{r.z, r.gx, r.gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax};
+  r.dev = raster_dev(r.z, r.gx, r.gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax);
   return GLH_OK;
 }
 
@@ -1558,18 +1567,18 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     // (the contract is independent of the surfaces and motion models: the general code has its instantiation too)
     bool plain = c->hp_rx == 2 && c->hp_ry == 2 && c->interp_k == 3;  // the 5 x 5 median, bicubic sampling ...
     for (int o = 0; o < O; ++o) plain &= c->obs[o].bits == 8;            // ... of 8-bit frames
-    const bool surf = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z || !c->all_cartesian || (fast && !common) ||
-                      !plain;
+    const bool rast = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z;  // (the instantiations with the raster samples)
+    const bool surf = rast || !c->all_cartesian || (fast && !common) || !plain;
     int tbv = 512, nobsv = O;
     if (big) {
       tbv = 1024;
       if (ppt != 10) ppt = 0;
     }
     c->last_variant[0] = tbv; c->last_variant[1] = ppt; c->last_variant[2] = nobsv;
-    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0);
+    c->last_variant[3] = (fast ? 1 : 0) | (surf ? 2 : 0) | (common ? 4 : 0) | (rast ? 8 : 0);
     // codes the library carries (glh_point_variants.h): exact / exact general / fast common / fast general / fast
     // general under the contract
-    const void* kern = pt_kernel(tbv, ppt, nobsv, surf, fast, surf ? common : fast);
+    const void* kern = pt_kernel(tbv, ppt, nobsv, rast ? 2 : (surf ? 1 : 0), fast, surf ? common : fast);
     if (!kern) return fail(GLH_E_STATE, "no instantiation of the fused kernel for <%d, %d, %d>", tbv, ppt, nobsv);
     void* kargs[] = {(void*)&a};
     HIPCHK(hipLaunchKernel(kern, grid, block, kargs, lds, on));
@@ -2521,6 +2530,7 @@ extern "C" int glh_stage_raster_sample(int dev, const double* z, int nx, int ny,
                                        const double* xy, int n, int order, double* values, uint8_t* oob) {
   if (!z || !xy || !values || !oob || n <= 0 || (order != 0 && order != 1)) return fail(GLH_E_INVALID, "bad argument");
   CHK(check_raster_args(nx, ny, gx, gy, sx, sy));
+  CHK(check_raster_uniform(nx, ny, gx, gy, xmin, xmax, ymin, ymax));
   HIPCHK(hipSetDevice(dev));
   DevBuf dz, dgx, dgy, dxy, dv, do_;
   CHK(dz.up(z, (size_t)nx * ny * 8));
@@ -2529,7 +2539,7 @@ extern "C" int glh_stage_raster_sample(int dev, const double* z, int nx, int ny,
   CHK(dxy.up(xy, (size_t)n * 16));
   CHK(dv.alloc((size_t)n * 8));
   CHK(do_.alloc((size_t)n));
-  RasterDev r{dz.as<double>(), dgx.as<double>(), dgy.as<double>(), nx, ny, sx, sy, xmin, xmax, ymin, ymax};
+  const RasterDev r = raster_dev(dz.as<double>(), dgx.as<double>(), dgy.as<double>(), nx, ny, sx, sy, xmin, xmax, ymin, ymax);
   hipLaunchKernelGGL(k_raster_sample, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, 0, r, dxy.as<double>(), n, order,
                      dv.as<double>(), do_.as<uint8_t>());
   CHK(finish());

@@ -192,4 +192,13 @@ void hc_project_fast(const double* cam24, const double* xyz, int n, double* uv) 
   const unsigned f = cam_flags(c);
   for (int i = 0; i < n; ++i) project_fast(c, f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
 }
+// raster_interval (glh_math.h): the interval of every x in the coordinate array g[n]
+void hc_raster_interval(const double* g, int n, double lo, double hi, const double* x, int m, int* out) {
+  double a, b;  // (lo, hi: the outer limits the guess is made from -- Raster.xlim for cell centres g)
+  for (int i = 0; i < m; ++i) {
+    out[i] = raster_interval(g, n, x[i], lo, (double)n / (hi - lo), a, b);
+    if (a != g[out[i]] || b != g[out[i] + 1]) out[i] = -1000;
+  }
+}
+int hc_raster_uniform(const double* g, int n, double lo, double hi) { return raster_coordinates_uniform(g, n, lo, hi) ? 1 : 0; }
 }

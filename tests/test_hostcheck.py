@@ -241,3 +241,33 @@ def test_cell_form_of_the_fitted_surface_equals_the_coefficient_form(hc):
         scale = np.abs(coef).max()
         worst = max(worst, np.abs(out[:, 1] - out[:, 0]).max() / scale)
     assert worst < 5e-14, worst
+
+
+def test_raster_interval_is_the_clipped_searchsorted(hc):
+    """find_indices of scipy's RegularGridInterpolator: clip(searchsorted(g, x) - 1, 0, n - 2).  The kernels guess the
+    interval from the cell size and move by at most one (glh_math.h: raster_interval): same answer on the cell centres
+    of a uniform grid (np.linspace, what Raster.x is) -- at and around every centre, between them, outside the ends, with
+    centres perturbed by up to a fifth of a cell; coordinates further than a quarter cell from uniform are refused by the
+    library (raster_coordinates_uniform)."""
+    rng = np.random.default_rng(5)
+    grids = [np.linspace(-13.7, 250.3, n) for n in (2, 3, 17, 400, 2001)] + [np.linspace(4.1e5, 4.3e5, 1999) + 0.25]
+    jitter = np.linspace(0.0, 300.0, 601)
+    jitter[1:-1] += rng.uniform(-0.1, 0.1, 599)  # (cells of 0.5: up to a fifth of a cell)
+    grids.append(jitter)
+    for g in grids:
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        assert (np.diff(g) > 0).all()
+        x = np.concatenate([g, np.nextafter(g, -np.inf), np.nextafter(g, np.inf), (g[:-1] + g[1:]) / 2,
+                            rng.uniform(g[0] - 3.0, g[-1] + 3.0, 4000), [g[0] - 1e9, g[-1] + 1e9]])
+        want = np.clip(np.searchsorted(g, x, side="left") - 1, 0, len(g) - 2).astype(np.int32)
+        got = np.empty(len(x), dtype=np.int32)
+        # (outer limits as Raster._limits makes them from cell centres: half a cell beyond the ends)
+        d = (g[-1] - g[0]) / (len(g) - 1)
+        lo, hi = C.c_double(g[0] - d / 2), C.c_double(g[-1] + d / 2)
+        assert hc.hc_raster_uniform(p(g), len(g), lo, hi) == 1
+        hc.hc_raster_interval(p(g), len(g), lo, hi, p(np.ascontiguousarray(x)), len(x), p(got))
+        np.testing.assert_array_equal(got, want)
+    for g in (np.sort(rng.uniform(0, 100, 300)), np.cumsum(rng.uniform(0.01, 5.0, 64) ** 3)):
+        g = np.ascontiguousarray(g)
+        d = (g[-1] - g[0]) / (len(g) - 1)
+        assert hc.hc_raster_uniform(p(g), len(g), C.c_double(g[0] - d / 2), C.c_double(g[-1] + d / 2)) == 0

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Registers / scratch / code size of ONE instantiation of the fused kernel in seconds (the full library takes 1.5 min):
 # a scratch translation unit that includes the kernel headers and instantiates only the requested variant.
-#   tools/regcheck.sh [TB PPT NOBS SURF FAST CONTRACT]      (default: 512 10 1 false true true = C3)
+#   tools/regcheck.sh [TB PPT NOBS SURF FAST CONTRACT]      (default: 512 10 1 false true true = C3; SURF: false / true / 2)
 #   REGCHECK_FLAGS: extra compiler flags (e.g. "-mllvm -disable-machine-licm")
 TB=${1:-512}; PPT=${2:-10}; NOBS=${3:-1}; SURF=${4:-false}; FAST=${5:-true}; CON=${6:-$FAST}
+case $SURF in false) SURF=0 ;; true) SURF=1 ;; esac   # (the surface code: 0 plain, 1 general, 2 general with rasters)
 OUT=${REGCHECK_OUT:-/tmp/regcheck}
 mkdir -p $OUT
 cat > $OUT/one.hip <<EOT
