@@ -195,8 +195,8 @@ __device__ __forceinline__ uint32_t viewshed_bits(const Surfaces& surf, double x
 
 // CartesianMotion.compute_log_likelihoods (motion.py:181-204) for one (evolved) particle
 __device__ __forceinline__ double dem_log_likelihood(const double* m, const Surfaces& surf, double x, double y,
-                                                     double z, bool* oob) {
-  const double zd = dem_at(m, surf, x, y, oob), zs = dem_sigma_at(m, surf, x, y, oob);
+                                                     double z, bool* oob, const RasterPatch* patches = nullptr) {
+  const double zd = dem_at(m, surf, x, y, oob, patches), zs = dem_sigma_at(m, surf, x, y, oob, patches);
   if (zs != 0.0) {
     const double d = zd - z;
     return (1.0 / (2.0 * (zs * zs))) * (d * d);
@@ -313,7 +313,8 @@ __device__ __forceinline__ void evolve_cartesian_m(double* p, const double* m, c
 // run over constant surfaces paid for their registers)
 template <bool FAST = false, bool GRID = true>
 __device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
-                                                double tau2, const Surfaces& surf, bool* oob) {
+                                                double tau2, const Surfaces& surf, bool* oob,
+                                                const RasterPatch* patches = nullptr) {
   const int kind = (int)m[18];
   if (kind == GLH_MOTION_CARTESIAN) {
     evolve_cartesian_m<FAST>(p, m, n, tau, tau2);
@@ -345,11 +346,11 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
   // tangent models: the height follows the surface plus a random walk of the offset
   const double dx = tau * p[3] + 0.5 * a[0] * tau2;
   const double dy = tau * p[4] + 0.5 * a[1] * tau2;
-  double z_off = p[2] - (GRID ? dem_at(m, surf, p[0], p[1], oob) : m[16]);
+  double z_off = p[2] - (GRID ? dem_at(m, surf, p[0], p[1], oob, patches) : m[16]);
   z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;
   p[1] += dy;
-  p[2] = (GRID ? dem_at(m, surf, p[0], p[1], oob) : m[16]) + z_off;
+  p[2] = (GRID ? dem_at(m, surf, p[0], p[1], oob, patches) : m[16]) + z_off;
   p[3] += tau * a[0];
   p[4] += tau * a[1];
 }

@@ -357,9 +357,12 @@ GLH_HD RasterDev raster_dev(const double* z, const double* gx, const double* gy,
 // sample needs anyway, instead of log2(n) dependent ones (22 memory latencies per sample of a 2 000 x 2 000 DEM).
 // With |g[j] - ideal_j| < d / 4 the guess floor((x - min) / d - 1 / 2) is within one of the answer, so one step ends
 // where the search would.  ga, gb: g[i], g[i + 1].
-GLH_HD int raster_interval(const double* g, int n, double x, double lo_limit, double k, double& ga, double& gb) {
+GLH_HD int raster_guess(int n, double x, double lo_limit, double k) {
   const double t = (x - lo_limit) * k - 0.5;
-  int i = t > 0.0 ? (t < (double)(n - 2) ? (int)t : n - 2) : 0;  // (NaN: 0; the caller has tested x against the limits)
+  return t > 0.0 ? (t < (double)(n - 2) ? (int)t : n - 2) : 0;  // (NaN: 0; the caller has tested x against the limits)
+}
+// (g may be a window of the coordinates placed so that g[j] is coordinate j for j = i - 1 .. i + 2: all this reads)
+GLH_HD int raster_interval(const double* g, int n, double x, int i, double& ga, double& gb) {
   ga = g[i];
   gb = g[i + 1];
   if (i > 0 && ga >= x) {
@@ -382,24 +385,63 @@ inline bool raster_coordinates_uniform(const double* g, int n, double lo_limit, 
   return true;
 }
 
+// A window of a raster held near the samples (the fused kernel: LDS): nodes [i0, i0 + w) x [j0, j0 + h) in INTERVAL order
+// (ascending coordinates, whichever way the array runs) and their coordinates.  A tracked point's particles fall into a few
+// cells of a DEM; from the window a sample costs LDS reads where it cost two rounds of memory latency.
+constexpr int GLH_PATCH_W = 12;
+struct RasterPatch {
+  double z[GLH_PATCH_W * GLH_PATCH_W];
+  double gx[GLH_PATCH_W], gy[GLH_PATCH_W];
+  int32_t i0, j0, w, h;  // w = 0: nothing held
+};
+// where the window around (x, y) starts, and how many nodes it holds
+GLH_HD void raster_patch_origin(const RasterDev& r, double x, double y, int& i0, int& j0, int& w, int& h) {
+  w = r.nx < GLH_PATCH_W ? r.nx : GLH_PATCH_W;
+  h = r.ny < GLH_PATCH_W ? r.ny : GLH_PATCH_W;
+  const bool in = x >= r.xmin && x <= r.xmax && y >= r.ymin && y <= r.ymax;  // (false for NaN: the window starts at 0)
+  const int ic = in ? raster_guess(r.nx, x, r.xmin, r.kx) : 0, jc = in ? raster_guess(r.ny, y, r.ymin, r.ky) : 0;
+  i0 = ic - (w / 2 - 1);
+  j0 = jc - (h / 2 - 1);
+  i0 = i0 < 0 ? 0 : (i0 > r.nx - w ? r.nx - w : i0);
+  j0 = j0 < 0 ? 0 : (j0 > r.ny - h ? r.ny - h : j0);
+}
+// the raster's value at node (ix, iy) of the interval order
+GLH_HD double raster_node(const RasterDev& r, int ix, int iy) {
+  const int col = r.sx > 0 ? ix : r.nx - 1 - ix, row = r.sy > 0 ? iy : r.ny - 1 - iy;
+  return r.z[(size_t)row * r.nx + col];
+}
+
 // order 1: bilinear (RegularGridInterpolator method 'linear'); order 0: 'nearest'.  Sets *oob when the
-// point is outside the raster's outer limits (the reference raises ValueError there).
-GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob) {
+// point is outside the raster's outer limits (the reference raises ValueError there).  `patch`: a window of THIS raster
+// (or null); a sample whose interval and its neighbours lie inside is read from it -- same values, same arithmetic.
+GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob, const RasterPatch* patch = nullptr) {
   if (!(x >= r.xmin && x <= r.xmax && y >= r.ymin && y <= r.ymax)) {
     *oob = true;
     return NAN;
   }
   double xa, xb, ya, yb;
-  const int i0 = raster_interval(r.gx, r.nx, x, r.xmin, r.kx, xa, xb), i1 = raster_interval(r.gy, r.ny, y, r.ymin, r.ky, ya, yb);
+  const int gi = raster_guess(r.nx, x, r.xmin, r.kx), gj = raster_guess(r.ny, y, r.ymin, r.ky);
+  if (patch && order == 1) {
+    // the step of raster_interval reads nodes guess - 1 .. guess + 2 (clipped to the raster): all inside the window?
+    const int li = gi - patch->i0, lj = gj - patch->j0;
+    const bool in_x = (li >= 1 || gi == 0) && li >= 0 && (li + 2 < patch->w || gi == r.nx - 2) && li + 1 < patch->w;
+    const bool in_y = (lj >= 1 || gj == 0) && lj >= 0 && (lj + 2 < patch->h || gj == r.ny - 2) && lj + 1 < patch->h;
+    if (in_x && in_y) {
+      const int i0 = raster_interval(patch->gx - patch->i0, r.nx, x, gi, xa, xb) - patch->i0;
+      const int i1 = raster_interval(patch->gy - patch->j0, r.ny, y, gj, ya, yb) - patch->j0;
+      const double y0 = (x - xa) / (xb - xa);
+      const double y1 = (y - ya) / (yb - ya);
+      const double* z = patch->z + i1 * GLH_PATCH_W + i0;
+      return z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) +
+             z[GLH_PATCH_W + 1] * y0 * y1;
+    }
+  }
+  const int i0 = raster_interval(r.gx, r.nx, x, gi, xa, xb), i1 = raster_interval(r.gy, r.ny, y, gj, ya, yb);
   const double y0 = (x - xa) / (xb - xa);
   const double y1 = (y - ya) / (yb - ya);
-  auto V = [&](int ix, int iy) -> double {
-    const int col = r.sx > 0 ? ix : r.nx - 1 - ix, row = r.sy > 0 ? iy : r.ny - 1 - iy;
-    return r.z[(size_t)row * r.nx + col];
-  };
-  if (order == 0) return V(y0 <= 0.5 ? i0 : i0 + 1, y1 <= 0.5 ? i1 : i1 + 1);
-  return V(i0, i1) * (1.0 - y0) * (1.0 - y1) + V(i0, i1 + 1) * (1.0 - y0) * y1 + V(i0 + 1, i1) * y0 * (1.0 - y1) +
-         V(i0 + 1, i1 + 1) * y0 * y1;
+  if (order == 0) return raster_node(r, y0 <= 0.5 ? i0 : i0 + 1, y1 <= 0.5 ? i1 : i1 + 1);
+  return raster_node(r, i0, i1) * (1.0 - y0) * (1.0 - y1) + raster_node(r, i0, i1 + 1) * (1.0 - y0) * y1 +
+         raster_node(r, i0 + 1, i1) * y0 * (1.0 - y1) + raster_node(r, i0 + 1, i1 + 1) * y0 * y1;
 }
 
 // The surface height / its sigma under (x, y) for one point: the context's raster when the point's
@@ -408,11 +450,13 @@ GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, b
 struct Surfaces {
   RasterDev dem, dem_sigma, viewshed;
 };
-GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob) {
-  return m[20] != 0.0 ? raster_sample(s.dem, x, y, 1, oob) : m[16];
+// (patches: windows of the dem [0] and the dem_sigma [1] raster, or null)
+GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob, const RasterPatch* patches = nullptr) {
+  return m[20] != 0.0 ? raster_sample(s.dem, x, y, 1, oob, patches) : m[16];
 }
-GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double y, bool* oob) {
-  return m[21] != 0.0 ? raster_sample(s.dem_sigma, x, y, 1, oob) : m[17];
+GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double y, bool* oob,
+                           const RasterPatch* patches = nullptr) {
+  return m[21] != 0.0 ? raster_sample(s.dem_sigma, x, y, 1, oob, patches ? patches + 1 : nullptr) : m[17];
 }
 
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is

@@ -63,6 +63,42 @@ __device__ __forceinline__ void pt_put(double (&v)[PPT], int r, double q) {
   for (int k = 0; k < PPT; ++k) v[k] = r == k ? q : v[k];
 }
 
+// Windows of the dem and dem_sigma rasters around the point, in LDS (instantiations with the raster samples only)
+template <bool GRID>
+struct PtPatches {
+  __device__ __forceinline__ const RasterPatch* get() const { return nullptr; }
+};
+template <>
+struct PtPatches<true> {
+  RasterPatch p[2];
+  __device__ __forceinline__ const RasterPatch* get() const { return p; }
+};
+// Whole block: the window of raster r around (x, y) into *dst (LDS).  No barrier.
+template <int TB>
+__device__ __forceinline__ void pt_patch_load(const RasterDev& r, double x, double y, bool used, RasterPatch* dst) {
+  const int tid = threadIdx.x;
+  if (!r.z || !used) {  // (uniform)
+    if (tid == 0) dst->w = dst->h = dst->i0 = dst->j0 = 0;
+    return;
+  }
+  int i0, j0, w, h;
+  raster_patch_origin(r, x, y, i0, j0, w, h);  // (the same in every thread)
+  static_assert(TB >= GLH_PATCH_W * GLH_PATCH_W + 2 * GLH_PATCH_W, "one item per thread");
+  const int lj = tid / GLH_PATCH_W, li = tid - lj * GLH_PATCH_W;
+  if (tid < GLH_PATCH_W * GLH_PATCH_W) {
+    if (li < w && lj < h) dst->z[tid] = raster_node(r, i0 + li, j0 + lj);
+  } else if (tid < GLH_PATCH_W * GLH_PATCH_W + GLH_PATCH_W) {
+    const int k = tid - GLH_PATCH_W * GLH_PATCH_W;
+    if (k < w) dst->gx[k] = r.gx[i0 + k];
+  } else if (tid < GLH_PATCH_W * GLH_PATCH_W + 2 * GLH_PATCH_W) {
+    const int k = tid - GLH_PATCH_W * GLH_PATCH_W - GLH_PATCH_W;
+    if (k < h) dst->gy[k] = r.gy[j0 + k];
+  }
+  if (tid == 0) {
+    dst->i0 = i0; dst->j0 = j0; dst->w = w; dst->h = h;
+  }
+}
+
 struct PointArgs {
   // The resampled state is stored RUN-LENGTH COMPACT: systematic resampling returns its sources in order, so the
   // copies of a source are adjacent and identical; only the first of each run is written (records 0 .. U-1) and
@@ -675,6 +711,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   __shared__ int s_status[NOBS];
   __shared__ double s_u;     // np.random.random() of this point's systematic resampling (tracker.py:173)
   __shared__ double s_K[6];  // the point's first evolved particle: pivot of the shifted moments (phase A -> F)
+  __shared__ PtPatches<GRID> s_patches;  // (code 2: windows of the dem / dem_sigma rasters around the point)
   __shared__ CamDev s_cam[NOBS];           // cameras: LDS broadcast reads instead of ~60 live SGPRs each
   __shared__ double s_m[GLH_MOTION_FULL_LEN];  // this point's motion parameters: the loops below store to global
                                           // memory, so reading them through a global pointer would reload
@@ -864,6 +901,16 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // consecutive lanes store, and mostly load, consecutive 16-byte words.
   const int rec_stride = COMMON || uin ? 1 : 3, chunk_stride = COMMON || uin ? N : 1;
   const double2* Pin2 = reinterpret_cast<const double2*>(Pin);
+  if constexpr (GRID) {
+    // The point's particles fall into a few cells of its surfaces: a 12 x 12-node window of each raster around particle
+    // 0 (before the step) is brought into LDS, and the samples of phases A and E read it -- a sample from memory is two
+    // rounds of latency (coordinates, then nodes), and the tangent models take two per particle.  Samples that leave the
+    // window read the raster as before.
+    const double2 q0 = Pin2[(size_t)s_rec[0] * rec_stride];
+    pt_patch_load<TB>(a.surf.dem, q0.x, q0.y, m[20] != 0.0, &s_patches.p[0]);
+    pt_patch_load<TB>(a.surf.dem_sigma, q0.x, q0.y, m[21] != 0.0, &s_patches.p[1]);
+    __syncthreads();
+  }
   // the evolve step of particle k re-applied to its pre-evolve record x (phase E)
   // CartesianMotion with axyz_sigma[2] == 0 (uniform): the third normal only ever meets that zero
   const bool third = SURF || m[15] != 0.0;
@@ -872,7 +919,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
-      evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob);
+      evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
     } else {
       evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
     }
@@ -936,7 +983,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #endif
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
         if constexpr (SURF)
-          evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &raster_oob);
+          evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &raster_oob, s_patches.get());
         else
           evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
         if (i == 0) {
@@ -949,7 +996,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
           if (GRID && gridded) {
-            ll = dem_log_likelihood(m, a.surf, x[0], x[1], x[2], &raster_oob);
+            ll = dem_log_likelihood(m, a.surf, x[0], x[1], x[2], &raster_oob, s_patches.get());
           } else if (zs != 0.0) {
             const double d = m[16] - x[2];
             ll = (1.0 / (2.0 * (zs * zs))) * (d * d);

@@ -40,9 +40,10 @@ static const void* pt_kernel(int tb, int ppt, int nobs, int surf, bool fast, boo
   return nullptr;
 }
 
-static std::vector<const void*> pt_all_kernels() {
-  std::vector<const void*> v;
-#define GLH_PT_PUSH(TB, PPT, NOBS, S, F, C) v.push_back(GLH_PT_NAME(TB, PPT, NOBS, S, F, C)());
+// (every instantiation with its surface code: code 2 holds the raster windows in static LDS)
+static std::vector<std::pair<const void*, int>> pt_all_kernels() {
+  std::vector<std::pair<const void*, int>> v;
+#define GLH_PT_PUSH(TB, PPT, NOBS, S, F, C) v.push_back({GLH_PT_NAME(TB, PPT, NOBS, S, F, C)(), S});
 #define GLH_PT_PUSH_SHAPE(TB, PPT, NOBS) GLH_PT_CODES(GLH_PT_PUSH, TB, PPT, NOBS)
   GLH_PT_SHAPES(GLH_PT_PUSH_SHAPE)
 #undef GLH_PT_PUSH_SHAPE
@@ -82,6 +83,8 @@ static int fail(int code, const char* fmt, ...) {
 // LDS plan of the fused kernel (glh_point.h): c[N] + region 2
 constexpr int PT_LDS_MAX = 152 * 1024;   // dynamic LDS of one workgroup (static <= 5 KB on top, 160 KB per CU)
 constexpr int PT_LDS_HALF = 75 * 1024;   // dynamic LDS that still lets two workgroups share a CU
+constexpr int PT_PATCH_LDS = 3 * 1024;   // static LDS of the raster windows (code 2: glh_point.h, PtPatches), taken off both
+static_assert(PT_PATCH_LDS >= 2 * (int)sizeof(RasterPatch), "the raster windows fit their share");
 
 // ------------------------------------------------------------------------------------------
 // stages (for the event timers)
@@ -463,8 +466,9 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
     hipError_t e2 = hipFuncSetAttribute((const void*)k_ssd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipError_t e3 = hipFuncSetAttribute((const void*)k_tileprep, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipError_t e4 = hipSuccess;
-    for (const void* f : pt_all_kernels()) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX);
+    for (const auto& f : pt_all_kernels()) {
+      hipError_t e = hipFuncSetAttribute(f.first, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         PT_LDS_MAX - (f.second == 2 ? PT_PATCH_LDS : 0));
       if (e != hipSuccess) e4 = e;
     }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
@@ -1421,14 +1425,17 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
   // (the template CDF lies over the search tile while the LUT is made: no bytes of its own)
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2;
+  // (a context with rasters runs the instantiations that keep windows of them in static LDS)
+  const int patch = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z ? PT_PATCH_LDS : 0;
+  const int lds_half = PT_LDS_HALF - patch, lds_max = PT_LDS_MAX - patch;
   int r2;
-  if (cN + std::max(r2_min, typical) <= PT_LDS_HALF)
-    r2 = PT_LDS_HALF - cN;
+  if (cN + std::max(r2_min, typical) <= lds_half)
+    r2 = lds_half - cN;
   else
-    r2 = std::min(PT_LDS_MAX - cN, 72 * 1024);
-  if (getenv("GLH_PT_ONE_BLOCK")) r2 = std::min(PT_LDS_MAX - cN, 100 * 1024);  // experiment: 1 workgroup / CU
+    r2 = std::min(lds_max - cN, 72 * 1024);
+  if (getenv("GLH_PT_ONE_BLOCK")) r2 = std::min(lds_max - cN, 100 * 1024);  // experiment: 1 workgroup / CU
   if (mode == 2) r2 = r2_min;  // test hook: typical tiles no longer fit -> HBM workspaces
-  if (r2 < r2_min || cN + r2 > PT_LDS_MAX) return false;  // (N beyond ~10 900: the staged kernels take the step)
+  if (r2 < r2_min || cN + r2 > lds_max) return false;  // (N beyond ~10 900: the staged kernels take the step)
   *r2_bytes = r2;
   return true;
 }

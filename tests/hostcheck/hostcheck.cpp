@@ -196,9 +196,33 @@ void hc_project_fast(const double* cam24, const double* xyz, int n, double* uv) 
 void hc_raster_interval(const double* g, int n, double lo, double hi, const double* x, int m, int* out) {
   double a, b;  // (lo, hi: the outer limits the guess is made from -- Raster.xlim for cell centres g)
   for (int i = 0; i < m; ++i) {
-    out[i] = raster_interval(g, n, x[i], lo, (double)n / (hi - lo), a, b);
+    out[i] = raster_interval(g, n, x[i], raster_guess(n, x[i], lo, (double)n / (hi - lo)), a, b);
     if (a != g[out[i]] || b != g[out[i] + 1]) out[i] = -1000;
   }
+}
+// raster_sample with and without a window of the raster around (cx, cy): values [m][2], hits = samples served by the window
+int hc_raster_patch(const double* z, int nx, int ny, const double* gx, const double* gy, int sx, int sy, double xmin, double xmax,
+                    double ymin, double ymax, double cx, double cy, const double* xy, int m, double* values) {
+  const RasterDev r = raster_dev(z, gx, gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax);
+  RasterPatch p;
+  raster_patch_origin(r, cx, cy, p.i0, p.j0, p.w, p.h);
+  for (int j = 0; j < p.h; ++j)
+    for (int i = 0; i < p.w; ++i) p.z[j * GLH_PATCH_W + i] = raster_node(r, p.i0 + i, p.j0 + j);
+  for (int i = 0; i < p.w; ++i) p.gx[i] = gx[p.i0 + i];
+  for (int j = 0; j < p.h; ++j) p.gy[j] = gy[p.j0 + j];
+  // (count the hits by poisoning the raster itself: a sample that still reads it differs)
+  int hits = 0;
+  std::vector<double> poison((size_t)nx * ny, 1e300);
+  RasterDev rp = r;
+  rp.z = poison.data();
+  for (int i = 0; i < m; ++i) {
+    bool o1 = false, o2 = false, o3 = false;
+    values[2 * i] = raster_sample(r, xy[2 * i], xy[2 * i + 1], 1, &o1);
+    values[2 * i + 1] = raster_sample(r, xy[2 * i], xy[2 * i + 1], 1, &o2, &p);
+    const double vp = raster_sample(rp, xy[2 * i], xy[2 * i + 1], 1, &o3, &p);
+    if (!o3 && vp == values[2 * i + 1]) ++hits;
+  }
+  return hits;
 }
 int hc_raster_uniform(const double* g, int n, double lo, double hi) { return raster_coordinates_uniform(g, n, lo, hi) ? 1 : 0; }
 }

@@ -271,3 +271,30 @@ def test_raster_interval_is_the_clipped_searchsorted(hc):
         g = np.ascontiguousarray(g)
         d = (g[-1] - g[0]) / (len(g) - 1)
         assert hc.hc_raster_uniform(p(g), len(g), C.c_double(g[0] - d / 2), C.c_double(g[-1] + d / 2)) == 0
+
+
+def test_raster_window_serves_the_same_samples(hc):
+    """A window of a raster around a point (glh_math.h: RasterPatch -- the fused kernel keeps one per surface in LDS): the
+    samples it serves are bit for bit the raster's own, for either orientation of the array, at the raster's edges and
+    corners, for rasters smaller than the window; samples outside it fall through to the raster."""
+    rng = np.random.default_rng(9)
+    for nx, ny, sx, sy in ((300, 200, 1, -1), (40, 50, -1, 1), (7, 9, 1, 1), (2, 2, 1, -1), (12, 13, -1, -1)):
+        z = np.ascontiguousarray(rng.standard_normal((ny, nx)))
+        xlim, ylim = (100.0, 100.0 + 2.0 * nx), (-50.0, -50.0 + 3.0 * ny)
+        gx = np.ascontiguousarray(np.linspace(xlim[0] + 1.0, xlim[1] - 1.0, nx))
+        gy = np.ascontiguousarray(np.linspace(ylim[0] + 1.5, ylim[1] - 1.5, ny))
+        for cx, cy in ((xlim[0] + 0.3, ylim[0] + 0.1), (xlim[1] - 0.2, ylim[1] - 0.4), (np.mean(xlim), np.mean(ylim)),
+                       (xlim[0] + 9.0, ylim[1] - 7.0)):
+            near = np.column_stack((cx + rng.uniform(-6, 6, 400), cy + rng.uniform(-9, 9, 400)))
+            on_nodes = np.column_stack((rng.choice(gx, 60), rng.choice(gy, 60)))
+            far = np.column_stack((rng.uniform(*xlim, 100), rng.uniform(*ylim, 100)))
+            xy = np.ascontiguousarray(np.vstack((near, on_nodes, far, [[cx, cy]])))
+            xy[:, 0] = np.clip(xy[:, 0], *xlim)
+            xy[:, 1] = np.clip(xy[:, 1], *ylim)
+            vals = np.empty((len(xy), 2))
+            hits = hc.hc_raster_patch(p(z), nx, ny, p(gx), p(gy), sx, sy, C.c_double(xlim[0]), C.c_double(xlim[1]),
+                                      C.c_double(ylim[0]), C.c_double(ylim[1]), C.c_double(cx), C.c_double(cy), p(xy),
+                                      len(xy), p(vals))
+            np.testing.assert_array_equal(vals[:, 0], vals[:, 1])
+            assert np.isfinite(vals).all()
+            assert hits >= (300 if min(nx, ny) >= 12 else len(xy) if max(nx, ny) <= 12 else 1), hits
