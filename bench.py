@@ -687,6 +687,8 @@ def secondary_legs(args, device, T, rendered, seed):
             ("C2", "C2", None, "fast", min(T, workloads.CONFIGS["C2"]["frames"]), "C3", 1, 8, "cartesian"),
             # TangentCartesianMotion, the model of real glacier runs (motion.py:339-430): the general instantiation
             ("C3_tangent", "C3", None, "fast", T, "C3", 1, 8, "tangent_cartesian"),
+            # ... over a gridded DEM + DEM uncertainty (glimpse.Raster, 2 m cells): what real runs bring
+            ("C3_tangent_dem", "C3", None, "fast", T, "C3", 1, 8, "tangent_cartesian+dem"),
             ("C3_rgb", "C3", None, "fast", T, "C3_rgb", 3, 8, "cartesian"),
             ("C3_u16", "C3", None, "fast", T, "C3_u16", 1, 16, "cartesian"),
             # float32 frames (an orthophoto / reflectance observer): the C3 frames scaled to [0, 1]
@@ -705,11 +707,14 @@ def secondary_legs(args, device, T, rendered, seed):
             with _lib.Context(wl.P, wl.N, wl.O, device_id=device, max_tile=max(wl.tile), max_search_dim=dim,
                               max_frames=T) as ctx:
                 workloads.setup_context(ctx, wl, frames)
-                apply_motion(ctx, wl, motion)
+                motion, _, dem = motion.partition("+")
+                apply_motion(ctx, wl, motion, "gridded" if dem else "constant")
                 ctx.set_track_streams(1 if key == "C3_one_stream" else args.streams)
                 legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
                 if motion != "cartesian":
                     legs[key]["motion"] = motion
+                if dem:
+                    legs[key]["dem"] = "gridded"
         except Exception as e:  # noqa: BLE001
             legs[key] = {"error": repr(e)}
     return legs

@@ -177,7 +177,9 @@ int glh_set_motion(glh_ctx* ctx, const double* params);
  * bilinearly at every particle, Raster.sample order 1, raster.py:913-1027) or _VIEWSHED (nearest
  * cell, order 0, Tracker.test_particles tracker.py:114-117).  z [ny][nx] is Raster.array; gx / gy are
  * the ASCENDING cell-centre coordinates (Grid.x / Grid.y reversed where dx / dy < 0); sx, sy the signs
- * of dx, dy; the limits are Grid.min / Grid.max.  z = NULL removes the raster.  nx, ny >= 2.        */
+ * of dx, dy; the limits are Grid.min / Grid.max.  z = NULL removes the raster.  nx, ny >= 2.  The coordinates must be
+ * those of a uniform grid over the limits (np.linspace, as Grid makes them) to within a quarter cell:
+ * GLH_E_UNSUPPORTED otherwise (the kernels find a sample's cell from the cell size).                  */
 #define GLH_RASTER_DEM 0
 #define GLH_RASTER_DEM_SIGMA 1
 #define GLH_RASTER_VIEWSHED 2

@@ -31,12 +31,10 @@ with _lib.Context(wl.P, wl.N, wl.O, max_frames=T, max_search_dim=255 if wl.bits 
     workloads.setup_context(ctx, wl, frames)
     if HP:
         ctx.set_highpass((int(HP), int(HP)))
-    if os.environ.get("GLH_MOTION"):  # e.g. tangent_cartesian: the general instantiation (bench.py: apply_motion)
-        full = np.zeros((wl.P, _lib.MOTION_FULL_LEN))
-        full[:, :_lib.MOTION_LEN] = wl.params
-        full[:, 18] = _lib.MOTION_KINDS[os.environ["GLH_MOTION"]]
-        full[:, 19] = 0.05
-        ctx.set_motion(full)
+    if os.environ.get("GLH_MOTION") or os.environ.get("GLH_DEM"):  # e.g. tangent_cartesian / gridded (bench.py: apply_motion)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        bench.apply_motion(ctx, wl, os.environ.get("GLH_MOTION", "cartesian"), os.environ.get("GLH_DEM", "constant"))
     ctx.set_math(os.environ.get("GLH_MATH", "fast"))
     ctx.set_frame(0)
     ctx.init_particles(seed=3)
