@@ -715,6 +715,8 @@ def secondary_legs(args, device, T, rendered, seed):
                     legs[key]["motion"] = motion
                 if dem:
                     legs[key]["dem"] = "gridded"
+                if motion != "cartesian" or dem:  # (the committed PMC passes are of the CartesianMotion runs over constants)
+                    legs[key]["traffic_ratio"] = None
         except Exception as e:  # noqa: BLE001
             legs[key] = {"error": repr(e)}
     return legs
