@@ -311,10 +311,12 @@ __device__ __forceinline__ void evolve_cartesian_m(double* p, const double* m, c
 // GRID = false: the caller knows that this point's surfaces are constants (m[20] = m[21] = 0) -- no raster code is compiled
 // into that copy (the fused kernel's phase A keeps one loop for each: with the raster samples in the body, the loop of a
 // run over constant surfaces paid for their registers)
-template <bool FAST = false, bool GRID = true>
+// ZKNOWN (tangent models only): the caller has the evolved height (the fused kernel parks it in phase A for the gather's
+// re-evolution) -- the two surface samples, the square root and the third normal are not needed again.
+template <bool FAST = false, bool GRID = true, bool ZKNOWN = false>
 __device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
                                                 double tau2, const Surfaces& surf, bool* oob,
-                                                const RasterPatch* patches = nullptr) {
+                                                const RasterPatch* patches = nullptr, double z_known = 0.0) {
   const int kind = (int)m[18];
   if (kind == GLH_MOTION_CARTESIAN) {
     evolve_cartesian_m<FAST>(p, m, n, tau, tau2);
@@ -346,6 +348,14 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
   // tangent models: the height follows the surface plus a random walk of the offset
   const double dx = tau * p[3] + 0.5 * a[0] * tau2;
   const double dy = tau * p[4] + 0.5 * a[1] * tau2;
+  if constexpr (ZKNOWN) {
+    p[0] += dx;
+    p[1] += dy;
+    p[2] = z_known;
+    p[3] += tau * a[0];
+    p[4] += tau * a[1];
+    return;
+  }
   double z_off = p[2] - (GRID ? dem_at(m, surf, p[0], p[1], oob, patches) : m[16]);
   z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;

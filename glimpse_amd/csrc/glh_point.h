@@ -914,13 +914,27 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // the evolve step of particle k re-applied to its pre-evolve record x (phase E)
   // CartesianMotion with axyz_sigma[2] == 0 (uniform): the third normal only ever meets that zero
   const bool third = SURF || m[15] != 0.0;
-  auto evolve_loaded = [&](int k, double* x) {
+  // The tangent models (uniform per point): phase A parks every particle's evolved height in the second half of the point's
+  // observer-0 slot of the uv scratch (the first half is observer 0's v where PPT = 0; nothing else lives there), and
+  // the gather's re-evolution takes it from there instead of sampling the surface twice more, with a square root and a
+  // third normal, per survivor.
+  // (Instantiations with the raster samples only: over constant surfaces the re-evolution is cheap, and the extra copy of
+  // the evolve step cost the general code 2-3 % in spills.)
+  const bool tangent_pt = GRID && (int)m[18] >= GLH_MOTION_TANGENT_CARTESIAN;
+  double* ZP = a.uv + (size_t)pt * N * 2 + N;
+  auto evolve_loaded = [&](int k, double* x, double z_parked) {
     double n[3];
-    evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
-      evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
+      if (GRID && tangent_pt) {
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, false);
+        evolve_particle<FAST, GRID, true>(x, m, n, tau, tau2, a.surf, &oob, nullptr, z_parked);
+      } else {
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
+        evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
+      }
     } else {
+      evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
       evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
     }
   };
@@ -992,6 +1006,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
+        if (GRID && tangent_pt) ZP[i] = x[2];  // (for the gather's re-evolution: evolve_loaded)
         if (a.has_dem && motion_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
@@ -1816,12 +1831,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   for (int h0 = tid; h0 < U; h0 += GU * TB) {
     int lo[GU], cnt[GU];
     double2 v[GU][3];
+    double zp[GU];  // (tangent models: the evolved height phase A parked)
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
       lo[g] = (int)(sc_n[g] & 0xffffu);
       cnt[g] = (int)(sc_n[g] >> 16);
       const double2* src = Pin2 + (size_t)rec_n[g] * rec_stride;
       v[g][0] = src[0]; v[g][1] = src[chunk_stride]; v[g][2] = src[2 * chunk_stride];
+      zp[g] = GRID && tangent_pt ? ZP[lo[g]] : 0.0;
     }
     fetch_next(h0 + GU * TB);  // (beyond U: slot 0 of the tables, a valid address; never used)
     // the records are evolved, stored and summed ONE AFTER ANOTHER (compiler barrier): only the loads overlap, the
@@ -1830,7 +1847,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     for (int g = 0; g < GU; ++g) {
       if (g) asm volatile("" ::: "memory");
       double x[6] = {v[g][0].x, v[g][0].y, v[g][1].x, v[g][1].y, v[g][2].x, v[g][2].y};
-      evolve_loaded(lo[g], x);
+      evolve_loaded(lo[g], x, zp[g]);
       const double w = c[lo[g]];
       const int h = h0 + g * TB;
       if (h < U) {
