@@ -521,8 +521,15 @@ __device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, con
   const double *cq = ws.cdf_q, *cv = ws.cdf_v;
   if (cdf_lds) {  // (raw / low are dead)
     double* lv = cdf_lds + pt_align16(hist_n * 8) / 8;
-    pt_stage<TB>(cdf_lds, ws.cdf_q, hist_n);
-    pt_stage<TB>(lv, ws.cdf_v, hist_n);
+    // quantiles and values requested together: one memory latency (two staging calls in a row were two)
+    for (int base = 0; base < hist_n; base += 2 * TB) {
+      const int i0 = base + tid, i1 = i0 + TB;
+      const double q0 = ws.cdf_q[i0 < hist_n ? i0 : 0], q1 = ws.cdf_q[i1 < hist_n ? i1 : 0];
+      const double v0 = ws.cdf_v[i0 < hist_n ? i0 : 0], v1 = ws.cdf_v[i1 < hist_n ? i1 : 0];
+      asm volatile("" ::: "memory");  // (the loads stay above the stores)
+      if (i0 < hist_n) { cdf_lds[i0] = q0; lv[i0] = v0; }
+      if (i1 < hist_n) { cdf_lds[i1] = q1; lv[i1] = v1; }
+    }
     cq = cdf_lds;
     cv = lv;
   }
