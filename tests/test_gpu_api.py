@@ -300,6 +300,29 @@ def test_raster_sample_on_the_device(golden):
         assert (filled[~g[f"r{i}_mixed_in"]] == -7.0).all() and (filled[g[f"r{i}_mixed_in"]] != -7.0).all()
 
 
+def test_raster_coordinates_must_be_a_uniform_grid():
+    """The kernels find a sample's cell from the cell size (glh_math.h: raster_interval), which is scipy's find_indices only
+    for cell centres of a uniform grid -- what every glimpse Raster has.  The C ABI refuses anything else, loudly."""
+    from glimpse_amd import _lib
+
+    class Warped(glimpse_amd.Raster):
+        def device_args(self):
+            z, nx, ny, gx, gy, sx, sy, x0, x1, y0, y1 = super().device_args()
+            gx = gx.copy()
+            gx[3:] += 0.3 * abs(float(self.d[0]))  # (ascending still, but not uniform)
+            return z, nx, ny, gx, gy, sx, sy, x0, x1, y0, y1
+
+    z = np.arange(12.0 * 9).reshape(9, 12)
+    ok = glimpse_amd.Raster(z, x=(0.0, 24.0), y=(18.0, 0.0))
+    assert np.isfinite(ok.sample([[5.0, 5.0]])).all()
+    with pytest.raises(_lib.GlhError, match="uniform grid"):
+        Warped(z, x=(0.0, 24.0), y=(18.0, 0.0)).sample([[5.0, 5.0]])
+    with _lib.Context(2, 64, 1, max_frames=2) as ctx:
+        ctx.set_raster(_lib.RASTER_DEM, ok)
+        with pytest.raises(_lib.GlhError, match="uniform grid"):
+            ctx.set_raster(_lib.RASTER_DEM_SIGMA, Warped(z, x=(0.0, 24.0), y=(18.0, 0.0)))
+
+
 def test_gridded_surfaces_end_to_end(golden):
     """Tracker.track on a gridded dem / dem_sigma (CartesianMotion), a tangent model on a gridded dem, and a
     viewshed (tracker.py:114-117), incl. tracks the surfaces do not cover (ValueError captured, NaN rows),
