@@ -196,7 +196,13 @@ __device__ __forceinline__ uint32_t viewshed_bits(const Surfaces& surf, double x
 // CartesianMotion.compute_log_likelihoods (motion.py:181-204) for one (evolved) particle
 __device__ __forceinline__ double dem_log_likelihood(const double* m, const Surfaces& surf, double x, double y,
                                                      double z, bool* oob, const RasterPatch* patches = nullptr) {
-  const double zd = dem_at(m, surf, x, y, oob, patches), zs = dem_sigma_at(m, surf, x, y, oob, patches);
+  double zd, zs;
+  // (both surfaces rasters on one grid, the sample inside their windows: the cell and the weights once for both)
+  if (!(patches && m[20] != 0.0 && m[21] != 0.0 &&
+        raster_sample_pair(surf.dem, surf.dem_sigma, patches, patches + 1, x, y, zd, zs))) {
+    zd = dem_at(m, surf, x, y, oob, patches);
+    zs = dem_sigma_at(m, surf, x, y, oob, patches);
+  }
   if (zs != 0.0) {
     const double d = zd - z;
     return (1.0 / (2.0 * (zs * zs))) * (d * d);

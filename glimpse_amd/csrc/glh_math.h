@@ -444,6 +444,33 @@ GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, b
          raster_node(r, i0 + 1, i1) * y0 * (1.0 - y1) + raster_node(r, i0 + 1, i1 + 1) * y0 * y1;
 }
 
+// Two rasters on ONE grid (a DEM and its uncertainty usually are) sampled at one point through their windows: the cell and
+// the two weights are found once.  Returns false (nothing done) unless both samples can be served from the windows --
+// the caller then samples each raster on its own.  Same values, same arithmetic as raster_sample.
+GLH_HD bool raster_sample_pair(const RasterDev& r0, const RasterDev& r1, const RasterPatch* p0, const RasterPatch* p1, double x,
+                               double y, double& v0, double& v1) {
+  const bool same = r0.nx == r1.nx && r0.ny == r1.ny && r0.xmin == r1.xmin && r0.xmax == r1.xmax && r0.ymin == r1.ymin &&
+                    r0.ymax == r1.ymax && p0->i0 == p1->i0 && p0->j0 == p1->j0 && p0->w == p1->w && p0->h == p1->h;  // (uniform)
+  if (!same) return false;
+  if (!(x >= r0.xmin && x <= r0.xmax && y >= r0.ymin && y <= r0.ymax)) return false;
+  const int gi = raster_guess(r0.nx, x, r0.xmin, r0.kx), gj = raster_guess(r0.ny, y, r0.ymin, r0.ky);
+  const int li = gi - p0->i0, lj = gj - p0->j0;
+  const bool in_x = (li >= 1 || gi == 0) && li >= 0 && (li + 2 < p0->w || gi == r0.nx - 2) && li + 1 < p0->w;
+  const bool in_y = (lj >= 1 || gj == 0) && lj >= 0 && (lj + 2 < p0->h || gj == r0.ny - 2) && lj + 1 < p0->h;
+  if (!(in_x && in_y)) return false;
+  // (the coordinates of one grid are the same numbers in both windows: np.linspace of the same limits)
+  double xa, xb, ya, yb;
+  const int i0 = raster_interval(p0->gx - p0->i0, r0.nx, x, gi, xa, xb) - p0->i0;
+  const int i1 = raster_interval(p0->gy - p0->j0, r0.ny, y, gj, ya, yb) - p0->j0;
+  const double y0 = (x - xa) / (xb - xa);
+  const double y1 = (y - ya) / (yb - ya);
+  const double* z = p0->z + i1 * GLH_PATCH_W + i0;
+  v0 = z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) + z[GLH_PATCH_W + 1] * y0 * y1;
+  z = p1->z + i1 * GLH_PATCH_W + i0;
+  v1 = z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) + z[GLH_PATCH_W + 1] * y0 * y1;
+  return true;
+}
+
 // The surface height / its sigma under (x, y) for one point: the context's raster when the point's
 // flag says so (m[20] dem, m[21] dem_sigma), else the constant m[16] / m[17] (an infinite 1 x 1
 // raster in the reference, motion.py:136-141, raster.py:1021-1026).

@@ -221,6 +221,10 @@ int hc_raster_patch(const double* z, int nx, int ny, const double* gx, const dou
     values[2 * i + 1] = raster_sample(r, xy[2 * i], xy[2 * i + 1], 1, &o2, &p);
     const double vp = raster_sample(rp, xy[2 * i], xy[2 * i + 1], 1, &o3, &p);
     if (!o3 && vp == values[2 * i + 1]) ++hits;
+    // the pair form (one cell, one set of weights for two rasters on one grid): the same raster twice
+    double a = 0.0, b = 0.0;
+    if (raster_sample_pair(r, r, &p, &p, xy[2 * i], xy[2 * i + 1], a, b) && (a != values[2 * i] || b != values[2 * i]))
+      values[2 * i + 1] = -1e300;
   }
   return hits;
 }
