@@ -4,8 +4,9 @@
 # glimpse_amd/lib/NAME.so, --flag=value runs `new` with that extra bench argument.
 # prints: ms per step (wall), sum of the launch durations per step, GPU span per step (two streams: launches overlap)
 # usage: [AB_ENVS="GLH_PT_ONE_BLOCK=1 nt.so --frames-per-call=1"] tools/ab.sh [bench args]
+BASE=base; [ -f glimpse_amd/lib/base.so ] || BASE=""   # (no base.so: only `new` and the AB_ENVS variants run)
 for i in 1 2 3; do
-  for v in base new $AB_ENVS; do
+  for v in $BASE new $AB_ENVS; do
     (
       extra=""
       case $v in
