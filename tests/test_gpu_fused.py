@@ -465,6 +465,77 @@ def test_three_and_four_observers_on_the_fused_kernel(lib, O, math):
 
 
 @pytest.mark.parametrize("math", ["exact", "fast"])
+def test_tangent_models_over_rasters_with_three_observers(lib, math):
+    """The instantiations with the raster samples where observer 0's coordinates are parked in memory (three observers:
+    k_point_step<.., 0, 3, 2, ..>): the tangent models' evolved height, parked by phase A for the gather, shares the point's
+    observer-0 slot of the uv scratch with those coordinates; windows of both surfaces in LDS; a Cartesian point with the
+    DEM term and a point over constants in the same batch.  Bit for bit the staged kernels, host-fed and device draws."""
+    import glimpse_amd
+
+    cs = _multi_observer_case(3, P=4)
+    P, N, T = cs["P"], cs["N"], cs["T"]
+    rng = np.random.default_rng(31)
+    xy = cs["params"][:, 0:2]
+    lo, hi = xy.min(axis=0) - 60.0, xy.max(axis=0) + 60.0
+    nx, ny = 57, 49
+    dem = glimpse_amd.Raster(0.03 * rng.standard_normal((ny, nx)), x=(lo[0], hi[0]), y=(hi[1], lo[1]))
+    dem_sigma = glimpse_amd.Raster(0.2 + 0.1 * rng.random((ny, nx)), x=(lo[0], hi[0]), y=(hi[1], lo[1]))
+    params = np.zeros((P, lib.MOTION_FULL_LEN))
+    params[:, :18] = cs["params"]
+    params[:, 18] = [2, 3, 0, 2]  # tangent Cartesian, tangent cylindrical, Cartesian (DEM term over rasters), tangent Cartesian
+    params[:, 19] = 0.05
+    params[:, 20:22] = 1.0
+    params[-1, 20:22] = 0.0  # (the last point: constant surfaces, in a context that holds rasters)
+    params[-1, 17] = 0.3
+    for p in range(P):
+        if params[p, 18] == 3:
+            params[p, 4:7] = (0.15, 0.0, 0.0)
+            params[p, 7:10] = (0.05, 0.3, 0.0)
+            params[p, 13:16] = (0.02, 0.05, 0.0)
+    init = rng.standard_normal((P, N, 6))
+    ev = rng.standard_normal((T - 1, P, N, 3))
+    us = rng.random((T - 1, P))
+    for device_rng in (False, True):
+        res = []
+        for mode in (1, 0):
+            with lib.Context(P, N, 3, max_tile=31, max_search_dim=160, max_frames=T) as ctx:
+                for o in range(3):
+                    ctx.observer_init(o, T, cs["imgsz"][0], cs["imgsz"][1], 1, cs["sigmas"][o])
+                    ctx.observer_set_cameras(o, np.tile(cs["cams"][o], (T, 1)))
+                    for t in range(T):
+                        ctx.observer_upload_frame(o, t, cs["frames"][o][t])
+                ctx.begin_sequence(P, N, (21, 21))
+                ctx.set_raster(lib.RASTER_DEM, dem)
+                ctx.set_raster(lib.RASTER_DEM_SIGMA, dem_sigma)
+                ctx.set_motion(params)
+                ctx.set_math(math)
+                ctx.set_fused(mode)
+                ctx.set_debug(2)
+                ctx.set_frame(0)
+                ctx.init_particles(seed=5) if device_rng else ctx.init_particles(normals=init)
+                for o in range(3):
+                    ctx.init_templates(o, 0)
+                ctx.record_moments(0)
+                idx = []
+                for i in range(1, T):
+                    images = [i] * 3 if i != 2 else [-1, -1, -1]  # (frame 2: no image anywhere -- the weights stay)
+                    if device_rng:
+                        ctx.step(i, 1.0, images, seed=5)
+                    else:
+                        ctx.step(i, 1.0, images, normals=ev[i - 1], u=us[i - 1])
+                    idx.append(ctx.resample_indices())
+                    if mode:
+                        assert ctx.last_variant()[:3] == (512, 0, 3) and ctx.last_variant()[3] & 8
+                assert (ctx.point_status() == 0).all()
+                res.append(dict(p=ctx.get_particles(), w=ctx.get_weights(), m=ctx.get_moments(0, T), idx=np.stack(idx)))
+        np.testing.assert_array_equal(res[0]["idx"], res[1]["idx"])
+        np.testing.assert_array_equal(res[0]["p"], res[1]["p"])
+        np.testing.assert_array_equal(res[0]["w"], res[1]["w"])
+        np.testing.assert_allclose(res[0]["m"], res[1]["m"], rtol=1e-12, atol=1e-13)
+        assert (res[0]["p"][[0, 1, 3], :, 5] == 0.0).all()  # (the tangent models leave vz = 0)
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
 @pytest.mark.parametrize("variant", [dict(highpass=(3, 3)), dict(highpass=(7, 5)), dict(highpass=(1, 3)),
                                      dict(interpolation=(1, 1)), dict(highpass=(3, 3), interpolation=(1, 1)),
                                      dict(highpass=(5, 5), hp_mode="nearest"), dict(highpass=(3, 7), hp_mode="wrap"),
