@@ -1820,7 +1820,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #ifndef GLH_PT_GU
 #define GLH_PT_GU 2
 #endif
-  constexpr int GU = GLH_PT_GU;  // records in flight per thread
+  // records in flight per thread.  The general code keeps ONE: with two, its 128 registers spill two record chunks inside this
+  // loop (40 B of scratch); one record in flight, none -- TangentCartesianMotion -3.4 %, uint16 frames -3.3 %, over rasters
+  // +-0 (profiles/ab_r04/r4j59_ab_gu1.txt).  The plain code has the registers for two (round 3: -1 % against one).
+  constexpr int GU = SURF ? 1 : GLH_PT_GU;
   // The record index of a survivor, uin[source], is a memory load the record loads depend on: the words of the NEXT
   // iteration (source | copies from the rank table, record index from memory) are fetched while this iteration's
   // records are evolved (C4, whose 16-wave workgroup has its CU to itself: -0.8 %; C3 / C5: -0.2 .. -0.4 %).
