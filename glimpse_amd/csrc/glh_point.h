@@ -937,8 +937,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, false);
         evolve_particle<FAST, GRID, true>(x, m, n, tau, tau2, a.surf, &oob, nullptr, z_parked);
       } else {
+        // (with rasters the tangent models took the branch above, and the other models' step reads no surface: the copy
+        // without raster code serves -- the gather of the raster instantiations carries no sampler at all)
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
-        evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
+        evolve_particle<FAST, false>(x, m, n, tau, tau2, a.surf, &oob);
       }
     } else {
       evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, third);
