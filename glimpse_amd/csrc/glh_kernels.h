@@ -1204,11 +1204,26 @@ __device__ __forceinline__ void normalize_box_f32_block(const uint8_t* frame, in
   const UDiv by_w = udiv_make(w);
   for (int base = 0; base < n; base += 4 * NT) {  // (four pixel loads in flight per thread)
     float v[4];
+    // (the channel count is decided outside the four fetches: behind a per-pixel branch every load was waited for in its
+    // own block; the arithmetic is pixel_float's)
+    const float* px[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = min(base + q * NT + tid, n - 1);
       const int r = udiv(by_w, idx), c = idx - r * w;
-      v[q] = (float)pixel_float(frame, width, channels, 32, box[1] + r, box[0] + c);
+      px[q] = reinterpret_cast<const float*>(frame) + ((size_t)(box[1] + r) * width + (box[0] + c)) * channels;
+    }
+    if (channels == 1) {  // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = px[q][0];
+    } else {
+      float ch[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ch[q][0] = px[q][0]; ch[q][1] = px[q][1]; ch[q][2] = px[q][2];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = ((ch[q][0] + ch[q][1]) + ch[q][2]) / 3.0f;
     }
     asm volatile("" ::: "memory");  // (the loads stay above the stores)
 #pragma unroll

@@ -342,15 +342,45 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
   const UDiv by_w = udiv_make(w);
   for (int base = 0; base < n; base += 4 * TB) {
     int key[4], at[4];
+    // (a thread past the end fetches pixel 0 again, and the channel count is decided OUTSIDE the four fetches:
+    // unconditional loads issued back to back -- behind a guard or a per-pixel channel branch each load sat in its own
+    // block and was waited for there, four memory latencies in a row)
+    size_t px[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      const int r = udiv(by_w, idx), c = idx - r * w;
+      const int idx = base + q * TB + tid, idc = idx < n ? idx : 0;
+      const int r = udiv(by_w, idc), c = idc - r * w;
       at[q] = r * wp + c;
-      key[q] = idx < n ? pixel_key(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
+      px[q] = (size_t)(box[1] + r) * ob.width + (box[0] + c);
     }
+    if (ob.channels == 1) {  // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) key[q] = ob.frame[px[q]];
+    } else if (ob.channels == 3) {
+      // the three bytes of an RGB pixel as ONE unaligned 4-byte load and a byte sum (v_sad_u8); the frame's last pixel
+      // reads the frame's last four bytes and takes the upper three
+      const size_t lim = (size_t)ob.width * ob.height * 3 - 4;
+      uint32_t wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t a3 = px[q] * 3;
+        __builtin_memcpy(&wq[q], ob.frame + (a3 > lim ? lim : a3), 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        key[q] = (int)__builtin_amdgcn_sad_u8(px[q] * 3 > lim ? wq[q] >> 8 : wq[q] & 0x00ffffffu, 0u, 0u);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int sum = 0;
+        for (int ch = 0; ch < ob.channels; ++ch) sum += ob.frame[px[q] * ob.channels + ch];
+        key[q] = sum;
+      }
+    }
+    asm volatile("" ::: "memory");  // (the loads stay above the stores and atomics)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (base + q * TB + tid >= n) key[q] = -1;
       if (key[q] >= 0) {
         keys[at[q]] = (uint16_t)key[q];
         atomicAdd(&ws.hist[key[q]], 1u);
@@ -614,14 +644,38 @@ __device__ __forceinline__ void pt_tile_prep_wide(const ObsFrame& ob, const int*
   uint32_t kmin = 0xffffffffu, kmax = 0u;
   for (int base = 0; base < n; base += 4 * TB) {  // (four pixel loads in flight per thread)
     int key[4];
+    // (unconditional loads -- a thread past the end fetches pixel 0 again -- with the channel count decided outside the
+    // four fetches: behind a guard or a per-pixel channel branch every load was waited for in its own block)
+    const uint16_t* px[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int idx = base + q * TB + tid;
-      const int r = udiv(by_w, idx), c = idx - r * w;
-      key[q] = idx < n ? pixel_key16(ob.frame, ob.width, ob.channels, box[1] + r, box[0] + c) : -1;
+      const int idx = base + q * TB + tid, idc = idx < n ? idx : 0;
+      const int r = udiv(by_w, idc), c = idc - r * w;
+      px[q] = reinterpret_cast<const uint16_t*>(ob.frame) + ((size_t)(box[1] + r) * ob.width + (box[0] + c)) * ob.channels;
     }
+    if (ob.channels == 1) {  // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) key[q] = px[q][0];
+    } else if (ob.channels == 3) {
+      int ch[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ch[q][0] = px[q][0]; ch[q][1] = px[q][1]; ch[q][2] = px[q][2];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) key[q] = ch[q][0] + ch[q][1] + ch[q][2];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int sum = 0;
+        for (int k = 0; k < ob.channels; ++k) sum += px[q][k];
+        key[q] = sum;
+      }
+    }
+    asm volatile("" ::: "memory");  // (the loads stay above the stores)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (base + q * TB + tid >= n) key[q] = -1;
       if (key[q] >= 0) {
         raw[base + q * TB + tid] = (uint32_t)key[q];
         kmin = min(kmin, (uint32_t)key[q]);

@@ -793,3 +793,54 @@ def test_templates_up_to_63_pixels_on_the_fused_kernel(lib, math):
         np.testing.assert_array_equal(res[0][0], res[1][0])
         np.testing.assert_array_equal(res[0][1], res[1][1])
         np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_search_tile_that_touches_the_last_pixel_of_the_frame(lib, channels):
+    """A tracked point in the bottom-right corner: its search box ends at (width, height), so the tile fetch reads the frame's
+    very last pixel -- which the RGB fetch (one unaligned 4-byte load per pixel) takes from the frame's last four bytes.
+    Bit for bit the staged kernels."""
+    from scipy.optimize import fsolve
+
+    from glimpse_amd import synth, workloads
+
+    T, P, N = 4, 2, 800
+    W = H = 192
+    wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(W, H))
+    wl.channels = channels
+    cam = wl.cams[0]
+    half = wl.tile[0] / 2 + 1.5  # (the box is the cloud widened by half a template and, being narrower than the template + 3, by 1.5)
+    target = np.array([W - half - 0.35, H - half - 0.35])  # box: ceil(max u + half) = W for a cloud a few hundredths of a pixel wide
+    xy = fsolve(lambda q: synth.project(cam, np.array([[q[0], q[1], 0.0]]))[0] - target, x0=(1.0, 1.0), xtol=1e-12)
+    rng = np.random.default_rng(2)
+    shape = (H, W) if channels == 1 else (H, W, 3)
+    still = rng.integers(0, 256, shape, dtype=np.uint8)  # (a static texture: the point does not move)
+    still[-1, -1] = 255                                   # (... whose last pixel is not like its neighbours)
+    frames = [[still.copy() for _ in range(T)]]
+    params = workloads.motion_params(np.array([xy, xy + (-6.0, 6.0)]))
+    params[:, 2:4] = 1e-4
+    params[:, 4:7] = 0.0
+    params[:, 7:10] = (1e-4, 1e-4, 0.0)
+    params[:, 13:16] = (1e-5, 1e-5, 0.0)
+    out = []
+    for mode in (1, 0):
+        with lib.Context(P, N, 1, max_search_dim=96, max_frames=T) as ctx:
+            workloads.setup_context(ctx, wl, frames)
+            ctx.set_motion_cartesian(params)
+            ctx.set_fused(mode)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=3)
+            ctx.init_templates(0, 0)
+            ctx.record_moments(0)
+            boxes = []
+            for i in range(1, T):
+                ctx.step(i, 1.0, [i], seed=3)
+                boxes.append(ctx.search_boxes().copy())
+            assert (ctx.observer_status() == lib.OBS_OK).all() and (ctx.point_status() == 0).all()
+            out.append(dict(p=ctx.get_particles(), w=ctx.get_weights(), m=ctx.get_moments(0, T), boxes=np.stack(boxes)))
+    fused, staged = out
+    assert (fused["boxes"][:, 0, 0, 2:] == (W, H)).all(), fused["boxes"][:, 0, 0]  # (point 0's box ends at the frame's corner)
+    np.testing.assert_array_equal(fused["boxes"], staged["boxes"])
+    np.testing.assert_array_equal(fused["p"], staged["p"])
+    np.testing.assert_array_equal(fused["w"], staged["w"])
+    np.testing.assert_allclose(fused["m"], staged["m"], rtol=1e-12, atol=1e-13)
