@@ -1879,7 +1879,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // records in flight per thread.  The general code keeps ONE: with two, its 128 registers spill two record chunks inside this
   // loop (40 B of scratch); one record in flight, none -- TangentCartesianMotion -3.4 %, uint16 frames -3.3 %, over rasters
   // +-0 (profiles/ab_r04/r4j59_ab_gu1.txt).  The plain code has the registers for two (round 3: -1 % against one).
-  constexpr int GU = SURF ? 1 : GLH_PT_GU;
+  // The 1 024-thread plain code (C4: one workgroup per CU, nothing else hides its latencies) takes three: -1.5 %, no scratch
+  // (r4j71_ab_gu_plain.txt; C3 / C5 at 512 threads: one, two and three within noise).
+  constexpr int GU = SURF ? 1 : (TB >= 1024 ? GLH_PT_GU + 1 : GLH_PT_GU);
   // The record index of a survivor, uin[source], is a memory load the record loads depend on: the words of the NEXT
   // iteration (source | copies from the rank table, record index from memory) are fetched while this iteration's
   // records are evolved (C4, whose 16-wave workgroup has its CU to itself: -0.8 %; C3 / C5: -0.2 .. -0.4 %).
