@@ -1109,14 +1109,16 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       }
     };
-    if constexpr (PPT > 0 && NOBS <= 2 && !SURF) {
+    if constexpr (PPT > 0 && NOBS <= 2 && !GRID) {
       // unrolled over the per-thread particles (u0[r] = u with a static index instead of a compare-select chain
-      // over the array); only where one observer keeps the body small
+      // over the array); only where one observer keeps the body small.  The general code without the raster samples too
+      // (round 4: TangentCartesianMotion, uint16 and float frames -2 %, no scratch left in any of its one-observer
+      // instantiations); with the samples the body is ten times the size
 #pragma unroll
       for (int r = 0; r < NREG; ++r)
         if (r < rounds) a_iter(r);
     } else {
-#pragma unroll 1
+#pragma unroll 2
       for (int r = 0; r < rounds; ++r) a_iter(r);
     }
     PT_STAMP(17);
