@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       for (int r = 0; r < NREG; ++r)
         if (r < rounds) a_iter(r);
     } else {
-#pragma unroll 2
+#pragma unroll 1
       for (int r = 0; r < rounds; ++r) a_iter(r);
     }
     PT_STAMP(17);
