@@ -1109,11 +1109,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
       }
     };
-    if constexpr (PPT > 0 && NOBS <= 2 && !GRID) {
+    if constexpr (PPT > 0 && NOBS <= 2) {
       // unrolled over the per-thread particles (u0[r] = u with a static index instead of a compare-select chain
-      // over the array); only where one observer keeps the body small.  The general code without the raster samples too
-      // (round 4: TangentCartesianMotion, uint16 and float frames -2 %, no scratch left in any of its one-observer
-      // instantiations); with the samples the body is ten times the size
+      // over the array).  Every instantiation that keeps observer 0's coordinates in registers, the general ones included
+      // (round 4: TangentCartesianMotion, uint16 and float frames -2 %; over rasters -2 % with one observer, -6 .. -9 % with
+      // two, although the unrolled loop is 120 .. 150 KB of code there)
 #pragma unroll
       for (int r = 0; r < NREG; ++r)
         if (r < rounds) a_iter(r);
