@@ -16,7 +16,9 @@ of one frame update; with `--steps K` it is K steps of F = round(99 / K) consecu
 `--steps 20`: 20 steps x 5 updates over a 101-frame sequence) -- a step is one pass of the hot path over one batch of
 input, here F frames for all points.  The W warm-up steps run the first W steps of the same sequence, untimed; the
 state is then re-initialised (untimed) and the K timed steps start from the prior.  `--burn-in B` (> 0) instead times
-K single-frame steps after B untimed updates (the steady-state window used for A/B runs).
+K single-frame steps after B untimed updates (the steady-state window used for A/B runs).  The timed region is repeated
+`--repeats` R = 5 times inside the invocation (re-initialised, untimed, in between): `value`, `ms_per_step` and the
+roofline figures are those of the MEDIAN repetition, `spread` holds the minimum / maximum / every repetition.
 
 N > 1: one process per GPU, each tracking its own block of points (weak scaling; `--split strong` divides the
 workload's points instead), no data-path collective, ONE RCCL gather of the posterior moments at the end of
@@ -101,6 +103,10 @@ def parse_args(argv=None):
                     help="frame samples: uint8 (BASELINE's configurations) or uint16 (the same scene on a 16-bit sensor)")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
                     help="frame channels: 1 (gray, BASELINE's configurations) or 3 (RGB uint8: what time-lapse JPEGs decode to)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (the K steps) is run this many times inside the one invocation, the state "
+                         "re-initialised (untimed) in between; `value` / `ms_per_step` are the MEDIAN repetition's, "
+                         "`spread` lists min / max / n (boxes of the pool differ by 3-5 %%, one 44-ms sample says little)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs of the default run (exact arithmetic at C3, the C4 shard, C5, C2)")
     ap.add_argument("--dump-moments", default=None, help="rank 0 saves the (gathered) posterior history (T, P, 12) here (.npy)")
@@ -601,7 +607,7 @@ def apply_motion(ctx, wl, motion, dem="constant"):
 # ------------------------------------------------------------------------------------------------
 # secondary legs of the default run: the other configurations and the parity-grade arithmetic, short
 # ------------------------------------------------------------------------------------------------
-def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
+def measure_sequence(ctx, wl, n_frames, seed, math, warm=3, repeats=3):
     """The whole sequence of `wl` from the prior (frame 0 initialises, frames 1 .. n_frames-1 are timed) on a context that
     already holds its frames: one glh_track call, HIP events around every launch.  Returns the figures of a secondary
     leg: ms per frame update (wall and kernel), roofline fraction by SURVEY 8(d)'s algorithmic bytes, PMC traffic ratio
@@ -625,18 +631,21 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
     initialise()
     run(1, min(warm, n_frames - 1))
     ctx.sync()
-    initialise()
-    ctx.sync()
     ctx.profile_enable(True)
-    ctx.profile_reset()
-    t0 = time.perf_counter()
-    run(1, n_frames - 1)
-    ctx.sync()
-    wall = time.perf_counter() - t0
-    stage_ms = ctx.profile_get()
-    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
-    launch_ms = ctx.profile_launches(dom)
-    span_ms = ctx.profile_span(dom)
+    passes = []
+    for _ in range(max(1, repeats)):  # (the median repetition is reported, like the headline)
+        initialise()
+        ctx.sync()
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        run(1, n_frames - 1)
+        ctx.sync()
+        wall = time.perf_counter() - t0
+        stage_ms = ctx.profile_get()
+        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+        passes.append((wall, stage_ms, dom, ctx.profile_launches(dom), ctx.profile_span(dom)))
+    walls = sorted(p[0] for p in passes)
+    wall, stage_ms, dom, launch_ms, span_ms = sorted(passes, key=lambda p: p[0])[(len(passes) - 1) // 2]
     streams = ctx.last_track_streams()
     ctx.profile_enable(False)
     status = ctx.observer_status()
@@ -652,8 +661,11 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3):
         "workload": wl.describe()["workload"], "math": math, "frames": n_frames, "kernel": kern,
         "variant": list(ctx.last_variant()),
         "ms_per_frame": 1e3 * wall / (n_frames - 1),
+        "ms_per_frame_min_max": [round(1e3 * walls[0] / (n_frames - 1), 5), round(1e3 * walls[-1] / (n_frames - 1), 5)],
+        "repeats": len(walls),
         "kernel_ms_per_launch": per_launch, "track_streams": streams, "gpu_ms_per_frame": gpu_per_frame,
         "value": wl.P * wl.N * (n_frames - 1) / wall,
+        "frames_per_s": (n_frames - 1) / wall,
         "roofline_frac": abytes / (gpu_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": abytes,
         "traffic_ratio": None if traffic is None else traffic / abytes,
@@ -681,6 +693,9 @@ def secondary_legs(args, device, T, rendered, seed):
             # of rounds 1-3, where a launch has the chip to itself
             ("C3_one_stream", "C3", None, "fast", T, "C3", 1, 8, "cartesian"),
             ("C4_shard", "C4", None, "fast", T, "C3", 1, 8, "cartesian"),
+            # BASELINE config 4 WHOLE on this one GPU (10 000 points x 10 000 particles, 2 x 4.8 GB of state): the N = 1
+            # anchor of the strong-scaling curve; north_star asks for 50 frames/s of this on eight GPUs
+            ("C4_full_1gpu", "C4", workloads.CONFIGS["C4"]["points"], "fast", T, "C3", 1, 8, "cartesian"),
             ("C5", "C5", workloads.CONFIGS["C5"]["points"], "fast", T, "C5", 1, 8, "cartesian"),
             # what each of C5's four GPUs runs: 512 of the 2 048 points
             ("C5_shard", "C5", None, "fast", T, "C5", 1, 8, "cartesian"),
@@ -710,7 +725,7 @@ def secondary_legs(args, device, T, rendered, seed):
                 motion, _, dem = motion.partition("+")
                 apply_motion(ctx, wl, motion, "gridded" if dem else "constant")
                 ctx.set_track_streams(1 if key == "C3_one_stream" else args.streams)
-                legs[key] = measure_sequence(ctx, wl, n_frames, seed, math)
+                legs[key] = measure_sequence(ctx, wl, n_frames, seed, math, repeats=min(3, max(1, args.repeats)))
                 if motion != "cartesian":
                     legs[key]["motion"] = motion
                 if dem:
@@ -843,27 +858,37 @@ def worker(args):
     if world > 1:
         gather()  # warm the communicator up outside the timed region
     ctx.sync()
-    initialise()  # back to the prior (untimed)
-    run(1, B)  # burn-in, untimed
-    ctx.sync()
 
-    # HIP events around every kernel launch on the context's stream, over the timed region itself
+    # The timed region -- the K steps -- R times (round 5): every repetition starts from the prior again (untimed
+    # re-initialisation + burn-in), is bracketed by barriers and carries its own HIP events around every kernel launch;
+    # the line reports the MEDIAN repetition (its wall time, its launch durations, its GPU span) and the spread of all.
+    R = max(1, args.repeats)
+    passes = []
     ctx.profile_enable(True)
-    ctx.profile_reset()
-    group.barrier()
-    t0 = time.perf_counter()
-    run(1 + B, K * F)
-    gathered = None
-    if world > 1:
+    for _ in range(R):
+        initialise()  # back to the prior (untimed)
+        run(1, B)  # burn-in, untimed
         ctx.sync()
-        gathered = gather()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = group.max(elapsed)
-    stage_ms = ctx.profile_get()
-    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
-    launch_ms = ctx.profile_launches(dom)
-    span_ms = ctx.profile_span(dom)
+        ctx.profile_reset()
+        group.barrier()
+        t0 = time.perf_counter()
+        run(1 + B, K * F)
+        gathered = None
+        if world > 1:
+            ctx.sync()
+            gathered = gather()
+        group.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed = group.max(elapsed)
+        stage_ms = ctx.profile_get()
+        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+        passes.append(dict(elapsed=elapsed, stage_ms=stage_ms, dom=dom, launch_ms=ctx.profile_launches(dom),
+                           span_ms=ctx.profile_span(dom), gathered=gathered))
+    order = sorted(range(R), key=lambda i: passes[i]["elapsed"])
+    mid = passes[order[(R - 1) // 2]]  # the median repetition (the lower middle one of an even count)
+    elapsed, stage_ms, dom, launch_ms, span_ms = (mid[k] for k in ("elapsed", "stage_ms", "dom", "launch_ms", "span_ms"))
+    gathered = passes[-1]["gathered"]  # (checked against the state the last repetition left; every repetition draws the same)
+    all_elapsed = [p["elapsed"] for p in passes]
     streams = ctx.last_track_streams() if C > 1 else 1
     ctx.profile_enable(False)
     _mark("headline timed")
@@ -903,6 +928,11 @@ def worker(args):
             "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
             "ms_per_frame": 1e3 * elapsed / (K * F),
+            "spread": {"n": R, "statistic": "median of n repetitions of the timed region in this invocation",
+                       "ms_per_step_min": 1e3 * min(all_elapsed) / K, "ms_per_step_max": 1e3 * max(all_elapsed) / K,
+                       "value_min": total_points * wl.N * K * F / max(all_elapsed),
+                       "value_max": total_points * wl.N * K * F / min(all_elapsed),
+                       "ms_per_step_all": [round(1e3 * e / K, 5) for e in all_elapsed]},
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,

@@ -182,6 +182,9 @@ struct glh_ctx {
   hipStream_t extra_streams[3] = {nullptr, nullptr, nullptr};  // streams 2 .. 4 of glh_track
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int last_track_streams = 1;  // streams the last glh_track used
+  bool capturing = false;      // glh_track is recording its frame loop into a hipGraph (no event timers meanwhile)
+  hipGraphExec_t track_graph = nullptr;  // the last captured frame loop (kept until the next one or the context's end)
+  int force_tb = 0;            // experiment (GLH_PT_BIG_FRAMES): this launch runs the 1 024-thread instantiation
   double *sse = nullptr, *sse_copy = nullptr, *ll_dbg = nullptr;
   double* lu = nullptr;
   double* poly = nullptr;
@@ -243,7 +246,7 @@ struct StageTimer {
   hipStream_t s;
   StageTimer(glh_ctx* ctx, int st, hipStream_t on = nullptr) : c(ctx), stage(st), s(on ? on : ctx->stream) {
     c->launches[st]++;
-    if (!c->profiling) return;
+    if (!c->profiling || c->capturing) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!c->pool.empty()) {
@@ -315,6 +318,7 @@ extern "C" int glh_destroy(glh_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)glh_comm_destroy(c);
+  if (c->track_graph) (void)hipGraphExecDestroy(c->track_graph);
   for (auto& e : c->pending) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -1556,7 +1560,7 @@ static int fused_step(glh_ctx* c, int frame, double tau, const int32_t* images, 
     // (PPT per thread) and its v in c[] up to 10240 particles, both parked in LDS / the uv scratch beyond that and with
     // three or four observers.  Two observers keep observer 0 in registers as well (round 4: the first observer's pass is
     // peeled off the observer loop, so the registers are dead during the second observer's tile pipeline).
-    const bool big = c->N > 10 * PT_BLK;
+    const bool big = c->N > 10 * PT_BLK || c->force_tb == PT_BLK_BIG;
     const int tb = big ? PT_BLK_BIG : PT_BLK;
     const dim3 block(tb);
     int ppt = c->N <= 4 * tb ? 4 : (c->N <= 10 * tb ? 10 : 0);
@@ -1694,12 +1698,65 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
     ns = std::min(ns, c->P);
   }
   c->last_track_streams = ns;
-  if (ns == 1) {
-    for (int k = 0; k < n_frames; ++k) {
-      CHK(glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed));
-      if (c->track_covariances) CHK(glh_record_covariances(c, frames[k]));
+  // experiment (GLH_PT_BIG_FRAMES=n): the first n frames of the call run the 1 024-thread instantiation with the whole
+  // CU's LDS (the wide search tiles after the prior fit without the HBM workspaces)
+  int big_frames = 0, r2_big = r2_bytes;
+  if (const char* e = getenv("GLH_PT_BIG_FRAMES")) {
+    if (fused_ok && c->N <= 10 * PT_BLK && O <= 2) {
+      big_frames = atoi(e);
+      const int cN = pt_align16(c->N * 8) + pt_align16(4 * pt_plan_ints(c->nleaves, c->nnodes, c->nlevels, c->nroots));
+      const int patch = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z ? PT_PATCH_LDS : 0;
+      r2_big = std::max(r2_bytes, std::min(PT_LDS_MAX - patch - cN, 100 * 1024));
     }
-    return GLH_OK;
+  }
+  if (ns == 1) {
+    // experiment (GLH_TRACK_GRAPH=1): the frame loop of a one-stream run as ONE hipGraph launch -- small batches (C2,
+    // a GPU's share of C5) spend 15 % of a frame between two launches
+    const bool graph = fused_ok && !c->track_covariances && getenv("GLH_TRACK_GRAPH") && n_frames > 1;
+    if (graph) {
+      HIPCHK(hipSetDevice(c->cfg.device_id));
+      for (int b = 0; b < 2; ++b)  // (nothing may be allocated while the stream is being captured)
+        if (!c->uidx[b]) CHK(dalloc(&c->uidx[b], (size_t)c->cfg.max_points * c->cfg.max_particles));
+      for (int o = 0; o < O; ++o)
+        if (c->obs[o].bits >= 32) CHK(prepare_bins16(c, o, true));
+      CHK(drain_profile(c));
+      if (c->track_graph) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipGraphExecDestroy(c->track_graph);
+        c->track_graph = nullptr;
+      }
+      HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+      c->capturing = true;
+    }
+    int rc = GLH_OK;
+    for (int k = 0; k < n_frames && rc == GLH_OK; ++k) {
+      c->force_tb = k < big_frames ? PT_BLK_BIG : 0;
+      if (fused_ok && (graph || big_frames > 0)) {
+        rc = glh_set_frame(c, frames[k]);
+        if (rc == GLH_OK)
+          rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed,
+                          k < big_frames ? r2_big : r2_bytes);
+      } else {
+        rc = glh_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, nullptr, seed);
+      }
+      if (rc == GLH_OK && c->track_covariances) rc = glh_record_covariances(c, frames[k]);
+    }
+    c->force_tb = 0;
+    if (graph) {
+      c->capturing = false;
+      hipGraph_t g = nullptr;
+      const hipError_t e1 = hipStreamEndCapture(c->stream, &g);
+      if (rc != GLH_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      HIPCHK(e1);
+      hipError_t e2 = hipGraphInstantiate(&c->track_graph, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIPCHK(e2);
+      HIPCHK(hipGraphLaunch(c->track_graph, c->stream));
+    }
+    return rc;
   }
   HIPCHK(hipSetDevice(c->cfg.device_id));
   if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1719,10 +1776,12 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
     rc = glh_set_frame(c, frames[k]);
     for (int q = 0; q < ns && rc == GLH_OK; ++q) {
       const int p0 = (int)((int64_t)c->P * q / ns), p1 = (int)((int64_t)c->P * (q + 1) / ns);
-      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed, r2_bytes, p0, p1 - p0,
-                      on[q], q == ns - 1);
+      c->force_tb = k < big_frames ? PT_BLK_BIG : 0;
+      rc = fused_step(c, frames[k], taus[k], images + (size_t)k * O, GLH_RNG_PHILOX, nullptr, seed,
+                      k < big_frames ? r2_big : r2_bytes, p0, p1 - p0, on[q], q == ns - 1);
     }
   }
+  c->force_tb = 0;
   for (int q = 1; q < ns; ++q) {
     (void)hipEventRecord(c->ev_join[q - 1], on[q]);
     (void)hipStreamWaitEvent(c->stream, c->ev_join[q - 1], 0);

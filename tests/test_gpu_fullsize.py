@@ -90,3 +90,65 @@ def test_full_size_properties(name, shape, math):
     hi = run(lib, wl, frames, half, wl.P, 1)
     np.testing.assert_array_equal(np.concatenate((lo["moments"], hi["moments"]), axis=1), big["moments"])
     np.testing.assert_array_equal(np.concatenate((lo["particles"], hi["particles"])), big["particles"])
+
+
+def test_full_c4_on_one_gpu():
+    """BASELINE config 4 WHOLE on one GPU -- 10 000 points x 10 000 particles (2 x 4.8 GB of state, 10^8 particles per
+    frame): the N = 1 anchor of the strong-scaling curve, and every size limit at the shape north_star names (points per
+    context, size_t indexing of the state, the history, the record-index tables).  Properties only, and host downloads
+    kept small: the resample indices (0.4 GB), the posterior history, a few points' particles."""
+    from glimpse_amd import _lib as lib
+    from glimpse_amd import workloads
+
+    T3 = 3
+    wl = workloads.Workload("C4", n_frames=T3, n_points=10000)
+    assert (wl.P, wl.N) == (10000, 10000) and wl.tile == (31, 31)
+    frames = [wl.frames(0)]
+    picks = (0, 1, 4999, 5000, 9998, 9999)
+
+    def run(p0, p1, mode, want_idx=False, points=()):
+        sub = wl.slice(p0, p1)
+        with lib.Context(sub.P, wl.N, 1, max_tile=31, max_search_dim=160, max_frames=T3) as ctx:
+            workloads.setup_context(ctx, sub, frames)
+            ctx.set_point_offset(p0)
+            ctx.set_fused(mode)
+            ctx.set_math("fast")
+            if want_idx:
+                ctx.set_debug(2)
+            ctx.set_frame(0)
+            ctx.init_particles(seed=SEED)
+            ctx.init_templates(0, 0)
+            ctx.record_moments(0)
+            if mode == 1 and not want_idx:
+                ctx.track([1, 2], [1.0, 1.0], [[1], [2]], seed=SEED)  # (the frame loop in one call: two streams)
+            else:
+                for i in range(1, T3):
+                    ctx.step(i, 1.0, [i], seed=SEED)
+            return dict(moments=ctx.get_moments(0, T3), status=ctx.point_status(), obs=ctx.observer_status(),
+                        idx=ctx.resample_indices() if want_idx else None,
+                        state={p: ctx.get_point_state(p - p0) for p in points})
+
+    big = run(0, wl.P, 1, want_idx=True, points=picks + tuple(range(2500, 2548)))
+    assert (big["status"] == 0).all() and (big["obs"] == lib.OBS_OK).all()
+    assert np.isfinite(big["moments"]).all()
+    idx = big["idx"]
+    assert idx.shape == (10000, 10000) and idx.min() >= 0 and idx.max() < wl.N
+    assert (np.diff(idx, axis=1) >= 0).all()
+    assert abs(np.median(big["moments"][-1, :, 3]) - 0.15) < 0.03
+    # 48 points on the staged kernels, same global RNG keys: bit for bit the rows of the big run
+    p0, p1 = 2500, 2548
+    small = run(p0, p1, 0, want_idx=True, points=tuple(range(p0, p1)))
+    np.testing.assert_array_equal(small["idx"], idx[p0:p1])
+    for p in range(p0, p1):
+        np.testing.assert_array_equal(small["state"][p][0], big["state"][p][0])
+        np.testing.assert_array_equal(small["state"][p][1], big["state"][p][1])
+    np.testing.assert_allclose(small["moments"], big["moments"][:, p0:p1], rtol=1e-11, atol=1e-12)
+    del idx, small
+    # two shards of 5 000 points, each through glh_track (two streams each): the unsharded history and the picked states
+    lo = run(0, 5000, 1, points=picks[:3])
+    hi = run(5000, 10000, 1, points=picks[3:])
+    np.testing.assert_array_equal(np.concatenate((lo["moments"], hi["moments"]), axis=1), big["moments"])
+    for p in picks:
+        part = lo if p < 5000 else hi
+        np.testing.assert_array_equal(part["state"][p][0], big["state"][p][0])
+        np.testing.assert_array_equal(part["state"][p][1], big["state"][p][1])
