@@ -535,14 +535,12 @@ def cpu_baseline_parallel(wl, frames, n_frames, per_point_seconds, target_second
     }
 
 
-def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
-    """The same sequence through the drop-in Python API, glimpse_amd.Tracker.track(rng="philox"): wall time of the
-    whole call (frame upload, the frame loop, per-frame status reads, result download) per frame update."""
+def _api_objects(wl, frames, n_frames):
+    """Observers and motion models of `wl` as the drop-in API takes them."""
     import datetime
 
     import glimpse_amd as g
 
-    t00 = time.perf_counter()
     t_start = datetime.datetime(2020, 1, 1)
     unit = datetime.timedelta(days=1)
     observers = []
@@ -558,6 +556,16 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
         q = wl.params[p]
         models.append(g.CartesianMotion(xy=q[0:2], time_unit=unit, dem=q[16], dem_sigma=q[17], n=wl.N, xy_sigma=q[2:4],
                                         vxyz=q[4:7], vxyz_sigma=q[7:10], axyz=q[10:13], axyz_sigma=q[13:16]))
+    return observers, models
+
+
+def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
+    """The same sequence through the drop-in Python API, glimpse_amd.Tracker.track(rng="philox"): wall time of the
+    whole call (frame upload, the frame loop, per-frame status reads, result download) per frame update."""
+    import glimpse_amd as g
+
+    t00 = time.perf_counter()
+    observers, models = _api_objects(wl, frames, n_frames)
     tracker = g.Tracker(observers, device=device)  # (workspaces sized from the prior: the API's default)
     t_setup = time.perf_counter() - t00
     t0 = time.perf_counter()
@@ -571,11 +579,131 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
         wall = dt if wall is None else min(wall, dt)
     ok = sum(e is None for e in tracks.errors)
     finite = bool(np.isfinite(tracks.means[:, -1]).all())
-    if tracker._ctx is not None:
-        tracker._ctx.close()
-    return {"api_ms_per_step": 1e3 * wall / (n_frames - 1), "api_track_seconds": wall,
-            "api_first_call_seconds": wall_cold, "api_object_setup_seconds": t_setup,
-            "api_tracks_ok": ok, "api_last_means_finite": finite}
+    out = {"api_ms_per_step": 1e3 * wall / (n_frames - 1), "api_track_seconds": wall,
+           "api_first_call_seconds": wall_cold, "api_object_setup_seconds": t_setup,
+           "api_tracks_ok": ok, "api_last_means_finite": finite}
+    # Tracker.track(parallel=2): two persistent worker processes (here: sharing this one GPU), the frames shared with
+    # them once through shared memory, the history collected by one RCCL exchange or -- two ranks on one device cannot
+    # make a communicator -- through host memory.  What a call costs beyond the workers' own tracking.
+    try:
+        t0 = time.perf_counter()
+        par = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed, parallel=2)
+        cold = time.perf_counter() - t0  # starts the workers, shares the frames, makes their contexts
+        warm, info = None, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            par = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed, parallel=2)
+            dt = time.perf_counter() - t0
+            if warm is None or dt < warm:
+                warm, info = dt, par.parallel_info
+        out["api_parallel_2"] = {
+            "workers": 2, "devices": min(2, max(1, _device_count())), "transport": par.transport,
+            "first_call_seconds": cold, "call_seconds": warm, "ms_per_step": 1e3 * warm / (n_frames - 1),
+            "worker_track_seconds": info["worker_track_seconds"], "worker_seconds": info["worker_seconds"],
+            "overhead_seconds_per_call": warm - max(info["worker_track_seconds"]),
+            "single_process_call_seconds": wall, "contexts_made_in_warm_call": int(sum(info["contexts_made"])),
+            "shared_frame_bytes": info["shared_frame_bytes"],
+            "same_as_single_process": bool(np.array_equal(par.means, tracks.means, equal_nan=True)
+                                           and np.array_equal(par.sigmas, tracks.sigmas, equal_nan=True)),
+            "note": "overhead = the call's wall time beyond the slower worker's own Tracker.track(): pickled models out, "
+                    "errors / warnings and the history back; on ONE GPU the two workers share the device, so the call "
+                    "cannot be faster than the single-process one"}
+    except Exception as e:  # noqa: BLE001
+        out["api_parallel_2"] = {"error": repr(e)}
+    tracker.close()
+    return out
+
+
+def from_files_leg(wl, frames, n_frames, seed, device, fmt, compute_only_seconds):
+    """C3 as a run FROM IMAGE FILES (image.py:137-214): the frames are written to a directory as `fmt`
+    ("jpeg": quality 95, what a time-lapse camera leaves; "tiff": uncompressed) -- untimed --, then
+    Tracker.track(rng="philox") runs from glimpse_amd.Image(path=...) objects that hold no pixels: a pool of threads
+    decodes them (Pillow, one thread per usable core) while the frame loop runs on the frames already resident (pinned
+    staging ring + copy stream, glh_observer_upload_frame_async).  Timed: the whole call on a Tracker whose context
+    exists (a first call made it) and whose frames were forgotten (`forget_frames`), the median of three.  Checked: the
+    tracks equal, bit for bit, those of the same pixels handed over as arrays."""
+    import datetime
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image as PILImage
+
+    import glimpse_amd as g
+
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="glh_bench_files_", dir=base)
+    ext, kw = (".jpg", dict(format="JPEG", quality=95)) if fmt == "jpeg" else (".tif", dict(format="TIFF"))
+    t_start, unit = datetime.datetime(2020, 1, 1), datetime.timedelta(days=1)
+    try:
+        paths = [[os.path.join(tmp, f"o{o}_{t:04d}{ext}") for t in range(n_frames)] for o in range(wl.O)]
+
+        def write(job):
+            o, t = job
+            PILImage.fromarray(np.asarray(frames[o][t])).save(paths[o][t], **kw)
+
+        with ThreadPoolExecutor(max_workers=usable_cores()) as pool:
+            list(pool.map(write, [(o, t) for o in range(wl.O) for t in range(n_frames)]))
+        file_bytes = sum(os.path.getsize(p) for po in paths for p in po)
+
+        def observers(from_arrays):
+            out = []
+            for o in range(wl.O):
+                v = wl.cams[o]
+                images = []
+                for t in range(n_frames):
+                    cam = g.Camera(imgsz=v[6:8], f=v[8:10], c=v[10:12], k=v[12:18], p=v[18:20], xyz=v[0:3], viewdir=v[3:6])
+                    if from_arrays:
+                        with PILImage.open(paths[o][t]) as im:
+                            images.append(g.Image(cam=cam, datetime=t_start + t * unit, array=np.asarray(im)))
+                    else:
+                        images.append(g.Image(path=paths[o][t], cam=cam, datetime=t_start + t * unit))
+                out.append(g.Observer(images, sigma=wl.sigmas[o], cache=False))  # (a read leaves nothing on the image)
+            return out
+
+        _, models = _api_objects(wl, [f[:2] for f in frames], 2)
+        tracker = g.Tracker(observers(False), device=device)
+        t0 = time.perf_counter()
+        tracks = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
+        cold = time.perf_counter() - t0  # makes the context as well
+        runs = []
+        for _ in range(3):
+            tracker.forget_frames()
+            t0 = time.perf_counter()
+            again = tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
+            runs.append((time.perf_counter() - t0, dict(tracker._feed_stats)))
+        same_again = bool(np.array_equal(again.means, tracks.means, equal_nan=True))
+        tracker.close()
+        runs.sort(key=lambda r: r[0])
+        wall, st = runs[1]
+        # the same pixels as in-memory arrays (decoded here, untimed): the tracks must be the same numbers
+        ref_tracker = g.Tracker(observers(True), device=device)
+        ref = ref_tracker.track(models, tile_size=wl.tile, rng="philox", seed=seed)
+        ref_tracker.close()
+        same = bool(np.array_equal(ref.means, tracks.means, equal_nan=True) and np.array_equal(ref.sigmas, tracks.sigmas, equal_nan=True))
+        return {
+            "workload": wl.describe()["workload"], "format": fmt, "files": st["files"], "file_MB": file_bytes / 1e6,
+            "decoded_MB": st["bytes"] / 1e6, "call_seconds": wall, "call_seconds_min_max": [runs[0][0], runs[-1][0]],
+            "first_call_seconds": cold, "frames_per_s": n_frames / wall, "ms_per_frame": 1e3 * wall / (n_frames - 1),
+            "decode_threads": st["threads"], "decode_ms_per_frame_per_core": 1e3 * st["decode_seconds"] / max(1, st["files"]),
+            "decode_bound_seconds": st["decode_seconds"] / max(1, st["threads"]),
+            "upload_staging_seconds": st["upload_seconds"],
+            "upload_staging_GBps": st["bytes"] / max(st["upload_seconds"], 1e-9) / 1e9,
+            "frame_loop_waited_for_decoders_seconds": st["wait_seconds"],
+            "compute_only_call_seconds": compute_only_seconds,
+            "gpu_idle_share": max(0.0, 1.0 - compute_only_seconds / wall),
+            "same_tracks_as_arrays": same and same_again,
+            "note": "gpu_idle_share = 1 - (the same call on frames already resident) / (this call): the share of the call the "
+                    "device pipeline was not the limiter; decode_bound_seconds = the decoders' summed time / threads, what "
+                    "the call cannot go below while decoding limits it"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _device_count():
+    from glimpse_amd import _lib
+
+    return _lib.device_count()
 
 
 def apply_motion(ctx, wl, motion, dem="constant"):
@@ -631,21 +759,26 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3, repeats=3):
     initialise()
     run(1, min(warm, n_frames - 1))
     ctx.sync()
-    ctx.profile_enable(True)
-    passes = []
-    for _ in range(max(1, repeats)):  # (the median repetition is reported, like the headline)
+
+    def one_pass(profiled):
         initialise()
         ctx.sync()
+        ctx.profile_enable(profiled)
         ctx.profile_reset()
         t0 = time.perf_counter()
         run(1, n_frames - 1)
         ctx.sync()
-        wall = time.perf_counter() - t0
-        stage_ms = ctx.profile_get()
-        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
-        passes.append((wall, stage_ms, dom, ctx.profile_launches(dom), ctx.profile_span(dom)))
-    walls = sorted(p[0] for p in passes)
-    wall, stage_ms, dom, launch_ms, span_ms = sorted(passes, key=lambda p: p[0])[(len(passes) - 1) // 2]
+        return time.perf_counter() - t0
+
+    # (like the headline: `repeats` passes without event timers, the median reported; one more with HIP events around
+    # every launch for the launch durations and the GPU span)
+    walls = sorted(one_pass(False) for _ in range(max(1, repeats)))
+    wall = walls[(len(walls) - 1) // 2]
+    profiled_wall = one_pass(True)
+    stage_ms = ctx.profile_get()
+    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+    launch_ms = ctx.profile_launches(dom)
+    span_ms = ctx.profile_span(dom)
     streams = ctx.last_track_streams()
     ctx.profile_enable(False)
     status = ctx.observer_status()
@@ -662,7 +795,7 @@ def measure_sequence(ctx, wl, n_frames, seed, math, warm=3, repeats=3):
         "variant": list(ctx.last_variant()),
         "ms_per_frame": 1e3 * wall / (n_frames - 1),
         "ms_per_frame_min_max": [round(1e3 * walls[0] / (n_frames - 1), 5), round(1e3 * walls[-1] / (n_frames - 1), 5)],
-        "repeats": len(walls),
+        "repeats": len(walls), "profiled_pass_ms_per_frame": 1e3 * profiled_wall / (n_frames - 1),
         "kernel_ms_per_launch": per_launch, "track_streams": streams, "gpu_ms_per_frame": gpu_per_frame,
         "value": wl.P * wl.N * (n_frames - 1) / wall,
         "frames_per_s": (n_frames - 1) / wall,
@@ -860,35 +993,38 @@ def worker(args):
     ctx.sync()
 
     # The timed region -- the K steps -- R times (round 5): every repetition starts from the prior again (untimed
-    # re-initialisation + burn-in), is bracketed by barriers and carries its own HIP events around every kernel launch;
-    # the line reports the MEDIAN repetition (its wall time, its launch durations, its GPU span) and the spread of all.
+    # re-initialisation + burn-in) and is bracketed by barriers; `value` is the MEDIAN repetition's, `spread` lists all.
+    # These repetitions carry NO event timers: a HIP event pair around every launch costs small batches 13 % of a
+    # frame (C2: 0.052 ms per frame with them, 0.045 without -- profiles/ab_r05/r5j01_graph_bigframes.txt).  One MORE
+    # pass of the same region is then run with HIP events around every kernel launch (on the streams the launches are
+    # enqueued on): the roofline's launch durations and GPU span come from that pass, its wall time is reported beside.
     R = max(1, args.repeats)
-    passes = []
-    ctx.profile_enable(True)
-    for _ in range(R):
+
+    def timed_pass(profiled):
         initialise()  # back to the prior (untimed)
         run(1, B)  # burn-in, untimed
         ctx.sync()
+        ctx.profile_enable(profiled)
         ctx.profile_reset()
         group.barrier()
         t0 = time.perf_counter()
         run(1 + B, K * F)
-        gathered = None
+        got = None
         if world > 1:
             ctx.sync()
-            gathered = gather()
+            got = gather()
         group.barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed = group.max(elapsed)
-        stage_ms = ctx.profile_get()
-        dom = max(stage_ms, key=lambda k: stage_ms[k][0])
-        passes.append(dict(elapsed=elapsed, stage_ms=stage_ms, dom=dom, launch_ms=ctx.profile_launches(dom),
-                           span_ms=ctx.profile_span(dom), gathered=gathered))
-    order = sorted(range(R), key=lambda i: passes[i]["elapsed"])
-    mid = passes[order[(R - 1) // 2]]  # the median repetition (the lower middle one of an even count)
-    elapsed, stage_ms, dom, launch_ms, span_ms = (mid[k] for k in ("elapsed", "stage_ms", "dom", "launch_ms", "span_ms"))
-    gathered = passes[-1]["gathered"]  # (checked against the state the last repetition left; every repetition draws the same)
-    all_elapsed = [p["elapsed"] for p in passes]
+        return group.max(time.perf_counter() - t0), got
+
+    all_elapsed = []
+    for _ in range(R):
+        all_elapsed.append(timed_pass(False)[0])
+    elapsed = sorted(all_elapsed)[(R - 1) // 2]  # the median repetition (the lower middle one of an even count)
+    profiled_elapsed, gathered = timed_pass(True)  # (the gathered history: checked against the state this last pass left)
+    stage_ms = ctx.profile_get()
+    dom = max(stage_ms, key=lambda k: stage_ms[k][0])
+    launch_ms = ctx.profile_launches(dom)
+    span_ms = ctx.profile_span(dom)
     streams = ctx.last_track_streams() if C > 1 else 1
     ctx.profile_enable(False)
     _mark("headline timed")
@@ -932,7 +1068,10 @@ def worker(args):
                        "ms_per_step_min": 1e3 * min(all_elapsed) / K, "ms_per_step_max": 1e3 * max(all_elapsed) / K,
                        "value_min": total_points * wl.N * K * F / max(all_elapsed),
                        "value_max": total_points * wl.N * K * F / min(all_elapsed),
-                       "ms_per_step_all": [round(1e3 * e / K, 5) for e in all_elapsed]},
+                       "ms_per_step_all": [round(1e3 * e / K, 5) for e in all_elapsed],
+                       "profiled_pass_ms_per_step": 1e3 * profiled_elapsed / K,
+                       "note": "the n repetitions run without event timers; one more pass of the same region with HIP "
+                               "events around every launch gives the roofline's launch durations and GPU span"},
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -1043,6 +1182,14 @@ def worker(args):
                 _mark("API leg")
             except Exception as e:  # noqa: BLE001
                 out["api_error"] = repr(e)
+            if secondary and "api_track_seconds" in out:
+                for fmt in ("jpeg", "tiff"):  # (the run from files: decode pool -> pinned ring -> HBM while tracking)
+                    try:
+                        out["secondary"][f"C3_from_files_{fmt}"] = from_files_leg(wl, frames, T, seed, device, fmt,
+                                                                                  out["api_track_seconds"])
+                    except Exception as e:  # noqa: BLE001
+                        out["secondary"][f"C3_from_files_{fmt}"] = {"error": repr(e)}
+                _mark("run from files")
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, frames, T, args.cpu_seconds)
@@ -1058,6 +1205,7 @@ def worker(args):
         if h["points_with_error_bits"] or h["observer_ok_fraction"] < 0.99 or not h["final_means_finite"] \
                 or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False \
                 or "api_error" in out or "cpu_baseline_error" in out \
+                or "error" in out.get("api_parallel_2", {}) or out.get("api_parallel_2", {}).get("same_as_single_process") is False \
                 or any("error" in leg or leg.get("points_with_error_bits") or not leg.get("final_means_finite", True)
                        or leg.get("observer_ok_fraction", 1.0) < 0.99 for leg in out.get("secondary", {}).values()):
             rc = 3

@@ -165,7 +165,7 @@ inline void spline_lu(int n, double* out) {
 // Degree-k collocation matrix (glh_math.h: gspl_*) factored without pivoting (it is totally positive), bandwidth k on
 // either side: out = [L: k arrays of n, L_d[i] at (i, i - d)] [u0inv: n] [U: k arrays of n, U_d[i] at (i, i + d)],
 // (2 k + 1) n doubles.  Same elimination as oracle/spline.py: lu_general.
-inline void spline_lu_general(int n, int k, double* out) {
+inline bool spline_lu_general(int n, int k, double* out) {
   // banded storage, (2 k + 1) columns per row: a(i, j) at band[i * W + (j - i + k)] -- the elimination below only ever
   // touches |i - j| <= k (round 4: this was a dense n x n matrix, O(dim^2) memory per size and O(dim^3) over the sizes
   // of a context, seconds at the 1280 .. 2000 pixel workspaces the Tracker's growth loop can reach)
@@ -178,7 +178,10 @@ inline void spline_lu_general(int n, int k, double* out) {
     gspl_basis((double)i, l, n, k, h);
     for (int m = 0; m <= k; ++m) {
       const int j = l - k + m;
-      if (j - i >= -k && j - i <= k) A(i, j) = h[m];  // (the support of row i lies within k of the diagonal)
+      // the support of row i lies within k of the diagonal: a basis value outside the band would be dropped from the
+      // factorisation without notice -- refused instead (a knot layout that put one there is a bug to be seen)
+      if (j - i >= -k && j - i <= k) A(i, j) = h[m];
+      else if (h[m] != 0.0) return false;
     }
   }
   double* L = out;
@@ -198,6 +201,7 @@ inline void spline_lu_general(int n, int k, double* out) {
     for (int d = 1; d <= k; ++d)
       if (i + d < n) U[(size_t)(d - 1) * n + i] = A(i, i + d);
   }
+  return true;
 }
 
 // The same collocation matrix inverted explicitly (row-major n x n): for small surfaces the fit is two

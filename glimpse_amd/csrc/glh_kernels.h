@@ -194,17 +194,20 @@ __device__ __forceinline__ uint32_t viewshed_bits(const Surfaces& surf, double x
 }
 
 // CartesianMotion.compute_log_likelihoods (motion.py:181-204) for one (evolved) particle
+// FAST: the surface samples in fast arithmetic (glh_math.h: raster_bilinear_fast), the scale by a Newton reciprocal.
+template <bool FAST = false>
 __device__ __forceinline__ double dem_log_likelihood(const double* m, const Surfaces& surf, double x, double y,
                                                      double z, bool* oob, const RasterPatch* patches = nullptr) {
   double zd, zs;
   // (both surfaces rasters on one grid, the sample inside their windows: the cell and the weights once for both)
   if (!(patches && m[20] != 0.0 && m[21] != 0.0 &&
-        raster_sample_pair(surf.dem, surf.dem_sigma, patches, patches + 1, x, y, zd, zs))) {
-    zd = dem_at(m, surf, x, y, oob, patches);
-    zs = dem_sigma_at(m, surf, x, y, oob, patches);
+        raster_sample_pair<FAST>(surf.dem, surf.dem_sigma, surf.same_grid != 0, patches, patches + 1, x, y, zd, zs))) {
+    zd = dem_at<FAST>(m, surf, x, y, oob, patches);
+    zs = dem_sigma_at<FAST>(m, surf, x, y, oob, patches);
   }
   if (zs != 0.0) {
     const double d = zd - z;
+    if constexpr (FAST) return rcp_nr(2.0 * (zs * zs)) * (d * d);
     return (1.0 / (2.0 * (zs * zs))) * (d * d);
   }
   return 0.0;
@@ -332,9 +335,15 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
   const bool cyl = kind == GLH_MOTION_CYLINDRICAL || kind == GLH_MOTION_TANGENT_CYLINDRICAL;
   const bool tangent = kind >= GLH_MOTION_TANGENT_CARTESIAN;
   double a[3];
-  a[0] = m[10] + m[13] * n[0];
-  a[1] = m[11] + m[14] * n[1];
-  a[2] = tangent ? 0.0 : m[12] + m[15] * n[2];
+  if constexpr (FAST) {
+    a[0] = glh_fma(m[13], n[0], m[10]);
+    a[1] = glh_fma(m[14], n[1], m[11]);
+    a[2] = tangent ? 0.0 : glh_fma(m[15], n[2], m[12]);
+  } else {
+    a[0] = m[10] + m[13] * n[0];
+    a[1] = m[11] + m[14] * n[1];
+    a[2] = tangent ? 0.0 : m[12] + m[15] * n[2];
+  }
   if (cyl) {
     // (r'', theta') -> (x'', y''): r'' * cos(th) - r' * sin(th) * th',  r'' * sin(th) + r' * cos(th) * th'
     const double vx = p[3], vy = p[4];
@@ -352,23 +361,37 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
     return;
   }
   // tangent models: the height follows the surface plus a random walk of the offset
-  const double dx = tau * p[3] + 0.5 * a[0] * tau2;
-  const double dy = tau * p[4] + 0.5 * a[1] * tau2;
+  // (FAST: fused multiply-adds, the two surface samples in fast arithmetic -- raster_bilinear_fast --, a Newton square root)
+  const double dx = FAST ? glh_fma(0.5 * tau2, a[0], tau * p[3]) : tau * p[3] + 0.5 * a[0] * tau2;
+  const double dy = FAST ? glh_fma(0.5 * tau2, a[1], tau * p[4]) : tau * p[4] + 0.5 * a[1] * tau2;
   if constexpr (ZKNOWN) {
     p[0] += dx;
     p[1] += dy;
     p[2] = z_known;
-    p[3] += tau * a[0];
-    p[4] += tau * a[1];
+    if constexpr (FAST) {
+      p[3] = glh_fma(tau, a[0], p[3]);
+      p[4] = glh_fma(tau, a[1], p[4]);
+    } else {
+      p[3] += tau * a[0];
+      p[4] += tau * a[1];
+    }
     return;
   }
-  double z_off = p[2] - (GRID ? dem_at(m, surf, p[0], p[1], oob, patches) : m[16]);
-  z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
+  double z_off = p[2] - (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches) : m[16]);
+  if constexpr (FAST)
+    z_off = glh_fma(m[19] * n[2], sqrt_nr(glh_fma(dx, dx, dy * dy)), z_off);
+  else
+    z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;
   p[1] += dy;
-  p[2] = (GRID ? dem_at(m, surf, p[0], p[1], oob, patches) : m[16]) + z_off;
-  p[3] += tau * a[0];
-  p[4] += tau * a[1];
+  p[2] = (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches) : m[16]) + z_off;
+  if constexpr (FAST) {
+    p[3] = glh_fma(tau, a[0], p[3]);
+    p[4] = glh_fma(tau, a[1], p[4]);
+  } else {
+    p[3] += tau * a[0];
+    p[4] += tau * a[1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2323,7 +2346,8 @@ __global__ __launch_bounds__(BLK) void k_weights(WeightArgs a) {
     }
     if (has_motion_term && gridded) {
       const double* q = a.particles + ((size_t)pt * a.N + i) * 6;
-      ll += dem_log_likelihood(m, a.surf, q[0], q[1], q[2], &oob);
+      ll += a.fast ? dem_log_likelihood<true>(m, a.surf, q[0], q[1], q[2], &oob)
+                   : dem_log_likelihood<false>(m, a.surf, q[0], q[1], q[2], &oob);
     } else if (zs != 0.0) {
       double z = a.particles[((size_t)pt * a.N + i) * 6 + 2];
       double d = m[16] - z;

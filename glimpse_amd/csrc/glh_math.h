@@ -149,6 +149,23 @@ GLH_HD double rcp_nr(double x) {  // 1 / x: v_rcp_f64 + two Newton steps (<= 1 u
   return 1.0 / x;
 #endif
 }
+GLH_HD double sqrt_nr(double x) {  // sqrt(x), x >= 0: v_rsq_f64 + Goldschmidt / Newton steps (<= 1 ulp for normal x; 0 -> 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return x > 0.0 ? g : x;  // (0 and NaN come back as they are; rsq(0) = inf would make NaN of them)
+#else
+  return sqrt(x);
+#endif
+}
 // min / max of two non-NaN doubles as ONE instruction (HIP's fmin / fmax canonicalise both operands first: three)
 GLH_HD double min_nn(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -361,18 +378,19 @@ GLH_HD int raster_guess(int n, double x, double lo_limit, double k) {
   const double t = (x - lo_limit) * k - 0.5;
   return t > 0.0 ? (t < (double)(n - 2) ? (int)t : n - 2) : 0;  // (NaN: 0; the caller has tested x against the limits)
 }
-// (g may be a window of the coordinates placed so that g[j] is coordinate j for j = i - 1 .. i + 2: all this reads)
-GLH_HD int raster_interval(const double* g, int n, double x, int i, double& ga, double& gb) {
-  ga = g[i];
-  gb = g[i + 1];
+// (g may be a window of the coordinates: g[(j - origin) * STRIDE] is coordinate j, for j = i - 1 .. i + 2 -- all this reads)
+template <int STRIDE = 1>
+GLH_HD int raster_interval(const double* g, int n, double x, int i, double& ga, double& gb, int origin = 0) {
+  ga = g[(i - origin) * STRIDE];
+  gb = g[(i + 1 - origin) * STRIDE];
   if (i > 0 && ga >= x) {
     --i;
     gb = ga;
-    ga = g[i];
+    ga = g[(i - origin) * STRIDE];
   } else if (i < n - 2 && gb < x) {
     ++i;
     ga = gb;
-    gb = g[i + 1];
+    gb = g[(i + 1 - origin) * STRIDE];
   }
   return i;
 }
@@ -391,8 +409,13 @@ inline bool raster_coordinates_uniform(const double* g, int n, double lo_limit, 
 constexpr int GLH_PATCH_W = 12;
 struct RasterPatch {
   double z[GLH_PATCH_W * GLH_PATCH_W];
-  double gx[GLH_PATCH_W], gy[GLH_PATCH_W];
+  // per axis, node k of the window: its coordinate g[k] at [2 k] and rcp_nr(g[k + 1] - g[k]), the reciprocal width of the
+  // interval it starts (fast arithmetic), at [2 k + 1] -- one 16-byte LDS read brings both
+  double ax[2 * GLH_PATCH_W], ay[2 * GLH_PATCH_W];
+  double fkx, fky;       // cells per unit length (the raster's kx, ky): the guess of raster_window_axis
   int32_t i0, j0, w, h;  // w = 0: nothing held
+  int32_t full;          // w == h == GLH_PATCH_W: raster_sample_window serves this window
+  int32_t pair;          // (window 0 only) ... and the dem_sigma window beside it lies on the same grid at the same origin
 };
 // where the window around (x, y) starts, and how many nodes it holds
 GLH_HD void raster_patch_origin(const RasterDev& r, double x, double y, int& i0, int& j0, int& w, int& h) {
@@ -411,10 +434,75 @@ GLH_HD double raster_node(const RasterDev& r, int ix, int iy) {
   return r.z[(size_t)row * r.nx + col];
 }
 
+// The bilinear interpolant of one cell in fast arithmetic (GLH_MATH_FAST): the weights are (x - xa) x the interval's
+// reciprocal width (a Newton reciprocal, rcp_nr: made once per interval when the window is loaded, per sample without a
+// window -- the same bits) instead of two IEEE divisions, and the four products are three fused multiply-adds.  Within
+// rounding of the exact form below; the fused and the staged kernels share it.
+GLH_HD double raster_bilinear_fast(double z00, double z10, double z01, double z11, double tx, double ty) {
+  const double a = glh_fma(tx, z10 - z00, z00), b = glh_fma(tx, z11 - z01, z01);
+  return glh_fma(ty, b - a, a);
+}
+// is the interval guess g (and what one step around it reads) inside a window of `w` nodes starting at `o` of an axis of `n`?
+GLH_HD bool raster_in_window(int g, int o, int w, int n) {
+  const int l = g - o;
+  return (l >= 1 || g == 0) && l >= 0 && (l + 2 < w || g == n - 2) && l + 1 < w;
+}
+
+// The common sample of the fused kernel in fast arithmetic, from the window ALONE (round 5): nothing of the raster's
+// descriptor is read -- the loop that called raster_sample for every particle re-loaded the kernel arguments 23 times per
+// particle and waited for each (scalar registers are short there).  One axis: cells from the window's first node,
+// f = (x - g[0]) k; for f in [1, W - 2) the interval is floor(f) moved by at most one (the coordinates are within a quarter
+// cell of a uniform grid's, so is g[0]: floor(f) is within one of the answer), x lies strictly inside the window's span --
+// hence inside the raster's limits, no bounds test -- and the interval is not clipped.  The same interval (g[i] < x <=
+// g[i + 1]) and the same weight (x - g[i]) * rcp_nr(g[i + 1] - g[i]) as raster_sample<true> finds: bit for bit its value.
+// Three dependent LDS round trips per sample (the window's origin and cell size, the guessed nodes, the cell's corners) and
+// one rarely taken branch: the first form of this -- the interval step as nested branches, every load behind its own
+// wait -- took six and fifteen exec-mask instructions per axis.
+GLH_HD bool raster_window_axis(const double* a, double k, double x, int& li, double& t) {
+  const double f = (x - a[0]) * k;
+  const bool ok = f >= 1.0 && f < (double)(GLH_PATCH_W - 2);  // (NaN: false)
+  int i = (int)fmin(fmax(f, 1.0), (double)(GLH_PATCH_W - 3));  // in [1, W - 3] whatever f is: the reads below stay inside
+  double ga = a[2 * i], r = a[2 * i + 1];
+  const double gb = a[2 * i + 2];
+  // (both comparisons always: as a short-circuit the second node's read sat behind a branch on the first, a round trip more)
+  if ((int)!(ga < x) | (int)!(x <= gb)) {
+    // the guess is one off: x within rounding of a node, or coordinates that are not exactly a uniform grid's (rare)
+    i += ga >= x ? -1 : 1;  // in [0, W - 2]
+    ga = a[2 * i];
+    r = a[2 * i + 1];
+  }
+  li = i;
+  t = (x - ga) * r;
+  return ok;
+}
+// p1: the window of a second raster on the same grid at the same origin (PAIR), sampled with the same cell and weights
+template <bool PAIR>
+GLH_HD bool raster_sample_window(const RasterPatch* p0, const RasterPatch* p1, double x, double y, double& v0, double& v1) {
+  int li, lj;
+  double tx, ty;
+  const bool okx = raster_window_axis(p0->ax, p0->fkx, x, li, tx);
+  const bool oky = raster_window_axis(p0->ay, p0->fky, y, lj, ty);
+  const double* z = p0->z + lj * GLH_PATCH_W + li;
+  v0 = raster_bilinear_fast(z[0], z[1], z[GLH_PATCH_W], z[GLH_PATCH_W + 1], tx, ty);
+  if constexpr (PAIR) {
+    const double* zz = p1->z + lj * GLH_PATCH_W + li;
+    v1 = raster_bilinear_fast(zz[0], zz[1], zz[GLH_PATCH_W], zz[GLH_PATCH_W + 1], tx, ty);
+  }
+  return okx & oky;  // (false: the values are of a clamped cell -- the caller samples the raster itself)
+}
+
 // order 1: bilinear (RegularGridInterpolator method 'linear'); order 0: 'nearest'.  Sets *oob when the
 // point is outside the raster's outer limits (the reference raises ValueError there).  `patch`: a window of THIS raster
 // (or null); a sample whose interval and its neighbours lie inside is read from it -- same values, same arithmetic.
+// FAST: raster_bilinear_fast for order 1 (order 0 has one form).
+template <bool FAST = false>
 GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob, const RasterPatch* patch = nullptr) {
+  if constexpr (FAST) {
+    if (patch && order == 1 && patch->full) {  // (uniform)
+      double v, unused;
+      if (raster_sample_window<false>(patch, patch, x, y, v, unused)) return v;
+    }
+  }
   if (!(x >= r.xmin && x <= r.xmax && y >= r.ymin && y <= r.ymax)) {
     *oob = true;
     return NAN;
@@ -423,20 +511,24 @@ GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, b
   const int gi = raster_guess(r.nx, x, r.xmin, r.kx), gj = raster_guess(r.ny, y, r.ymin, r.ky);
   if (patch && order == 1) {
     // the step of raster_interval reads nodes guess - 1 .. guess + 2 (clipped to the raster): all inside the window?
-    const int li = gi - patch->i0, lj = gj - patch->j0;
-    const bool in_x = (li >= 1 || gi == 0) && li >= 0 && (li + 2 < patch->w || gi == r.nx - 2) && li + 1 < patch->w;
-    const bool in_y = (lj >= 1 || gj == 0) && lj >= 0 && (lj + 2 < patch->h || gj == r.ny - 2) && lj + 1 < patch->h;
-    if (in_x && in_y) {
-      const int i0 = raster_interval(patch->gx - patch->i0, r.nx, x, gi, xa, xb) - patch->i0;
-      const int i1 = raster_interval(patch->gy - patch->j0, r.ny, y, gj, ya, yb) - patch->j0;
+    if (raster_in_window(gi, patch->i0, patch->w, r.nx) && raster_in_window(gj, patch->j0, patch->h, r.ny)) {
+      const int i0 = raster_interval<2>(patch->ax, r.nx, x, gi, xa, xb, patch->i0) - patch->i0;
+      const int i1 = raster_interval<2>(patch->ay, r.ny, y, gj, ya, yb, patch->j0) - patch->j0;
+      const double* z = patch->z + i1 * GLH_PATCH_W + i0;
+      if constexpr (FAST)
+        return raster_bilinear_fast(z[0], z[1], z[GLH_PATCH_W], z[GLH_PATCH_W + 1], (x - xa) * patch->ax[2 * i0 + 1],
+                                    (y - ya) * patch->ay[2 * i1 + 1]);
       const double y0 = (x - xa) / (xb - xa);
       const double y1 = (y - ya) / (yb - ya);
-      const double* z = patch->z + i1 * GLH_PATCH_W + i0;
       return z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) +
              z[GLH_PATCH_W + 1] * y0 * y1;
     }
   }
   const int i0 = raster_interval(r.gx, r.nx, x, gi, xa, xb), i1 = raster_interval(r.gy, r.ny, y, gj, ya, yb);
+  if constexpr (FAST)
+    if (order == 1)
+      return raster_bilinear_fast(raster_node(r, i0, i1), raster_node(r, i0 + 1, i1), raster_node(r, i0, i1 + 1),
+                                  raster_node(r, i0 + 1, i1 + 1), (x - xa) * rcp_nr(xb - xa), (y - ya) * rcp_nr(yb - ya));
   const double y0 = (x - xa) / (xb - xa);
   const double y1 = (y - ya) / (yb - ya);
   if (order == 0) return raster_node(r, y0 <= 0.5 ? i0 : i0 + 1, y1 <= 0.5 ? i1 : i1 + 1);
@@ -445,29 +537,37 @@ GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, b
 }
 
 // Two rasters on ONE grid (a DEM and its uncertainty usually are) sampled at one point through their windows: the cell and
-// the two weights are found once.  Returns false (nothing done) unless both samples can be served from the windows --
-// the caller then samples each raster on its own.  Same values, same arithmetic as raster_sample.
-GLH_HD bool raster_sample_pair(const RasterDev& r0, const RasterDev& r1, const RasterPatch* p0, const RasterPatch* p1, double x,
-                               double y, double& v0, double& v1) {
-  const bool same = r0.nx == r1.nx && r0.ny == r1.ny && r0.xmin == r1.xmin && r0.xmax == r1.xmax && r0.ymin == r1.ymin &&
-                    r0.ymax == r1.ymax && p0->i0 == p1->i0 && p0->j0 == p1->j0 && p0->w == p1->w && p0->h == p1->h;  // (uniform)
+// the two weights are found once.  `same_grid`: the host found the two rasters' coordinate arrays bit-identical
+// (glh_set_raster; equal limits alone would not say that).  Returns false (nothing done) unless both samples can be served
+// from the windows -- the caller then samples each raster on its own.  Same values, same arithmetic as raster_sample.
+template <bool FAST = false>
+GLH_HD bool raster_sample_pair(const RasterDev& r0, const RasterDev& r1, bool same_grid, const RasterPatch* p0,
+                               const RasterPatch* p1, double x, double y, double& v0, double& v1) {
+  if constexpr (FAST) {
+    if (p0->pair && raster_sample_window<true>(p0, p1, x, y, v0, v1)) return true;  // (pair: uniform)
+  }
+  const bool same = same_grid && r0.nx == r1.nx && r0.ny == r1.ny && r0.xmin == r1.xmin && r0.xmax == r1.xmax &&
+                    r0.ymin == r1.ymin && r0.ymax == r1.ymax && p0->i0 == p1->i0 && p0->j0 == p1->j0 && p0->w == p1->w &&
+                    p0->h == p1->h;  // (uniform)
   if (!same) return false;
   if (!(x >= r0.xmin && x <= r0.xmax && y >= r0.ymin && y <= r0.ymax)) return false;
   const int gi = raster_guess(r0.nx, x, r0.xmin, r0.kx), gj = raster_guess(r0.ny, y, r0.ymin, r0.ky);
-  const int li = gi - p0->i0, lj = gj - p0->j0;
-  const bool in_x = (li >= 1 || gi == 0) && li >= 0 && (li + 2 < p0->w || gi == r0.nx - 2) && li + 1 < p0->w;
-  const bool in_y = (lj >= 1 || gj == 0) && lj >= 0 && (lj + 2 < p0->h || gj == r0.ny - 2) && lj + 1 < p0->h;
-  if (!(in_x && in_y)) return false;
-  // (the coordinates of one grid are the same numbers in both windows: np.linspace of the same limits)
+  if (!(raster_in_window(gi, p0->i0, p0->w, r0.nx) && raster_in_window(gj, p0->j0, p0->h, r0.ny))) return false;
   double xa, xb, ya, yb;
-  const int i0 = raster_interval(p0->gx - p0->i0, r0.nx, x, gi, xa, xb) - p0->i0;
-  const int i1 = raster_interval(p0->gy - p0->j0, r0.ny, y, gj, ya, yb) - p0->j0;
+  const int i0 = raster_interval<2>(p0->ax, r0.nx, x, gi, xa, xb, p0->i0) - p0->i0;
+  const int i1 = raster_interval<2>(p0->ay, r0.ny, y, gj, ya, yb, p0->j0) - p0->j0;
+  const double* z = p0->z + i1 * GLH_PATCH_W + i0;
+  const double* zz = p1->z + i1 * GLH_PATCH_W + i0;
+  if constexpr (FAST) {
+    const double tx = (x - xa) * p0->ax[2 * i0 + 1], ty = (y - ya) * p0->ay[2 * i1 + 1];
+    v0 = raster_bilinear_fast(z[0], z[1], z[GLH_PATCH_W], z[GLH_PATCH_W + 1], tx, ty);
+    v1 = raster_bilinear_fast(zz[0], zz[1], zz[GLH_PATCH_W], zz[GLH_PATCH_W + 1], tx, ty);
+    return true;
+  }
   const double y0 = (x - xa) / (xb - xa);
   const double y1 = (y - ya) / (yb - ya);
-  const double* z = p0->z + i1 * GLH_PATCH_W + i0;
   v0 = z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) + z[GLH_PATCH_W + 1] * y0 * y1;
-  z = p1->z + i1 * GLH_PATCH_W + i0;
-  v1 = z[0] * (1.0 - y0) * (1.0 - y1) + z[GLH_PATCH_W] * (1.0 - y0) * y1 + z[1] * y0 * (1.0 - y1) + z[GLH_PATCH_W + 1] * y0 * y1;
+  v1 = zz[0] * (1.0 - y0) * (1.0 - y1) + zz[GLH_PATCH_W] * (1.0 - y0) * y1 + zz[1] * y0 * (1.0 - y1) + zz[GLH_PATCH_W + 1] * y0 * y1;
   return true;
 }
 
@@ -476,14 +576,18 @@ GLH_HD bool raster_sample_pair(const RasterDev& r0, const RasterDev& r1, const R
 // raster in the reference, motion.py:136-141, raster.py:1021-1026).
 struct Surfaces {
   RasterDev dem, dem_sigma, viewshed;
+  int32_t same_grid;  // the dem and dem_sigma coordinate arrays are bit-identical (the host compared them: glh_set_raster)
+  int32_t pad_;
 };
 // (patches: windows of the dem [0] and the dem_sigma [1] raster, or null)
+template <bool FAST = false>
 GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob, const RasterPatch* patches = nullptr) {
-  return m[20] != 0.0 ? raster_sample(s.dem, x, y, 1, oob, patches) : m[16];
+  return m[20] != 0.0 ? raster_sample<FAST>(s.dem, x, y, 1, oob, patches) : m[16];
 }
+template <bool FAST = false>
 GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double y, bool* oob,
                            const RasterPatch* patches = nullptr) {
-  return m[21] != 0.0 ? raster_sample(s.dem_sigma, x, y, 1, oob, patches ? patches + 1 : nullptr) : m[17];
+  return m[21] != 0.0 ? raster_sample<FAST>(s.dem_sigma, x, y, 1, oob, patches ? patches + 1 : nullptr) : m[17];
 }
 
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is

@@ -28,6 +28,16 @@
 
 namespace glh {
 
+// Two observers, plain code (round 5, experiment -DGLH_PT_RECOMP=1): observer 1's coordinates and the DEM term are not
+// parked in memory between phase A and phase C (32 + 16 bytes per particle-frame through the uv scratch and the weights
+// scratch) -- phase C re-evolves the particle from its pre-evolve record, like the gather does, and projects it again.
+#ifndef GLH_PT_RECOMP
+#define GLH_PT_RECOMP 0
+#endif
+#ifndef GLH_PT_PREFETCH2
+#define GLH_PT_PREFETCH2 0
+#endif
+
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
 constexpr int PT_MAX_TILE = 63;  // largest template side the fused kernel handles (rows padded to 64 floats)
@@ -78,7 +88,7 @@ template <int TB>
 __device__ __forceinline__ void pt_patch_load(const RasterDev& r, double x, double y, bool used, RasterPatch* dst) {
   const int tid = threadIdx.x;
   if (!r.z || !used) {  // (uniform)
-    if (tid == 0) dst->w = dst->h = dst->i0 = dst->j0 = 0;
+    if (tid == 0) dst->w = dst->h = dst->i0 = dst->j0 = dst->full = dst->pair = 0;
     return;
   }
   int i0, j0, w, h;
@@ -88,14 +98,26 @@ __device__ __forceinline__ void pt_patch_load(const RasterDev& r, double x, doub
   if (tid < GLH_PATCH_W * GLH_PATCH_W) {
     if (li < w && lj < h) dst->z[tid] = raster_node(r, i0 + li, j0 + lj);
   } else if (tid < GLH_PATCH_W * GLH_PATCH_W + GLH_PATCH_W) {
+    // a coordinate and (fast arithmetic) the reciprocal width of the interval it starts
     const int k = tid - GLH_PATCH_W * GLH_PATCH_W;
-    if (k < w) dst->gx[k] = r.gx[i0 + k];
+    if (k < w) {
+      const double g0 = r.gx[i0 + k], g1 = r.gx[k + 1 < w ? i0 + k + 1 : i0 + k];
+      dst->ax[2 * k] = g0;
+      dst->ax[2 * k + 1] = k + 1 < w ? rcp_nr(g1 - g0) : 0.0;
+    }
   } else if (tid < GLH_PATCH_W * GLH_PATCH_W + 2 * GLH_PATCH_W) {
     const int k = tid - GLH_PATCH_W * GLH_PATCH_W - GLH_PATCH_W;
-    if (k < h) dst->gy[k] = r.gy[j0 + k];
+    if (k < h) {
+      const double g0 = r.gy[j0 + k], g1 = r.gy[k + 1 < h ? j0 + k + 1 : j0 + k];
+      dst->ay[2 * k] = g0;
+      dst->ay[2 * k + 1] = k + 1 < h ? rcp_nr(g1 - g0) : 0.0;
+    }
   }
   if (tid == 0) {
     dst->i0 = i0; dst->j0 = j0; dst->w = w; dst->h = h;
+    dst->fkx = r.kx; dst->fky = r.ky;
+    dst->full = w == GLH_PATCH_W && h == GLH_PATCH_W;
+    dst->pair = 0;
   }
 }
 
@@ -418,7 +440,7 @@ __device__ __forceinline__ void pt_tile_prep(const ObsFrame& ob, const int* box,
 
 // cv2.matchTemplate(TM_SQDIFF) * 1/(tw*th) (tracker.py:609-614) from ws.S / ws.T into ws.Z (widened
 // to float64 for the spline fit); arithmetic and summation order of k_ssd.
-template <int TB>
+template <int TB, bool SPLIT16 = false>
 __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo, int ho, double* park = nullptr,
                                        double park_v = 0.0) {
   const int tid = threadIdx.x;
@@ -429,7 +451,9 @@ __device__ __forceinline__ void pt_ssd(const TileWs& ws, int tw, int th, int wo,
   // up to 16 lanes while strips x lanes fit the workgroup; the float64 sum of the float32 row sums is exact, so the
   // grouping of the rows does not change a bit of the result
   int G = ssd_row_split(wo, ho);
-  if (TB >= 1024)
+  // (SPLIT16: the two-observer instantiations do the same at 512 threads -- their small surfaces leave most lanes idle
+  // otherwise; C5 -1 %, the one-observer shapes +0.6 .. 0.8 %: profiles/ab_r04/r4j74_ab_g16.txt)
+  if (TB >= 1024 || SPLIT16)
     while (G < 16 && nstrips * (G * 2) <= TB) G *= 2;
   const double inv_area = 1.0 / (double)(tw * th);
   const int lgG = __ffs(G) - 1;  // G is a power of two
@@ -795,11 +819,17 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // general instantiation.
   static_assert(!CONTRACT || FAST, "the compile-time contract belongs to the fast arithmetic");
   constexpr bool COMMON = CONTRACT;
+  constexpr bool RECOMP = GLH_PT_RECOMP && NOBS == 2 && PPT > 0 && !SURF;
   const int rng_mode = COMMON ? (int)GLH_RNG_PHILOX : a.rng_mode;
   PT_STAMP(0);
   const uint16_t* uin = COMMON || a.uidx_in ? a.uidx_in + (size_t)pt * N : nullptr;
   int rec_first = 0;  // (common instantiation: the record of this thread's first particle, see below)
   if constexpr (COMMON) rec_first = (int)uin[tid < N ? tid : 0];
+  // (code 2: the position the raster windows are centred on -- particle 0 before the step -- is requested here, two dependent
+  // loads that travel during the prologue; made behind its barrier they were two memory latencies of their own)
+  double2 grid_q0 = make_double2(0.0, 0.0);
+  if constexpr (GRID)
+    grid_q0 = reinterpret_cast<const double2*>(Pin)[(size_t)(uin ? (int)uin[0] : 0) * (COMMON || uin ? 1 : 3)];
   if (tid == 0) {
     if (rng_mode == GLH_RNG_HOST) {
       s_u = a.u[pt];
@@ -967,9 +997,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // 0 (before the step) is brought into LDS, and the samples of phases A and E read it -- a sample from memory is two
     // rounds of latency (coordinates, then nodes), and the tangent models take two per particle.  Samples that leave the
     // window read the raster as before.
-    const double2 q0 = Pin2[(size_t)s_rec[0] * rec_stride];
+    const double2 q0 = grid_q0;
     pt_patch_load<TB>(a.surf.dem, q0.x, q0.y, m[20] != 0.0, &s_patches.p[0]);
     pt_patch_load<TB>(a.surf.dem_sigma, q0.x, q0.y, m[21] != 0.0, &s_patches.p[1]);
+    if (tid == 0) {  // (its own stores: both windows whole, on one grid -- the host compared the coordinates --, at one origin)
+      RasterPatch* p = s_patches.p;
+      p[0].pair = a.surf.same_grid && p[0].full && p[1].full && p[0].i0 == p[1].i0 && p[0].j0 == p[1].j0;
+    }
     __syncthreads();
   }
   // the evolve step of particle k re-applied to its pre-evolve record x (phase E)
@@ -1074,12 +1108,12 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
           if (GRID && gridded) {
-            ll = dem_log_likelihood(m, a.surf, x[0], x[1], x[2], &raster_oob, s_patches.get());
+            ll = dem_log_likelihood<FAST>(m, a.surf, x[0], x[1], x[2], &raster_oob, s_patches.get());
           } else if (zs != 0.0) {
             const double d = m[16] - x[2];
             ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
           }
-          W[i] = ll;
+          if constexpr (!RECOMP) W[i] = ll;  // (RECOMP: phase C makes the term again from the re-evolved height)
         }
         if (GRID && a.surf.viewshed.z) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
 #pragma unroll
@@ -1098,7 +1132,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
               c[i] = u;
               V0[i] = v;
             }
-          } else
+          } else if constexpr (!RECOMP)
             reinterpret_cast<double2*>(a.uv)[((size_t)o * a.P + pt) * N + i] = make_double2(u, v);
           if (isnan(u) || isnan(v)) {
             nanf[o] = true;
@@ -1315,6 +1349,53 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
         c_ready = true;
         w_done = w_here;
+      } else if constexpr (RECOMP) {
+        if (!c_ready) {  // observer 0 was skipped: c[] still holds its parked coordinates
+          for (int i = tid; i < N; i += TB) c[i] = 0.0;
+          c_ready = true;
+        }
+        // The particle again: its pre-evolve record (L2 / Infinity-Cache hot: phase A streamed it), the same noise, the
+        // same step, the same projection as phase A -- the same bits --, and with the evolved height at hand the motion
+        // model's term (tracker.py:143: appended last) and the weight in the same pass.
+        const bool mterm = a.has_dem && motion_term;  // uniform
+        const double zs = m[17];
+        auto rec_of = [&](int i) -> int { return COMMON || uin ? (int)uin[i < N ? i : 0] : (i < N ? i : 0); };
+        int rn = rec_of(tid + TB);
+        double2 nx0, nx1, nx2;
+        {
+          const double2* src = Pin2 + (size_t)rec_of(tid) * rec_stride;
+          nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
+        }
+#pragma unroll 1
+        for (int i = tid; i < N; i += TB) {
+          asm volatile("" ::: "memory");  // (camera / motion constants from LDS every iteration, as in phase A)
+          double x[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
+          {
+            const double2* src = Pin2 + (size_t)rn * rec_stride;
+            nx0 = src[0]; nx1 = src[chunk_stride]; nx2 = src[2 * chunk_stride];
+            rn = rec_of(i + 2 * TB);
+          }
+          double n[3];
+          evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
+          evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
+          double u, v;
+          if constexpr (COMMON)
+            project_simple_fast(s_cam[o], x[0], x[1], x[2], u, v);
+          else
+            project_m<FAST>(s_cam[o], a.cam_flags[o], x[0], x[1], x[2], u, v);
+          double ll = c[i];
+          ll += eval(u, v) * scale;
+          if (mterm) {
+            double t = 0.0;
+            if (zs != 0.0) {
+              const double d = m[16] - x[2];
+              t = (1.0 / (2.0 * (zs * zs))) * (d * d);
+            }
+            ll += t;
+          }
+          c[i] = weight_of<FAST>(ll, tab32);
+        }
+        w_done = true;
       } else if constexpr (NOBS > 1) {
         if (!c_ready) {  // observer 0 was skipped: c[] still holds its parked coordinates
           for (int i = tid; i < N; i += TB) c[i] = 0.0;
@@ -1327,6 +1408,24 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           // operations in the same order as the separate loop below, which then has nothing left to do)
           const bool mterm = a.has_dem && motion_term;  // uniform
           double wn = mterm ? W[tid < N ? tid : 0] : 0.0;
+#if GLH_PT_PREFETCH2
+          // (round 5 experiment: the coordinates and the term of the particle after next are requested as well -- what
+          // the scratch returns comes from memory, a microsecond away under load, and one particle's sampling is less)
+          double2 qn2 = uvp[tid + TB < N ? tid + TB : 0];
+          double wn2 = mterm ? W[tid + TB < N ? tid + TB : 0] : 0.0;
+          for (int i = tid; i < N; i += TB) {
+            const double2 q = qn;
+            const double wi = wn;
+            qn = qn2;
+            wn = wn2;
+            qn2 = uvp[i + 2 * TB < N ? i + 2 * TB : 0];
+            if (mterm) wn2 = W[i + 2 * TB < N ? i + 2 * TB : 0];
+            double ll = c[i];
+            ll += eval(q.x, q.y) * scale;
+            if (mterm) ll += wi;  // (tracker.py:143: appended last)
+            c[i] = weight_of<FAST>(ll, tab32);
+          }
+#else
           for (int i = tid; i < N; i += TB) {
             const double2 q = qn;
             const double wi = wn;
@@ -1337,6 +1436,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
             if (mterm) ll += wi;  // (tracker.py:143: appended last)
             c[i] = weight_of<FAST>(ll, tab32);
           }
+#endif
           w_done = true;
         } else {
           for (int i = tid; i < N; i += TB) {
@@ -1416,7 +1516,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       }
       ws.fh = fl;
       ws.fw = fl + 5 * ho;
-      pt_ssd<TB>(ws, tw, th, wo, ho, park, fl_v);
+      pt_ssd<TB, NOBS == 2>(ws, tw, th, wo, ho, park, fl_v);
       PT_STAMP(3);
       if (inv_lds) {  // (its own call: the inverses' address space stays known)
         ws.ih = invl;
@@ -1585,13 +1685,35 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   if (outside) flag_point(a.pt_status, a.pt_err_frame, pt, GLH_PT_SAMPLE_OUTSIDE, a.frame);
   if (!w_done) {
     const bool mterm = a.has_dem && motion_term;  // uniform
-    double wn = mterm ? W[tid < N ? tid : 0] : 0.0;
-    for (int i = tid; i < N; i += TB) {
-      double ll = c[i];
-      const double wi = wn;
-      if (mterm) wn = W[i + TB < N ? i + TB : 0];
-      if (mterm) ll += wi;  // the motion model's term is appended last (tracker.py:143)
-      c[i] = weight_of<FAST>(ll, tab32);  // the weights stay in LDS until the gather of phase E
+    if (RECOMP && mterm) {
+      // (the last observer was skipped on this frame, so its pass did not append the motion model's term: the evolved
+      // height once more, from the record)
+      const double zs = m[17];
+#pragma unroll 1
+      for (int i = tid; i < N; i += TB) {
+        const double2* src = Pin2 + (size_t)(COMMON || uin ? (int)uin[i] : i) * rec_stride;
+        const double2 v0 = src[0], v1 = src[chunk_stride], v2 = src[2 * chunk_stride];
+        double x[6] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
+        double n[3];
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
+        evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
+        double ll = c[i], t = 0.0;
+        if (zs != 0.0) {
+          const double d = m[16] - x[2];
+          t = (1.0 / (2.0 * (zs * zs))) * (d * d);
+        }
+        ll += t;
+        c[i] = weight_of<FAST>(ll, tab32);
+      }
+    } else {
+      double wn = mterm ? W[tid < N ? tid : 0] : 0.0;
+      for (int i = tid; i < N; i += TB) {
+        double ll = c[i];
+        const double wi = wn;
+        if (mterm) wn = W[i + TB < N ? i + TB : 0];
+        if (mterm) ll += wi;  // the motion model's term is appended last (tracker.py:143)
+        c[i] = weight_of<FAST>(ll, tab32);  // the weights stay in LDS until the gather of phase E
+      }
     }
     __syncthreads();
   }

@@ -83,7 +83,7 @@ static int fail(int code, const char* fmt, ...) {
 // LDS plan of the fused kernel (glh_point.h): c[N] + region 2
 constexpr int PT_LDS_MAX = 152 * 1024;   // dynamic LDS of one workgroup (static <= 5 KB on top, 160 KB per CU)
 constexpr int PT_LDS_HALF = 75 * 1024;   // dynamic LDS that still lets two workgroups share a CU
-constexpr int PT_PATCH_LDS = 3 * 1024;   // static LDS of the raster windows (code 2: glh_point.h, PtPatches), taken off both
+constexpr int PT_PATCH_LDS = 3328;       // static LDS of the raster windows (code 2: glh_point.h, PtPatches), taken off both
 static_assert(PT_PATCH_LDS >= 2 * (int)sizeof(RasterPatch), "the raster windows fit their share");
 
 // ------------------------------------------------------------------------------------------
@@ -152,7 +152,9 @@ struct glh_ctx {
   struct RasterBuf {
     double *z = nullptr, *gx = nullptr, *gy = nullptr;
     RasterDev dev{};
+    std::vector<double> hgx, hgy;  // host copies of the coordinates (same_grid below)
   } rasters[3];  // GLH_RASTER_DEM, _DEM_SIGMA, _VIEWSHED
+  bool same_grid = false;  // the dem and dem_sigma rasters have bit-identical coordinate arrays (Surfaces::same_grid)
   double* covariances = nullptr;  // [max_frames][P][36], allocated on first use
   double* uj = nullptr;           // [P][N] host-fed per-particle uniforms (stratified / choice)
   double* extra_ll = nullptr;     // [P][N] caller-computed log-likelihood term of the next glh_update_weights, or null
@@ -182,6 +184,7 @@ struct glh_ctx {
   hipStream_t extra_streams[3] = {nullptr, nullptr, nullptr};  // streams 2 .. 4 of glh_track
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int last_track_streams = 1;  // streams the last glh_track used
+  int n_cus = 256;             // compute units of the device (hipDeviceProp: glh_create)
   bool capturing = false;      // glh_track is recording its frame loop into a hipGraph (no event timers meanwhile)
   hipGraphExec_t track_graph = nullptr;  // the last captured frame loop (kept until the next one or the context's end)
   int force_tb = 0;            // experiment (GLH_PT_BIG_FRAMES): this launch runs the 1 024-thread instantiation
@@ -389,6 +392,10 @@ extern "C" int glh_create(const glh_config* cfg, glh_ctx** out) {
   glh_ctx* c = new (std::nothrow) glh_ctx();
   if (!c) return fail(GLH_E_NOMEM, "out of host memory");
   c->cfg = k;
+  {
+    int cus = 0;  // (what decides whether a batch is two rounds of workgroups per half: glh_track's two streams)
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, k.device_id) == hipSuccess && cus > 0) c->n_cus = cus;
+  }
   const size_t P = k.max_points, N = k.max_particles, O = k.n_observers;
   c->tile_cap = k.max_tile * k.max_tile;
   c->search_cap = k.max_search_dim * (k.max_search_dim + 16);  // rows padded for the fused kernel
@@ -750,9 +757,9 @@ static int ensure_expanded(glh_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));                                                          \
   } while (0)
 
-// Fast arithmetic (glh_set_math): every kernel has it.  What it changes in the general instantiation (gridded surfaces,
-// the other motion models) is the projection, the sampling, the weights and the resampling; their evolve steps and
-// surface lookups have one form only.
+// Fast arithmetic (glh_set_math): every kernel has it.  In the general instantiation (gridded surfaces, the other motion
+// models) it changes the projection, the sampling, the weights and the resampling, and (round 5) the surface lookups of
+// the evolve step and of the DEM term (glh_math.h: raster_bilinear_fast) and the tangent models' step.
 static bool use_fast(const glh_ctx* c) { return c->fast_math; }
 
 static Surfaces surfaces(const glh_ctx* c) {
@@ -760,6 +767,7 @@ static Surfaces surfaces(const glh_ctx* c) {
   s.dem = c->rasters[GLH_RASTER_DEM].dev;
   s.dem_sigma = c->rasters[GLH_RASTER_DEM_SIGMA].dev;
   s.viewshed = c->rasters[GLH_RASTER_VIEWSHED].dev;
+  s.same_grid = c->same_grid ? 1 : 0;
   return s;
 }
 
@@ -792,6 +800,9 @@ extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, in
   HIPCHK(hipStreamSynchronize(c->stream));
   dfree(r.z); dfree(r.gx); dfree(r.gy);
   r.dev = RasterDev{};
+  r.hgx.clear();
+  r.hgy.clear();
+  c->same_grid = false;
   if (!z) return GLH_OK;
   CHK(check_raster_args(nx, ny, gx, gy, sx, sy));
   CHK(check_raster_uniform(nx, ny, gx, gy, xmin, xmax, ymin, ymax));
@@ -802,6 +813,12 @@ extern "C" int glh_set_raster(glh_ctx* c, int which, const double* z, int nx, in
   HIPCHK(hipMemcpy(r.gx, gx, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(r.gy, gy, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
   r.dev = raster_dev(r.z, r.gx, r.gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax);
+  r.hgx.assign(gx, gx + nx);
+  r.hgy.assign(gy, gy + ny);
+  // a DEM and its uncertainty on ONE grid share the cell and the weights of a sample (raster_sample_pair): only when the
+  // coordinate arrays are the same numbers -- equal limits and sizes alone allow a quarter cell of difference
+  const auto &d0 = c->rasters[GLH_RASTER_DEM], &d1 = c->rasters[GLH_RASTER_DEM_SIGMA];
+  c->same_grid = d0.z && d1.z && d0.hgx == d1.hgx && d0.hgy == d1.hgy;
   return GLH_OK;
 }
 
@@ -1689,7 +1706,7 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
   // -4 %; four ways: worse).  Same kernel, same per-point arithmetic: results are bit for bit those of one stream.
   int r2_bytes = 0;
   const bool fused_ok = c->fused && !c->have_active && !c->keep_sse && !c->have_extra && fused_plan(c, &r2_bytes);
-  const int slots = 256 * (c->N > 10 * PT_BLK ? 1 : 2);  // workgroups the chip holds at once
+  const int slots = c->n_cus * (c->N > 10 * PT_BLK ? 1 : 2);  // workgroups the chip holds at once
   int ns = 1;
   if (fused_ok && !c->track_covariances) {
     if (c->track_streams >= 2) ns = c->track_streams;
@@ -1930,7 +1947,9 @@ extern "C" int glh_set_interpolation(glh_ctx* c, int kx, int ky) {
         total += (int64_t)(2 * k + 1) * n;
       }
       std::vector<double> lu((size_t)total);
-      for (int n = k + 1; n <= maxn; ++n) spline_lu_general(n, k, lu.data() + off[n]);
+      for (int n = k + 1; n <= maxn; ++n)
+        if (!spline_lu_general(n, k, lu.data() + off[n]))
+          return fail(GLH_E_STATE, "spline collocation matrix of size %d, degree %d has support outside its band", n, k);
       CHK(dalloc(&c->glu[q], (size_t)total));
       CHK(dalloc(&c->glu_off[q], (size_t)maxn + 1));
       HIPCHK(hipMemcpy(c->glu[q], lu.data(), (size_t)total * sizeof(double), hipMemcpyHostToDevice));
@@ -2503,8 +2522,8 @@ static int stage_sample_impl(int dev, const float* sse, int ho, int wo, int kx, 
     std::vector<double> z((size_t)ho * wo);
     for (size_t i = 0; i < z.size(); ++i) z[i] = (double)sse[i];
     std::vector<double> fv((size_t)(2 * kx + 1) * ho), fu((size_t)(2 * ky + 1) * wo);
-    spline_lu_general(ho, kx, fv.data());
-    spline_lu_general(wo, ky, fu.data());
+    if (!spline_lu_general(ho, kx, fv.data()) || !spline_lu_general(wo, ky, fu.data()))
+      return fail(GLH_E_STATE, "spline collocation matrix has support outside its band");
     const int maxn = ho > wo ? ho : wo;
     std::vector<int64_t> zero(maxn + 1, 0);
     DevBuf dz, dfv, dfu, doff, dbox, dst, duv, dval, dout;

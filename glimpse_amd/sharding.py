@@ -20,8 +20,8 @@ the same directory instead -- never silently.
     ... track ...
     moments, status = group.gather_moments(ctx, 0, T, sharding.shard_sizes(len(models), group.world))   # rank 0
 
-`init` / `gather_points` below are the same gather for callers that already live inside a torch.distributed
-job (gloo on CPU, nccl = RCCL on GPUs); nothing in the library needs them.
+Callers that already live inside a torch.distributed job and want to issue the collective themselves: `examples/torch_interop.py`
+(a zero-copy view of the library's history buffer, the same gather with gloo / nccl); nothing in this package imports torch.
 """
 import os
 import tempfile
@@ -290,66 +290,3 @@ class Group:
             self._ctx.comm_destroy()
         if self.store is not None:
             self.store.leave()
-
-
-# ---- for callers inside a torch.distributed job --------------------------------------------------
-class DeviceArray:
-    """Zero-copy view of a library-owned device buffer through `__cuda_array_interface__` (torch.as_tensor accepts
-    it): e.g. the moments history of `Context.moments_device()` for a collective the caller issues itself."""
-
-    def __init__(self, ptr, shape, typestr="<f8"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2}
-
-
-def init(backend=None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun) and bind
-    this process to GPU LOCAL_RANK.  Returns (rank, world); (0, 1) without a launcher."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
-        return 0, 1
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kwargs = {}
-        if backend == "nccl":
-            local = int(os.environ.get("LOCAL_RANK", "0"))
-            torch.cuda.set_device(local)
-            kwargs["device_id"] = torch.device("cuda", local)
-        dist.init_process_group(backend, **kwargs)
-    return dist.get_rank(), dist.get_world_size()
-
-
-def gather_points(arrays, n_points, dst=0, group=None):
-    """Gather per-point arrays (leading axis = this rank's points) to rank `dst` with torch.distributed.
-
-    `arrays`: list of ndarrays (host) or torch tensors (host or device) whose first axis has
-    this rank's `shard_range` length.  Returns the list of full arrays (first axis
-    `n_points`, in global point order) on `dst`, None elsewhere.  One collective per array;
-    shards are padded to the largest shard so a plain `gather` is enough (no all-to-all)."""
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return list(arrays)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = shard_sizes(n_points, world)
-    biggest = max(sizes)
-    out = []
-    for a in arrays:
-        t = torch.as_tensor(a) if not isinstance(a, torch.Tensor) else a
-        if t.shape[0] != sizes[rank]:
-            raise ValueError(f"rank {rank}: expected {sizes[rank]} points, got {t.shape[0]}")
-        if t.shape[0] < biggest:
-            pad = torch.zeros((biggest - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            t = torch.cat([t, pad])
-        t = t.contiguous()
-        recv = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, recv, dst=dst, group=group)
-        if rank == dst:
-            full = torch.cat([recv[r][: sizes[r]] for r in range(world)])
-            out.append(full.cpu().numpy() if isinstance(a, np.ndarray) else full)
-    return out if rank == dst else None

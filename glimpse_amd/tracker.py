@@ -95,23 +95,105 @@ def _vector24(img):
     return img.cam.vector24 if hasattr(img, "cam") else img.vector24
 
 
-def _parallel_worker(job):
-    """One worker process of Tracker.track(parallel=N): its own Tracker / context on its GPU, its block of tracks."""
-    tracker = Tracker(job["observers"], viewshed=job["viewshed"], resample_method=job["resample_method"],
-                      highpass=job["highpass"], interpolation=job["interpolation"], device=job["device"],
-                      max_search_dim=job["max_search_dim"])
-    if job["np_seed"] is not None:
-        np.random.seed(int(job["np_seed"]))
-    t = tracker.track(job["models"], _catch_errors=job["catch"], **job["kw"])
-    out = {k: getattr(t, k) for k in ("datetimes", "time_unit", "means", "sigmas", "covariances", "particles", "weights",
-                                      "images")}
-    out["errors"] = list(t.errors)
-    out["warnings"] = list(t.warnings)
-    out["reduced"] = getattr(t, "reduced", None)
-    out["last_particles"], out["last_weights"] = tracker.particles, tracker.weights
-    if tracker._ctx is not None:
-        tracker._ctx.close()
-    return out
+def _usable_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, whichever is smaller."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+class _FrameFeed:
+    """The frames a run touches, on their way to HBM in the order the sequence needs them (image.py:137-214: the
+    reference reads an image when a track first asks for it).  Images that still live in files are decoded by a pool of
+    threads (Pillow releases the GIL; one thread per usable core) WHILE the frame loop runs on the frames already
+    resident: `need(i)` waits for the frames of time steps <= i only, hands them to the device (pinned staging + copy
+    stream: glh_observer_upload_frame_async) together with every later frame that has been decoded meanwhile, and returns
+    the last time step whose frames are all resident -- the frame loop runs up to there in one call.  In-memory images
+    are all uploaded by the first call, as before."""
+
+    def __init__(self, tracker, ctx, matching):
+        self.tracker, self.ctx = tracker, ctx
+        first_use = {}
+        for i in range(len(matching)):
+            for o, m in enumerate(matching[i]):
+                if m is not None and (o, int(m)) not in tracker._uploaded:
+                    first_use.setdefault((o, int(m)), i)
+        self.jobs = sorted(first_use.items(), key=lambda kv: (kv[1], kv[0]))  # [((observer, image), first time step)]
+        self.ntimes = len(matching)
+        self.pos = 0
+        self.pool = None
+        self.futures = None
+        self.stats = tracker._feed_stats = dict(files=0, frames=len(self.jobs), decode_seconds=0.0, upload_seconds=0.0,
+                                                bytes=0, threads=0, waits=0, wait_seconds=0.0)
+        on_disk = [job for job, _ in self.jobs if getattr(tracker.observers[job[0]].images[job[1]], "array", None) is None]
+        self.stats["files"] = len(on_disk)
+        if len(on_disk) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self.stats["threads"] = min(_usable_cores(), len(on_disk))
+            self.pool = ThreadPoolExecutor(max_workers=self.stats["threads"])
+            self.futures = [self.pool.submit(self._pixels, job) for job, _ in self.jobs]
+
+    def _pixels(self, job):
+        import time
+
+        t0 = time.perf_counter()
+        obs = self.tracker.observers[job[0]]
+        a = np.ascontiguousarray(obs.images[job[1]].read(cache=obs.cache))  # (dtype checked by the upload)
+        return a, time.perf_counter() - t0
+
+    def _upload(self, k, wait):
+        import time
+
+        job = self.jobs[k][0]
+        if self.futures is not None:
+            fut = self.futures[k]
+            if not wait and not fut.done():
+                return False
+            if not fut.done():
+                t0 = time.perf_counter()
+                fut.result()
+                self.stats["waits"] += 1
+                self.stats["wait_seconds"] += time.perf_counter() - t0
+            a, dt = fut.result()
+            self.futures[k] = None  # (the pixels are not kept here)
+        else:
+            a, dt = self._pixels(job)
+        self.stats["decode_seconds"] += dt
+        t0 = time.perf_counter()
+        self.ctx.observer_upload_frame_async(job[0], job[1], a)
+        self.stats["upload_seconds"] += time.perf_counter() - t0
+        self.stats["bytes"] += a.nbytes
+        self.tracker._uploaded.add(job)
+        return True
+
+    def need(self, i):
+        """Every frame of time steps <= i is resident (or on its way, ahead of the next launch); returns the last time
+        step for which that holds."""
+        while self.pos < len(self.jobs) and self.jobs[self.pos][1] <= i:
+            self._upload(self.pos, True)
+            self.pos += 1
+        while self.pos < len(self.jobs) and self._upload(self.pos, self.futures is None):
+            self.pos += 1
+        if self.pos >= len(self.jobs):
+            self.close()
+            return self.ntimes - 1
+        return self.jobs[self.pos][1] - 1
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool = None
 
 
 class Tracker:
@@ -159,6 +241,10 @@ class Tracker:
         self.templates = None
         self._ctx = None
         self._ctx_key = None
+        self._feed = None
+        self._feed_stats = None  # decode / upload figures of the last run's frame feed (`_FrameFeed.stats`)
+        self._uploaded = set()
+        self._pool = None  # worker processes of track(parallel=N), kept between calls (glimpse_amd/parallel.py)
 
     # ---- host logic shared with the reference -------------------------------------------
     @property
@@ -260,7 +346,7 @@ class Tracker:
                            max_search_dim=search_dim, max_frames=n_frames)
         try:
             for o, obs in enumerate(self.observers):
-                first = obs.images[0].read()
+                first = obs.images[0].read(cache=obs.cache)  # (an observer that does not cache keeps no pixels)
                 if first.dtype not in (np.uint8, np.uint16, np.float32, np.float64) or \
                         (first.ndim == 3 and first.shape[2] not in (1, 3)):
                     raise NotImplementedError("frames must be uint8, uint16, float32 or float64 with one or three channels "
@@ -281,24 +367,42 @@ class Tracker:
         self._uploaded = set()
         return ctx
 
+    def _frame_dtypes(self):
+        """dtype (and channel count) of every observer's frames, read from its first image once (a read of a file-backed,
+        uncached image decodes the file)."""
+        key = tuple(id(obs.images[0]) for obs in self.observers)
+        if getattr(self, "_dtypes_key", None) != key:
+            firsts = [np.asarray(obs.images[0].read(cache=obs.cache)) for obs in self.observers]
+            self._dtypes = [(a.dtype, 1 if a.ndim == 2 else a.shape[2]) for a in firsts]
+            self._dtypes_key = key
+        return self._dtypes
+
     def _sixteen_bit(self):
         """Some observer's frames are uint16: no kernel takes those beyond 1117-pixel workspaces."""
-        return any(obs.images[0].read().dtype == np.uint16 for obs in self.observers)
+        return any(dt == np.uint16 for dt, _ in self._frame_dtypes())
 
     def _ranked_keys(self):
         """Some observer's frames are uint16 or float: the fused step ranks a tile's pixels and takes those frames
         while the workspaces are at most 255 pixels (the count of a tile's pixels must fit a 16-bit key)."""
-        return any(obs.images[0].read().dtype != np.uint8 for obs in self.observers)
+        return any(dt != np.uint8 for dt, _ in self._frame_dtypes())
 
     def _dim_limit(self, n_points):
         """The largest workspace side the automatic growth may ask for: what the kernels take (2000 pixels; 1117 for
         16-bit frames, glh_observer_set_depth) and what fits a memory budget -- search tile, keys and surface are
-        about 14 dim^2 bytes per point and observer, and half of the device's free memory may go to them."""
+        about 14 dim^2 bytes per point and observer, float frames add the 16 dim^2 bytes of their normalisation workspace
+        (allocated on first use, inside the run), uint16 frames a key histogram of 262 KB per point and channel whatever
+        the side -- and half of the device's free memory may go to all of them."""
         limit = 1117 if self._sixteen_bit() else 2000
         try:
             free, _ = _lib.device_memory(self.device)
-            per = 14.0 * max(1, len(self.observers)) * max(1, n_points)
-            limit = min(limit, int(np.sqrt(0.5 * free / per)))
+            P = max(1, n_points)
+            per, fixed = 0.0, 0.0
+            for dt, channels in self._frame_dtypes():
+                per += (14.0 + (16.0 if dt in (np.float32, np.float64) else 0.0)) * P
+                if dt == np.uint16:
+                    fixed += 4.0 * (65535 * channels + 1) * P
+            budget = 0.5 * free - fixed
+            limit = min(limit, int(np.sqrt(max(budget, 0.0) / max(per, 1.0))))
         except Exception:  # noqa: BLE001  (no device to ask: the kernels' limits alone)
             pass
         return limit
@@ -352,32 +456,13 @@ class Tracker:
         dim = max(tile_size) + 2 * 5.0 * spread + 8
         return self._fit_dim(max(max(tile_size) + 16, dim), self._dim_limit(len(motion_models)))
 
-    def _upload_images(self, ctx, matching):
-        """Frames the run will touch -> HBM, once.  Images that still live in files are decoded by a thread pool
-        (Pillow releases the GIL) while the frames already decoded are on their way to the device
-        (glh_observer_upload_frame_async: pinned staging + copy stream)."""
-        todo = [(o, int(img)) for o, obs in enumerate(self.observers)
-                for img in sorted({m for m in matching[:, o] if m is not None}) if (o, img) not in self._uploaded]
-        if not todo:
-            return
-
-        def pixels(job):
-            o, img = job
-            obs = self.observers[o]
-            return np.ascontiguousarray(obs.images[img].read(cache=obs.cache))  # (dtype checked by the upload)
-
-        on_disk = [j for j in todo if self.observers[j[0]].images[j[1]].array is None]
-        if len(on_disk) > 1:
-            from concurrent.futures import ThreadPoolExecutor
-
-            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(on_disk))) as pool:
-                for job, a in zip(todo, pool.map(pixels, todo)):
-                    ctx.observer_upload_frame_async(job[0], job[1], a)
-                    self._uploaded.add(job)
-        else:
-            for job in todo:
-                ctx.observer_upload_frame_async(job[0], job[1], pixels(job))
-                self._uploaded.add(job)
+    def _frame_feed(self, ctx, matching):
+        """Frames the run will touch -> HBM, once (`_FrameFeed`)."""
+        previous = getattr(self, "_feed", None)
+        if previous is not None:
+            previous.close()  # (a run that ended in an exception: its decoders stop here)
+        self._feed = _FrameFeed(self, ctx, matching)
+        return self._feed
 
     def _upload_surfaces(self, ctx, motion_models):
         """One gridded dem, one dem_sigma (shared by every model of the batch that uses a raster: `_batches` splits the
@@ -463,7 +548,6 @@ class Tracker:
         elif dim is None:
             dim = max(self._estimate_search_dim(motion_models, matching, taus, tile_size), max(31, max(tile_size)) + 16)
         ctx = self._context(ntracks, n, ntimes, tile_size, dim)
-        self._upload_images(ctx, matching)
         outgrown = [False]  # a search tile did not fit the workspaces (this attempt)
         uniform = bool(observer_mask.all()) and bool((first == first[0]).all()) and bool((last == last[0]).all())
 
@@ -480,6 +564,7 @@ class Tracker:
         def run(draws):
             """The frame loop (tracker.py:326-357) for all tracks at once."""
             ctx.begin_sequence(ntracks, n, tile_size)
+            feed = self._frame_feed(ctx, matching)  # (frames from files are decoded while the frames before them are tracked)
             self._upload_surfaces(ctx, motion_models)
             ctx.set_motion(params_table(motion_models))
             ctx.set_observer_mask(None if observer_mask.all() else observer_mask.astype(np.uint8))
@@ -506,7 +591,9 @@ class Tracker:
                         and not (template_indices == i).any())
 
             i = lo
+            deferred = []  # runs of common frames whose status words are read after the loop
             while i <= hi:
+                through = feed.need(i)  # the frames of time steps <= through are resident
                 ctx.set_frame(i)
                 starting = (first == i) & ~empty
                 running = (first < i) & (i <= last)
@@ -515,17 +602,14 @@ class Tracker:
                     set_active(window)
                     if draws is None and not return_particles:
                         # device RNG: the whole run of common frames in one call (glh_track: the launches are
-                        # enqueued back to back, no host round trip per frame); every frame keeps its own status
-                        # words, so the per-frame warnings are read afterwards
+                        # enqueued back to back, no host round trip per frame) -- as far as the frames are resident:
+                        # a sequence read from files is tracked while its later frames are still being decoded.  Every
+                        # frame keeps its own status words, so the per-frame warnings are read afterwards.
                         j = i
-                        while j + 1 <= hi and common(j + 1):
+                        while j + 1 <= min(hi, through) and common(j + 1):
                             j += 1
                         ctx.track(list(range(i, j + 1)), taus[i - 1:j], [images_of(k) for k in range(i, j + 1)], seed=seed)
-                        statuses = ctx.observer_status_frames(i, j - i + 1)
-                        # (one test for the whole run; the per-frame bookkeeping only where something was skipped)
-                        skipped = (statuses == _lib.OBS_OUT_OF_BOUNDS) | (statuses == _lib.OBS_TILE_TOO_LARGE)
-                        for k in np.nonzero(skipped.any(axis=(1, 2)))[0]:
-                            note_skips(running, statuses[k])
+                        deferred.append((i, j))
                         i = j + 1
                         continue
                     if draws is None:
@@ -568,6 +652,13 @@ class Tracker:
                     out_p[window, i] = P_[window]
                     out_w[window, i] = W_[window]
                 i += 1
+            feed.close()
+            for a, b in deferred:
+                statuses = ctx.observer_status_frames(a, b - a + 1)
+                # (one test for the whole run; the per-frame bookkeeping only where something was skipped)
+                skipped = (statuses == _lib.OBS_OUT_OF_BOUNDS) | (statuses == _lib.OBS_TILE_TOO_LARGE)
+                for k in np.nonzero(skipped.any(axis=(1, 2)))[0]:
+                    note_skips(np.ones(ntracks, dtype=bool), statuses[k])  # (a common frame: every track is running)
             return out_p, out_w, ctx.point_status(), ctx.point_error_frame()
 
         state0 = np.random.get_state() if rng == "numpy" else None
@@ -590,7 +681,6 @@ class Tracker:
             except (_lib.GlhError, MemoryError):
                 break
             ctx, dim = bigger, grown
-            self._upload_images(ctx, matching)
 
         means, sigmas = ctx.get_tracks(0, ntimes)  # (P, T, 6) each, laid out on the device
         covariances = None
@@ -674,48 +764,119 @@ class Tracker:
     def _track_parallel(self, workers, motion_models, params, observer_mask=None, rng="numpy", seed=0, point_offset=0,
                         **kw):
         """Tracks are independent (the reference maps `process` over them, tracker.py:381-387): contiguous blocks of
-        tracks go to `workers` freshly started processes, each with its own context on GPU (worker mod device
-        count) and `point_offset` = its first track, so a device-RNG run draws exactly what the single-process run
-        draws.  The results come back in track order.  With rng="numpy" every worker gets its own np.random seed
-        (drawn here from the global stream): like the reference's pool, a parallel run is not stream-compatible
-        with a serial one."""
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
+        tracks go to `workers` PERSISTENT processes (glimpse_amd/parallel.py: started at the first parallel call, one
+        context each on GPU (worker mod device count), reused by later calls), each with `point_offset` = its first
+        track, so a device-RNG run draws exactly what the single-process run draws.  The frames reach the workers once,
+        through shared memory (image.py:209 `sharedmem.copy` in the reference), never through pickles.  The posterior
+        history is collected on worker 0 by ONE RCCL exchange (`glh_gather_moments`) when the workers can make the
+        communicator, through host memory otherwise -- `Tracks.transport` says which.  With rng="numpy" every worker gets
+        its own np.random seed (drawn here from the global stream): like the reference's pool, a parallel run is not
+        stream-compatible with a serial one."""
+        import time
 
-        from . import sharding
+        from . import parallel, sharding
 
+        t_start = time.perf_counter()
         ntracks = len(motion_models)
         ndev = max(1, _lib.device_count())
+        pool = getattr(self, "_pool", None)
+        if pool is None or pool.n != workers or not pool.alive():
+            if pool is not None:
+                pool.close()
+            pool = self._pool = parallel.WorkerPool(workers, [w % ndev for w in range(workers)])
+        shared = pool.share(self.observers)
         mask = None if observer_mask is None else np.asarray(observer_mask, dtype=bool)
         seeds = np.random.randint(0, 2 ** 31 - 1, size=workers) if rng == "numpy" else [None] * workers
+        bounds = [sharding.shard_range(ntracks, workers, w) for w in range(workers)]  # (workers <= ntracks: none empty)
+        sizes = [b - a for a, b in bounds]
+        # one device batch per block (the usual case): the block's history lies in ONE context and can be gathered there;
+        # blocks that run as several batches (ragged particle counts, user-defined models, the serial residual stream)
+        # hand their host results over instead
+        serial = self.resample_method == "residual" and rng == "numpy"
+        gather = not serial and all(_batches(motion_models[a:b]) == [0] and _on_device(motion_models[a])
+                                    for a, b in bounds)
+        settings = dict(viewshed=self.viewshed, resample_method=self.resample_method, highpass=self.highpass,
+                        interpolation=self.interpolation, max_search_dim=self.max_search_dim)
         jobs = []
-        for w in range(workers):
-            a, b = sharding.shard_range(ntracks, workers, w)
-            if a == b:
-                continue
-            jobs.append(dict(observers=self.observers, viewshed=self.viewshed, resample_method=self.resample_method,
-                             highpass=self.highpass, interpolation=self.interpolation, device=w % ndev, max_search_dim=self.max_search_dim, models=motion_models[a:b],
-                             np_seed=seeds[w], catch=ntracks >= 2,
+        for w, (a, b) in enumerate(bounds):
+            jobs.append(dict(tracker=settings, models=motion_models[a:b], np_seed=seeds[w], catch=ntracks >= 2,
+                             gather=gather, sizes=sizes, call=pool.calls, want_last=w == workers - 1,
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
-        with ProcessPoolExecutor(max_workers=len(jobs), mp_context=mp.get_context("spawn")) as pool:
-            parts = list(pool.map(_parallel_worker, jobs))
+        parts = [{k: [parallel._import(x) for x in v] if isinstance(v, list) else parallel._import(v)
+                  for k, v in part.items()} for part in pool.call("track", jobs)]
 
         def cat(name):
             values = [part[name] for part in parts]
             return None if values[0] is None else [row for v in values for row in v]
 
         errors = cat("errors")
+        transport = parts[0]["transport"] if gather else "host"
+        if transport == "rccl":
+            # worker 0 holds every worker's history: (T, sum P, 12) -> means / sigmas (P, T, 6); rows of a failed track
+            # are NaN from the frame where it failed (what the workers' own copies hold from their status words)
+            moments = parts[0]["gathered"]
+            means = np.ascontiguousarray(np.transpose(moments[:, :, 0:6], (1, 0, 2)))
+            sigmas = None if kw.get("return_covariances") else np.ascontiguousarray(np.transpose(moments[:, :, 6:12], (1, 0, 2)))
+            lo = 0
+            for part, n in zip(parts, sizes):
+                for p, e in part.get("nan_from", ()):
+                    means[lo + p, e:] = np.nan
+                    if sigmas is not None:
+                        sigmas[lo + p, e:] = np.nan
+                lo += n
+        else:
+            means, sigmas = cat("means"), cat("sigmas")
+            why = next((part["why_host"] for part in parts if part.get("why_host")), "")
+            if gather:
+                parallel.log.warning("Tracker.track(parallel=%d): no RCCL communicator (%s); the posterior history was "
+                                     "collected through host memory", workers, why or "unavailable")
         if ntracks < 2 and errors[0] is not None:
             raise errors[0]
         self.particles, self.weights = parts[-1]["last_particles"], parts[-1]["last_weights"]
-        tracks = Tracks(datetimes=parts[0]["datetimes"], time_unit=parts[0]["time_unit"], means=cat("means"),
-                        sigmas=cat("sigmas"), covariances=cat("covariances"), particles=cat("particles"),
+        tracks = Tracks(datetimes=parts[0]["datetimes"], time_unit=parts[0]["time_unit"], means=means,
+                        sigmas=sigmas, covariances=cat("covariances"), particles=cat("particles"),
                         weights=cat("weights"), tracker=self, images=parts[0]["images"], params=params, errors=errors,
                         warnings=cat("warnings"))
+        tracks.transport = transport
+        tracks.parallel_info = dict(workers=workers, transport=transport, frames_shared_now=shared,
+                                    shared_frame_bytes=pool.frames.nbytes() if pool.frames else 0,
+                                    contexts_made=[bool(part["context_made"]) for part in parts],
+                                    worker_seconds=[part["seconds"] for part in parts],
+                                    worker_track_seconds=[part["track_seconds"] for part in parts],
+                                    call_seconds=time.perf_counter() - t_start)
         if kw.get("reduce_particles"):
             tracks.reduced = [r for part in parts for r in part["reduced"]]
         return tracks
+
+    def forget_frames(self):
+        """The next run reads and uploads every frame again (the files or arrays behind the images have changed)."""
+        self._uploaded = set()
+
+    def close(self):
+        """Release the device contexts and the worker processes of `track(parallel=N)` (they are kept between calls)."""
+        if getattr(self, "_feed", None) is not None:
+            self._feed.close()
+            self._feed = None
+        pool, self._pool = getattr(self, "_pool", None), None
+        if pool is not None:
+            pool.close()
+        for name in ("_ctx", "_sctx"):
+            ctx = getattr(self, name, None)
+            if ctx is not None:
+                setattr(self, name, None)
+                ctx.close()
+        self._ctx_key = None
+        self._sctx_key = None
+        self._last_state = None
+
+    def __del__(self):
+        try:
+            pool = getattr(self, "_pool", None)
+            if pool is not None:
+                pool.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def _track_runs(self, motion_models, params, observer_mask=None, reduce_particles=None, point_offset=0,
                     serial=False, **kw):

@@ -356,6 +356,8 @@ int glh_profile_enable(glh_ctx* ctx, int on);
 int glh_profile_reset(glh_ctx* ctx);
 int glh_stage_count(void);
 const char* glh_stage_name(int stage);
+/* `launches` counts kernel launches: when glh_track runs a batch on two streams (glh_set_track_streams) a frame update
+ * is TWO launches of the fused step, one per half of the points.                                                  */
 int glh_profile_get(glh_ctx* ctx, double* ms /* [stages] */, int64_t* launches /* [stages] */);
 /* Duration (ms) of every timed launch of `stage` since the last reset, in launch order: up to `cap` values
  * into ms, *n = how many there are (the first frames after the wide prior run longer than the steady state). */

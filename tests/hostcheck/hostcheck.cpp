@@ -208,8 +208,14 @@ int hc_raster_patch(const double* z, int nx, int ny, const double* gx, const dou
   raster_patch_origin(r, cx, cy, p.i0, p.j0, p.w, p.h);
   for (int j = 0; j < p.h; ++j)
     for (int i = 0; i < p.w; ++i) p.z[j * GLH_PATCH_W + i] = raster_node(r, p.i0 + i, p.j0 + j);
-  for (int i = 0; i < p.w; ++i) p.gx[i] = gx[p.i0 + i];
-  for (int j = 0; j < p.h; ++j) p.gy[j] = gy[p.j0 + j];
+  for (int i = 0; i < p.w; ++i) p.ax[2 * i] = gx[p.i0 + i], p.ax[2 * i + 1] = 0.0;
+  for (int j = 0; j < p.h; ++j) p.ay[2 * j] = gy[p.j0 + j], p.ay[2 * j + 1] = 0.0;
+  for (int i = 0; i + 1 < p.w; ++i) p.ax[2 * i + 1] = rcp_nr(p.ax[2 * i + 2] - p.ax[2 * i]);
+  for (int j = 0; j + 1 < p.h; ++j) p.ay[2 * j + 1] = rcp_nr(p.ay[2 * j + 2] - p.ay[2 * j]);
+  p.fkx = r.kx;
+  p.fky = r.ky;
+  p.full = p.w == GLH_PATCH_W && p.h == GLH_PATCH_W;
+  p.pair = p.full;
   // (count the hits by poisoning the raster itself: a sample that still reads it differs)
   int hits = 0;
   std::vector<double> poison((size_t)nx * ny, 1e300);
@@ -223,10 +229,36 @@ int hc_raster_patch(const double* z, int nx, int ny, const double* gx, const dou
     if (!o3 && vp == values[2 * i + 1]) ++hits;
     // the pair form (one cell, one set of weights for two rasters on one grid): the same raster twice
     double a = 0.0, b = 0.0;
-    if (raster_sample_pair(r, r, &p, &p, xy[2 * i], xy[2 * i + 1], a, b) && (a != values[2 * i] || b != values[2 * i]))
+    if (raster_sample_pair(r, r, true, &p, &p, xy[2 * i], xy[2 * i + 1], a, b) && (a != values[2 * i] || b != values[2 * i]))
       values[2 * i + 1] = -1e300;
   }
   return hits;
+}
+// the fast-arithmetic form of the same samples (raster_bilinear_fast): without and with the window, [m][2]; and the pair form
+void hc_raster_patch_fast(const double* z, int nx, int ny, const double* gx, const double* gy, int sx, int sy, double xmin,
+                          double xmax, double ymin, double ymax, double cx, double cy, const double* xy, int m, double* values) {
+  const RasterDev r = raster_dev(z, gx, gy, nx, ny, sx, sy, xmin, xmax, ymin, ymax);
+  RasterPatch p;
+  raster_patch_origin(r, cx, cy, p.i0, p.j0, p.w, p.h);
+  for (int j = 0; j < p.h; ++j)
+    for (int i = 0; i < p.w; ++i) p.z[j * GLH_PATCH_W + i] = raster_node(r, p.i0 + i, p.j0 + j);
+  for (int i = 0; i < p.w; ++i) p.ax[2 * i] = gx[p.i0 + i], p.ax[2 * i + 1] = 0.0;
+  for (int j = 0; j < p.h; ++j) p.ay[2 * j] = gy[p.j0 + j], p.ay[2 * j + 1] = 0.0;
+  for (int i = 0; i + 1 < p.w; ++i) p.ax[2 * i + 1] = rcp_nr(p.ax[2 * i + 2] - p.ax[2 * i]);
+  for (int j = 0; j + 1 < p.h; ++j) p.ay[2 * j + 1] = rcp_nr(p.ay[2 * j + 2] - p.ay[2 * j]);
+  p.fkx = r.kx;
+  p.fky = r.ky;
+  p.full = p.w == GLH_PATCH_W && p.h == GLH_PATCH_W;
+  p.pair = p.full;
+  for (int i = 0; i < m; ++i) {
+    bool o1 = false, o2 = false;
+    values[2 * i] = raster_sample<true>(r, xy[2 * i], xy[2 * i + 1], 1, &o1);
+    values[2 * i + 1] = raster_sample<true>(r, xy[2 * i], xy[2 * i + 1], 1, &o2, &p);
+    double a = 0.0, b = 0.0;
+    if (raster_sample_pair<true>(r, r, true, &p, &p, xy[2 * i], xy[2 * i + 1], a, b) &&
+        (a != values[2 * i + 1] || b != values[2 * i + 1]))
+      values[2 * i + 1] = -1e300;
+  }
 }
 int hc_raster_uniform(const double* g, int n, double lo, double hi) { return raster_coordinates_uniform(g, n, lo, hi) ? 1 : 0; }
 }

@@ -496,6 +496,32 @@ def test_tracking_from_image_files_equals_tracking_from_arrays(golden, tmp_path)
     np.testing.assert_array_equal(from_files.means, from_arrays.means)
     np.testing.assert_array_equal(from_files.sigmas, from_arrays.sigmas)
     assert (observers[0].images[1].array is None) and (observers[1].images[1].array is not None)
+    # Device RNG: the frame loop (glh_track) runs on the frames already resident while the later files are still being
+    # decoded (tracker.py: _FrameFeed) -- the sequence goes to the device in several calls, the status words of every
+    # frame are read afterwards; same tracks as from arrays, again after the frames were forgotten.
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = glimpse_amd.Tracker(observers_from(g), max_search_dim=128).track(models_from(g), tile_size=tile, rng="philox", seed=3)
+        for obs in observers:
+            obs.cache = False
+            for img in obs.images:
+                img.array = None
+        tracker = glimpse_amd.Tracker(observers, max_search_dim=128)
+        got = tracker.track(models_from(g), tile_size=tile, rng="philox", seed=3)
+        stats = dict(tracker._feed_stats)
+        assert stats["files"] == stats["frames"] == sum(len(obs.images) for obs in observers) and stats["threads"] >= 1
+        assert stats["bytes"] == sum(img.read(cache=False).nbytes for obs in observers for img in obs.images)
+        np.testing.assert_array_equal(got.means, ref.means)
+        np.testing.assert_array_equal(got.sigmas, ref.sigmas)
+        assert [type(e) for e in got.errors] == [type(e) for e in ref.errors]
+        resident = tracker.track(models_from(g), tile_size=tile, rng="philox", seed=3)  # nothing is read again
+        assert tracker._feed_stats["frames"] == 0
+        tracker.forget_frames()
+        again = tracker.track(models_from(g), tile_size=tile, rng="philox", seed=3)
+        assert tracker._feed_stats["files"] == stats["files"]
+        for t in (resident, again):
+            np.testing.assert_array_equal(t.means, ref.means)
+        tracker.close()
 
 
 def test_ragged_particle_counts_reproduce_reference(golden):
@@ -526,9 +552,14 @@ def test_ragged_particle_counts_reproduce_reference(golden):
 
 
 def test_parallel_workers_reproduce_the_single_process_run(golden):
-    """Tracker.track(parallel=N) (tracker.py:236, :381-387): N worker processes, each with its own context and its
-    contiguous block of tracks.  The device RNG is keyed on the global track index, so the parallel run IS the
-    single-process run, value for value; warnings, errors and the NaN rows of a failing track come back in order."""
+    """Tracker.track(parallel=N) (tracker.py:236, :381-387; glimpse_amd/parallel.py): N PERSISTENT worker processes, each
+    with its own context and its contiguous block of tracks, the frames shared with them once through shared memory.  The
+    device RNG is keyed on the global track index, so the parallel run IS the single-process run, value for value;
+    warnings, errors and the NaN rows of a failing track come back in order.  A second call finds the workers, their
+    contexts and their uploaded frames in place.  (Several workers on ONE GPU cannot make an RCCL communicator: the
+    history then comes through host memory, and the result says so.)"""
+    import time
+
     g = golden("g8_c2mini.npz")
     tile = tuple(int(v) for v in g["tile_size"])
     models = models_from(g)  # the 4th starts outside the image
@@ -537,8 +568,10 @@ def test_parallel_workers_reproduce_the_single_process_run(golden):
         warnings.simplefilter("ignore")
         serial = tracker.track(models, tile_size=tile, rng="philox", seed=5)
         last_p, last_w = tracker.particles.copy(), tracker.weights.copy()
-        for n in (2, 3):
+        for n in (2, 4):
+            t0 = time.perf_counter()
             par = tracker.track(models, tile_size=tile, rng="philox", seed=5, parallel=n)
+            first_call = time.perf_counter() - t0
             np.testing.assert_array_equal(par.means, serial.means)
             np.testing.assert_array_equal(par.sigmas, serial.sigmas)
             assert [type(e) for e in par.errors] == [type(e) for e in serial.errors]
@@ -546,10 +579,37 @@ def test_parallel_workers_reproduce_the_single_process_run(golden):
             assert par.params["parallel"] == n and par.means.shape == serial.means.shape
             np.testing.assert_array_equal(tracker.particles, last_p)
             np.testing.assert_array_equal(tracker.weights, last_w)
+            info = par.parallel_info
+            assert par.transport in ("rccl", "host") and info["workers"] == n and info["frames_shared_now"]
+            assert all(info["contexts_made"])
+            pids = [p.pid for p in tracker._pool.procs]
+            # again: the same processes, no context is made, no frame is shared or uploaded again
+            t0 = time.perf_counter()
+            again = tracker.track(models, tile_size=tile, rng="philox", seed=5, parallel=n)
+            second_call = time.perf_counter() - t0
+            np.testing.assert_array_equal(again.means, serial.means)
+            np.testing.assert_array_equal(again.sigmas, serial.sigmas)
+            assert [p.pid for p in tracker._pool.procs] == pids
+            assert not any(again.parallel_info["contexts_made"]) and not again.parallel_info["frames_shared_now"]
+            assert second_call < first_call, (first_call, second_call)
+        # covariances and particles are per-worker host downloads, in track order
+        cov = tracker.track(models[:3], tile_size=tile, rng="philox", seed=5, parallel=2, return_covariances=True,
+                            return_particles=True)
+        ref = tracker.track(models[:3], tile_size=tile, rng="philox", seed=5, return_covariances=True,
+                            return_particles=True)
+        np.testing.assert_array_equal(cov.means, ref.means)
+        np.testing.assert_array_equal(cov.covariances, ref.covariances)
+        np.testing.assert_array_equal(cov.particles, ref.particles)
+        np.testing.assert_array_equal(cov.weights, ref.weights)
+        assert cov.sigmas is None
         # host-fed draws: each worker consumes its own np.random stream -- a valid filter run, not the serial stream
         np.random.seed(3)
-        par = tracker.track(models[:3], tile_size=tile, parallel=True)  # True = one worker per GPU (here: one)
+        par = tracker.track(models[:3], tile_size=tile, parallel=2)
         assert np.isfinite(par.means).all() and abs(np.median(par.means[:, -1, 3]) - 0.15) < 0.05
+        par = tracker.track(models[:3], tile_size=tile, parallel=True)  # True = one worker per GPU (here: one: this process)
+        assert np.isfinite(par.means).all()
+    tracker.close()
+    assert tracker._pool is None
     assert glimpse_amd.Tracker._parse_parallel(False, 10) == 0 and glimpse_amd.Tracker._parse_parallel(8, 3) == 3
 
 

@@ -1,4 +1,5 @@
-"""Zero-copy hand-off of the library-owned moments history to torch (for callers that issue their own collective).
+"""Zero-copy hand-off of the library-owned moments history to torch (for callers that issue their own collective:
+examples/torch_interop.py -- the product package itself never imports torch).
 
 Runs in a fresh interpreter: torch bundles its own HIP runtime and must be imported BEFORE
 libglimpse_hip.so is loaded (a torch job would have done exactly that); inside the shared pytest process
@@ -16,9 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = r"""
 import sys
 sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/examples")
 import torch                      # first: see the module docstring
 import numpy as np
-from glimpse_amd import _lib, sharding, workloads
+import torch_interop
+from glimpse_amd import _lib, workloads
 
 T, P, N = 3, 4, 600
 wl = workloads.Workload("C2", n_frames=T, n_points=P, n_particles=N, imgsz=(640, 640))
@@ -34,7 +37,7 @@ with _lib.Context(P, N, 1, max_search_dim=160, max_frames=T) as ctx:
     ctx.sync()
     ptr, nbytes = ctx.moments_device()
     assert nbytes == T * P * 12 * 8
-    view = torch.as_tensor(sharding.DeviceArray(ptr, (T, P, 12)), device="cuda:0")
+    view = torch.as_tensor(torch_interop.DeviceArray(ptr, (T, P, 12)), device="cuda:0")
     assert view.dtype == torch.float64 and view.data_ptr() == ptr and view.is_contiguous()
     want = ctx.get_moments(0, T)
     np.testing.assert_array_equal(view.cpu().numpy(), want)

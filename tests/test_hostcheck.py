@@ -298,3 +298,11 @@ def test_raster_window_serves_the_same_samples(hc):
             np.testing.assert_array_equal(vals[:, 0], vals[:, 1])
             assert np.isfinite(vals).all()
             assert hits >= (300 if min(nx, ny) >= 12 else len(xy) if max(nx, ny) <= 12 else 1), hits
+            # fast arithmetic (raster_bilinear_fast: reciprocal interval widths, three fused multiply-adds): the window
+            # serves the raster's own fast samples bit for bit, and both stay within rounding of the exact form
+            fast = np.empty((len(xy), 2))
+            hc.hc_raster_patch_fast(p(z), nx, ny, p(gx), p(gy), sx, sy, C.c_double(xlim[0]), C.c_double(xlim[1]),
+                                    C.c_double(ylim[0]), C.c_double(ylim[1]), C.c_double(cx), C.c_double(cy), p(xy),
+                                    len(xy), p(fast))
+            np.testing.assert_array_equal(fast[:, 0], fast[:, 1])
+            np.testing.assert_allclose(fast[:, 0], vals[:, 0], rtol=0, atol=1e-14 * np.abs(z).max())

@@ -1,0 +1,105 @@
+"""The worker pool of `Tracker.track(parallel=N)` (glimpse_amd/parallel.py) without a GPU: persistent processes, the
+observers' frames shared once through shared memory -- never pickled --, large reply arrays through shared memory, a dying
+worker takes the call down instead of hanging it.  (The tracking itself on the workers: tests/test_gpu_api.py.)"""
+import datetime
+import multiprocessing.connection as mpc
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import glimpse_amd
+from glimpse_amd import parallel
+
+T0 = datetime.datetime(2021, 6, 1)
+DAY = datetime.timedelta(days=1)
+
+
+def _observers(rng, n=3, size=(320, 256)):
+    cam = glimpse_amd.Camera(imgsz=size, f=(400, 400), xyz=(0, 0, 50), viewdir=(0, -90, 0))
+    gray = [glimpse_amd.Image("mem", cam=cam, datetime=T0 + k * DAY, array=rng.integers(0, 255, size[::-1], dtype=np.uint8))
+            for k in range(n)]
+    rgb = [glimpse_amd.Image("mem", cam=cam, datetime=T0 + k * DAY,
+                             array=rng.integers(0, 255, size[::-1] + (3,), dtype=np.uint8)) for k in range(n)]
+    return [glimpse_amd.Observer(gray, sigma=0.3), glimpse_amd.Observer(rgb, sigma=0.5)]
+
+
+@pytest.fixture
+def pickled(monkeypatch):
+    """Sizes of everything this process sends through multiprocessing pipes."""
+    sizes = []
+    original = mpc._ForkingPickler.dumps.__func__
+
+    def dumps(cls, obj, protocol=None):
+        data = original(cls, obj, protocol)
+        sizes.append(len(data))
+        return data
+
+    monkeypatch.setattr(mpc._ForkingPickler, "dumps", classmethod(dumps))
+    return sizes
+
+
+def test_frames_reach_the_workers_through_shared_memory_only(pickled):
+    rng = np.random.default_rng(0)
+    observers = _observers(rng)
+    frame_bytes = sum(img.array.nbytes for obs in observers for img in obs.images)
+    pool = parallel.WorkerPool(2, [0, 0])
+    try:
+        assert pool.share(observers) is True
+        assert pool.frames.nbytes() >= frame_bytes
+        want = [[zlib.crc32(img.array.tobytes()) for img in obs.images] for obs in observers]
+        for digest in pool.call("digest", [None, None]):
+            assert [d[2] for d in digest] == want
+            assert digest[0][0] == (256, 320) and digest[1][0] == (256, 320, 3) and digest[0][1] == "uint8"
+        # what crossed the pipes: the image objects without their pixels, twice -- a small fraction of one frame
+        assert sum(pickled) < 0.05 * frame_bytes, (sum(pickled), frame_bytes)
+        assert max(pickled) < observers[0].images[0].array.nbytes
+        # the same observers again: nothing is sent; the workers are the same processes
+        pids = [p.pid for p in pool.procs]
+        sent = len(pickled)
+        assert pool.share(observers) is False and len(pickled) == sent
+        assert [p.pid for p in pool.procs] == pids and pool.alive()
+        # another pixel array on one image: shared again, the workers see the new pixels
+        observers[0].images[1].array = rng.integers(0, 255, (256, 320), dtype=np.uint8)
+        assert pool.share(observers) is True
+        digest = pool.call("digest", [None, None])[1]
+        assert digest[0][2][1] == zlib.crc32(observers[0].images[1].array.tobytes())
+        # the caller's images keep their own arrays (the workers got copies of the objects without pixels)
+        assert all(img.array is not None and img.array.flags.writeable for obs in observers for img in obs.images)
+    finally:
+        blocks = [b.name for b in pool.frames.blocks] if pool.frames else []
+        pool.close()
+    assert not pool.alive()
+    for name in blocks:  # the blocks are gone with the pool
+        assert not os.path.exists("/dev/shm/" + name.lstrip("/"))
+
+
+def test_large_arrays_of_a_reply_travel_through_shared_memory():
+    a = np.arange(100000, dtype=np.float64).reshape(100, 1000)
+    handle = parallel._export(a)
+    assert isinstance(handle, tuple) and handle[0] == "__shm__"
+    back = parallel._import(handle)
+    np.testing.assert_array_equal(back, a)
+    assert not os.path.exists("/dev/shm/" + handle[1].lstrip("/"))  # unlinked by the receiver
+    small = np.arange(10.0)
+    assert parallel._export(small) is small and parallel._import(small) is small
+    assert parallel._import(None) is None
+
+
+def test_a_failing_worker_takes_the_call_down(monkeypatch):
+    pool = parallel.WorkerPool(2, [0, 0])
+    try:
+        with pytest.raises(RuntimeError, match="worker [01] raised KeyError"):
+            pool.call("no such handler", [None, None])
+        assert not pool.alive()  # the pool is closed: the next parallel call starts a new one
+    finally:
+        pool.close()
+    pool = parallel.WorkerPool(2, [0, 0])
+    try:
+        pool.procs[1].terminate()
+        pool.procs[1].join(10)
+        with pytest.raises(RuntimeError, match="worker 1 (died|closed its pipe)"):
+            pool.call("digest", [None, None], timeout=30)
+    finally:
+        pool.close()

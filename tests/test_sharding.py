@@ -1,4 +1,5 @@
-"""Multi-GPU path on CPU: point sharding + the one end-of-sequence gather, world_size 2, gloo."""
+"""Multi-GPU path on CPU: point sharding, the torch-free group (FileStore + host transport, world_size 2), the launcher,
+and the example of a caller-issued gather inside a torch.distributed job (examples/torch_interop.py, gloo)."""
 import os
 import socket
 import subprocess
@@ -31,15 +32,17 @@ WORKER = r"""
 import os, sys
 import numpy as np
 sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/examples")
+import torch_interop
 from glimpse_amd import sharding
-rank, world = sharding.init(backend="gloo")
+rank, world = torch_interop.init(backend="gloo")
 assert world == 2
 P, T = 7, 5                                  # ragged: 4 + 3 points
 lo, hi = sharding.shard_range(P, world, rank)
 full_means = np.arange(P * T * 6, dtype=float).reshape(P, T, 6)
 full_sig = -full_means
 status = np.arange(P, dtype=np.int64) % 3
-got = sharding.gather_points([full_means[lo:hi], full_sig[lo:hi], status[lo:hi]], P)
+got = torch_interop.gather_points([full_means[lo:hi], full_sig[lo:hi], status[lo:hi]], P)
 if rank == 0:
     assert np.array_equal(got[0], full_means) and np.array_equal(got[1], full_sig)
     assert np.array_equal(got[2], status)
