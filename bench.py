@@ -600,6 +600,7 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
             "workers": 2, "devices": min(2, max(1, _device_count())), "transport": par.transport,
             "first_call_seconds": cold, "call_seconds": warm, "ms_per_step": 1e3 * warm / (n_frames - 1),
             "worker_track_seconds": info["worker_track_seconds"], "worker_seconds": info["worker_seconds"],
+            "parent_seconds": info["parent_seconds"],
             "overhead_seconds_per_call": warm - max(info["worker_track_seconds"]),
             "single_process_call_seconds": wall, "contexts_made_in_warm_call": int(sum(info["contexts_made"])),
             "shared_frame_bytes": info["shared_frame_bytes"],
@@ -618,8 +619,9 @@ def from_files_leg(wl, frames, n_frames, seed, device, fmt, compute_only_seconds
     """C3 as a run FROM IMAGE FILES (image.py:137-214): the frames are written to a directory as `fmt`
     ("jpeg": quality 95, what a time-lapse camera leaves; "tiff": uncompressed) -- untimed --, then
     Tracker.track(rng="philox") runs from glimpse_amd.Image(path=...) objects that hold no pixels: a pool of threads
-    decodes them (Pillow, one thread per usable core) while the frame loop runs on the frames already resident (pinned
-    staging ring + copy stream, glh_observer_upload_frame_async).  Timed: the whole call on a Tracker whose context
+    of decoder PROCESSES (glimpse_amd/ingest.py: Pillow, one per usable core but one) fills a shared-memory ring that is
+    page-locked for the device, and the frame loop runs on the frames already resident while the later ones are decoded
+    and copied (glh_observer_upload_frame_pinned on the copy stream).  Timed: the whole call on a Tracker whose context
     exists (a first call made it) and whose frames were forgotten (`forget_frames`), the median of three.  Checked: the
     tracks equal, bit for bit, those of the same pixels handed over as arrays."""
     import datetime
@@ -685,8 +687,10 @@ def from_files_leg(wl, frames, n_frames, seed, device, fmt, compute_only_seconds
             "workload": wl.describe()["workload"], "format": fmt, "files": st["files"], "file_MB": file_bytes / 1e6,
             "decoded_MB": st["bytes"] / 1e6, "call_seconds": wall, "call_seconds_min_max": [runs[0][0], runs[-1][0]],
             "first_call_seconds": cold, "frames_per_s": n_frames / wall, "ms_per_frame": 1e3 * wall / (n_frames - 1),
-            "decode_threads": st["threads"], "decode_ms_per_frame_per_core": 1e3 * st["decode_seconds"] / max(1, st["files"]),
-            "decode_bound_seconds": st["decode_seconds"] / max(1, st["threads"]),
+            "decode_threads": st["threads"], "decode_processes": st.get("processes", 0),
+            "pinned_ring": st.get("pinned_ring", False),
+            "decode_ms_per_frame_per_core": 1e3 * st["decode_seconds"] / max(1, st["files"]),
+            "decode_bound_seconds": st["decode_seconds"] / max(1, st["threads"] + st.get("processes", 0)),
             "upload_staging_seconds": st["upload_seconds"],
             "upload_staging_GBps": st["bytes"] / max(st["upload_seconds"], 1e-9) / 1e9,
             "frame_loop_waited_for_decoders_seconds": st["wait_seconds"],

@@ -66,6 +66,10 @@ SIGNATURES = {
     "glh_observer_set_depth": (_I, [_P, _I, _I]),
     "glh_observer_upload_frame": (_I, [_P, _I, _I, _P]),
     "glh_observer_upload_frame_async": (_I, [_P, _I, _I, _P]),
+    "glh_host_register": (_I, [_P, _U64]),
+    "glh_host_unregister": (_I, [_P]),
+    "glh_observer_upload_frame_pinned": (_I, [_P, _I, _I, _P, _P]),
+    "glh_upload_done": (_I, [_P, C.c_int64, _I, _P]),
     "glh_observer_set_frame_device": (_I, [_P, _I, _I, _P]),
     "glh_begin_sequence": (_I, [_P, _I, _I, _I, _I]),
     "glh_set_motion_cartesian": (_I, [_P, _P]),
@@ -186,6 +190,16 @@ def _arr(a, dtype, shape=None):
     return a
 
 
+def host_register(address, nbytes):
+    """Page-lock `nbytes` of host memory at `address` for the device (hipHostRegister): uploads from it need no staging
+    copy (Context.observer_upload_frame_pinned)."""
+    check(load().glh_host_register(C.c_void_p(int(address)), int(nbytes)))
+
+
+def host_unregister(address):
+    check(load().glh_host_unregister(C.c_void_p(int(address))))
+
+
 def device_count():
     n = C.c_int(0)
     check(load().glh_device_count(C.byref(n)))
@@ -286,6 +300,19 @@ class Context:
         """Upload without waiting for the device; `pixels` may be reused as soon as the call returns."""
         pixels = self._frame(obs, pixels)
         check(self.lib.glh_observer_upload_frame_async(self.handle, obs, image, _ptr(pixels)))
+
+    def observer_upload_frame_pinned(self, obs, image, pixels):
+        """Upload straight from REGISTERED host memory (`host_register`): no staging copy.  Returns the ticket of the copy;
+        `pixels` must stay untouched until `upload_done(ticket)`."""
+        pixels = self._frame(obs, pixels)
+        ticket = C.c_int64(0)
+        check(self.lib.glh_observer_upload_frame_pinned(self.handle, obs, image, _ptr(pixels), C.byref(ticket)))
+        return ticket.value
+
+    def upload_done(self, ticket, wait=False):
+        done = C.c_int(0)
+        check(self.lib.glh_upload_done(self.handle, int(ticket), 1 if wait else 0, C.byref(done)))
+        return bool(done.value)
 
     def observer_set_frame_device(self, obs, image, dev_ptr, owner=None):
         if owner is not None:

@@ -37,6 +37,11 @@ namespace glh {
 #ifndef GLH_PT_PREFETCH2
 #define GLH_PT_PREFETCH2 0
 #endif
+// Tangent models over rasters: phase A parks every particle's evolved height for the gather's re-evolution (1) or the
+// gather samples the surface again (0: an experiment of round 5, now that a sample from the window is ~45 instructions).
+#ifndef GLH_PT_ZPARK
+#define GLH_PT_ZPARK 1
+#endif
 
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
@@ -1022,8 +1027,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     if constexpr (SURF) {
       bool oob = false;  // (flagged by phase A, which evolved the same particle)
       if (GRID && tangent_pt) {
+#if GLH_PT_ZPARK
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, false);
         evolve_particle<FAST, GRID, true>(x, m, n, tau, tau2, a.surf, &oob, nullptr, z_parked);
+#else
+        evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, true);
+        evolve_particle<FAST, GRID, false>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
+#endif
       } else {
         // (with rasters the tangent models took the branch above, and the other models' step reads no surface: the copy
         // without raster code serves -- the gather of the raster instantiations carries no sampler at all)
@@ -1103,7 +1113,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
-        if (GRID && tangent_pt) ZP[i] = x[2];  // (for the gather's re-evolution: evolve_loaded)
+        if (GLH_PT_ZPARK && GRID && tangent_pt) ZP[i] = x[2];  // (for the gather's re-evolution: evolve_loaded)
         if (a.has_dem && motion_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
@@ -2030,7 +2040,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       cnt[g] = (int)(sc_n[g] >> 16);
       const double2* src = Pin2 + (size_t)rec_n[g] * rec_stride;
       v[g][0] = src[0]; v[g][1] = src[chunk_stride]; v[g][2] = src[2 * chunk_stride];
-      zp[g] = GRID && tangent_pt ? ZP[lo[g]] : 0.0;
+      zp[g] = GLH_PT_ZPARK && GRID && tangent_pt ? ZP[lo[g]] : 0.0;
     }
     fetch_next(h0 + GU * TB);  // (beyond U: slot 0 of the tables, a valid address; never used)
     // the records are evolved, stored and summed ONE AFTER ANOTHER (compiler barrier): only the loads overlap, the

@@ -132,6 +132,10 @@ struct glh_ctx {
   hipEvent_t stage_done[NSTAGE] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_busy[NSTAGE] = {false, false, false, false};
   int stage_next = 0;
+  // uploads from caller-registered host memory (glh_observer_upload_frame_pinned): ticket t has event pin_ev[t % NPIN]
+  static constexpr int NPIN = 64;
+  hipEvent_t pin_ev[NPIN] = {nullptr};
+  int64_t pin_next = 0, pin_completed = 0;  // tickets handed out; every ticket below pin_completed has finished
   hipEvent_t upload_done = nullptr;  // recorded on copy_stream after the latest upload
   bool uploads_pending = false;      // the compute stream has not yet been ordered after upload_done
   int P = 0, N = 0, tw = 0, th = 0, NB = 0;
@@ -322,6 +326,9 @@ extern "C" int glh_destroy(glh_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)glh_comm_destroy(c);
   if (c->track_graph) (void)hipGraphExecDestroy(c->track_graph);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  for (auto e : c->pin_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : c->pending) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -639,6 +646,68 @@ extern "C" int glh_observer_upload_frame_async(glh_ctx* c, int o, int image, con
   c->stage_busy[k] = true;
   c->uploads_pending = true;
   ob.frames[image] = ob.owned[image];
+  return GLH_OK;
+}
+
+extern "C" int glh_host_register(void* ptr, uint64_t bytes) {
+  if (!ptr || bytes == 0) return fail(GLH_E_INVALID, "null buffer");
+  HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable));  // (for every device of the process)
+  return GLH_OK;
+}
+
+extern "C" int glh_host_unregister(void* ptr) {
+  if (!ptr) return fail(GLH_E_INVALID, "null buffer");
+  HIPCHK(hipHostUnregister(ptr));
+  return GLH_OK;
+}
+
+// advance pin_completed over every ticket whose event has passed (in order: the copy stream runs them in order)
+static int pin_poll(glh_ctx* c, int64_t wait_for) {
+  while (c->pin_completed < c->pin_next) {
+    hipEvent_t e = c->pin_ev[c->pin_completed % glh_ctx::NPIN];
+    if (c->pin_completed <= wait_for) {
+      HIPCHK(hipEventSynchronize(e));
+    } else {
+      const hipError_t q = hipEventQuery(e);
+      if (q == hipErrorNotReady) break;
+      HIPCHK(q);
+    }
+    ++c->pin_completed;
+  }
+  return GLH_OK;
+}
+
+extern "C" int glh_observer_upload_frame_pinned(glh_ctx* c, int o, int image, const uint8_t* pixels, int64_t* ticket) {
+  CHK(check_obs(c, o));
+  Observer& ob = c->obs[o];
+  if (!pixels || !ticket || image < 0 || image >= ob.n_images) return fail(GLH_E_INVALID, "bad frame index %d", image);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  const size_t bytes = ob.frame_bytes();
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming));
+  }
+  const int64_t t = c->pin_next;
+  if (t - c->pin_completed >= glh_ctx::NPIN) CHK(pin_poll(c, t - glh_ctx::NPIN));  // (its event is about to be reused)
+  hipEvent_t& e = c->pin_ev[t % glh_ctx::NPIN];
+  if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!ob.owned[image]) CHK(dalloc(&ob.owned[image], bytes));
+  HIPCHK(hipMemcpyAsync(ob.owned[image], pixels, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(hipEventRecord(e, c->copy_stream));
+  HIPCHK(hipEventRecord(c->upload_done, c->copy_stream));
+  c->pin_next = t + 1;
+  c->uploads_pending = true;
+  ob.frames[image] = ob.owned[image];
+  *ticket = t;
+  return GLH_OK;
+}
+
+extern "C" int glh_upload_done(glh_ctx* c, int64_t ticket, int wait, int* done) {
+  if (!c || !done) return fail(GLH_E_INVALID, "null argument");
+  if (ticket < 0 || ticket >= c->pin_next) return fail(GLH_E_INVALID, "unknown upload ticket %lld", (long long)ticket);
+  HIPCHK(hipSetDevice(c->cfg.device_id));
+  CHK(pin_poll(c, wait ? ticket : -1));
+  *done = ticket < c->pin_completed ? 1 : 0;
   return GLH_OK;
 }
 

@@ -20,6 +20,7 @@ import atexit
 import copy
 import logging
 import multiprocessing as mp
+import multiprocessing.connection as mpc
 import os
 import traceback
 import weakref
@@ -43,9 +44,8 @@ def _export(a):
     shm = shared_memory.SharedMemory(create=True, size=a.nbytes)
     np.ndarray(a.shape, a.dtype, buffer=shm.buf)[...] = a
     handle = ("__shm__", shm.name, a.shape, a.dtype.str)
-    shm.close()
-    _forget(shm)
-    return handle
+    shm.close()  # (the receiver unlinks it; should it never get there, the resource tracker -- the parent's, shared by the
+    return handle  # workers -- removes the block when the parent ends)
 
 
 def _import(h):
@@ -60,17 +60,6 @@ def _import(h):
             shm.unlink()
         except FileNotFoundError:
             pass
-
-
-def _forget(shm):
-    """The block outlives this process's handle (the receiver unlinks it): keep the resource tracker from removing it,
-    or from warning about it, when this process ends."""
-    try:
-        from multiprocessing import resource_tracker
-
-        resource_tracker.unregister(shm._name, "shared_memory")
-    except Exception:  # noqa: BLE001
-        pass
 
 
 class SharedFrames:
@@ -147,8 +136,7 @@ def attach_observers(spec):
     """(worker) Observers whose images read from the shared blocks.  Returns (observers, blocks to keep alive)."""
     observers, keep = [], []
     for s in spec:
-        shm = shared_memory.SharedMemory(name=s["shm"])
-        _forget(shm)  # (the parent owns the block)
+        shm = shared_memory.SharedMemory(name=s["shm"])  # (the parent owns the block and unlinks it)
         keep.append(shm)
         block = np.ndarray(s["shape"], np.dtype(s["dtype"]), buffer=shm.buf)
         block.flags.writeable = False
@@ -225,12 +213,41 @@ def _track_block(state, args):
         state["ctx_id"] = id(tracker._ctx)
     out["transport"] = transport
     out["why_host"] = state.get("why_host", "")
-    if gathered is not None:
+    # The history goes into the parent's result block (one shared-memory block for all workers, kept between calls: its
+    # pages are mapped once), rows [lo, hi) of (tracks, times, 12) = means | sigmas: worker 0 writes everybody's after the
+    # RCCL gather, every worker its own otherwise.  Blocks of another shape (ragged runs) travel as arrays of the reply.
+    block = _result_block(state, args.get("result"))
+    lo, hi = args["rows"]
+    if gathered is not None and block is not None:
+        block[:, :, :] = np.transpose(gathered[0], (1, 0, 2))
+        out["in_block"] = "all"
+    elif gathered is not None:
         out["gathered"] = gathered[0]
     elif transport != "rccl" or not args["gather"]:
-        out["means"], out["sigmas"] = t.means, t.sigmas
+        m, sg = t.means, t.sigmas
+        if (block is not None and isinstance(m, np.ndarray) and m.shape == (hi - lo, block.shape[1], 6)
+                and (sg is None or (isinstance(sg, np.ndarray) and sg.shape == m.shape))):
+            block[lo:hi, :, 0:6] = m
+            if sg is not None:
+                block[lo:hi, :, 6:12] = sg
+            out["in_block"] = "rows"
+        else:
+            out["means"], out["sigmas"] = m, sg
     out["seconds"] = time.perf_counter() - t0
     return out
+
+
+def _result_block(state, spec):
+    """(worker) the parent's result block as an array (tracks, times, 12), attached once per block."""
+    if spec is None:
+        return None
+    name, shape = spec
+    held = state.get("result_shm")
+    if held is None or held[0] != name:
+        if held is not None:
+            held[1].close()
+        held = state["result_shm"] = (name, shared_memory.SharedMemory(name=name))
+    return np.ndarray(shape, np.float64, buffer=held[1].buf)
 
 
 _HANDLERS = {"track": _track_block, "digest": _frames_digest}
@@ -297,10 +314,16 @@ class WorkerPool:
 
     def __init__(self, n, devices):
         ctx = mp.get_context("spawn")  # fresh interpreters: the parent may have initialised the GPU runtime
+        # ONE resource tracker for the parent and the workers (started here, before they are: they inherit it): a block made
+        # on one side and unlinked on the other is then registered and unregistered in the same place
+        from multiprocessing import resource_tracker
+
+        resource_tracker.ensure_running()
         self.n = n
         self.token = f"pool_{os.getpid()}_{id(self):x}"
         self.calls = 0
         self.frames = None  # SharedFrames the workers hold
+        self.results = None  # shared-memory block the workers write the posterior history into
         self.procs, self.conns = [], []
         for rank in range(n):
             parent, child = ctx.Pipe()
@@ -329,8 +352,9 @@ class WorkerPool:
         pending = set(range(self.n))
         deadline = time.monotonic() + timeout
         while pending and failure is None:
+            ready = mpc.wait([self.conns[r] for r in pending], timeout=0.05)
             for r in list(pending):
-                if self.conns[r].poll(0.01):
+                if self.conns[r] in ready:
                     try:
                         status, value = self.conns[r].recv()
                     except (EOFError, OSError):
@@ -341,7 +365,7 @@ class WorkerPool:
                         break
                     replies[r] = value
                     pending.discard(r)
-                elif not self.procs[r].is_alive():
+                elif not ready and not self.procs[r].is_alive():
                     failure = f"worker {r} died (exit code {self.procs[r].exitcode})"
                     break
             if time.monotonic() > deadline:
@@ -354,6 +378,23 @@ class WorkerPool:
             self.close(kill=True)
             raise RuntimeError("Tracker.track(parallel=...): " + failure)
         return replies
+
+    def result_block(self, shape):
+        """(name, shape) of a float64 shared-memory block of at least this shape, kept between calls (grown on demand)."""
+        nbytes = int(np.prod(shape)) * 8
+        if self.results is None or self.results.size < nbytes:
+            if self.results is not None:
+                try:
+                    self.results.close()
+                    self.results.unlink()
+                except (BufferError, FileNotFoundError, OSError):
+                    pass
+            self.results = shared_memory.SharedMemory(create=True, size=max(nbytes, 1))
+        return self.results.name, tuple(int(v) for v in shape)
+
+    def result_array(self, shape):
+        """A COPY of the block's contents as (tracks, times, 12)."""
+        return np.array(np.ndarray(shape, np.float64, buffer=self.results.buf))
 
     def share(self, observers):
         """The workers see these observers' frames (shared once; again only when the image objects changed)."""
@@ -385,6 +426,13 @@ class WorkerPool:
         if self.frames is not None:
             self.frames.close()
             self.frames = None
+        if self.results is not None:
+            try:
+                self.results.close()
+                self.results.unlink()
+            except (BufferError, FileNotFoundError, OSError):
+                pass
+            self.results = None
         import shutil
 
         shutil.rmtree(sharding.FileStore.default_path(self.token), ignore_errors=True)

@@ -114,12 +114,16 @@ def _usable_cores():
 
 class _FrameFeed:
     """The frames a run touches, on their way to HBM in the order the sequence needs them (image.py:137-214: the
-    reference reads an image when a track first asks for it).  Images that still live in files are decoded by a pool of
-    threads (Pillow releases the GIL; one thread per usable core) WHILE the frame loop runs on the frames already
-    resident: `need(i)` waits for the frames of time steps <= i only, hands them to the device (pinned staging + copy
-    stream: glh_observer_upload_frame_async) together with every later frame that has been decoded meanwhile, and returns
-    the last time step whose frames are all resident -- the frame loop runs up to there in one call.  In-memory images
-    are all uploaded by the first call, as before."""
+    reference reads an image when a track first asks for it).  Images that still live in files are decoded WHILE the
+    frame loop runs on the frames already resident: `need(i)` waits for the frames of time steps <= i only, hands them
+    to the device (pinned staging + copy stream: glh_observer_upload_frame_async) together with every later frame that has
+    been decoded meanwhile, and returns the last time step whose frames are all resident -- the frame loop runs up to
+    there in one call.  Decoders: a pool of PROCESSES writing into a shared-memory ring (glimpse_amd/ingest.py) for
+    sequences of at least `PROCESS_MIN` files, threads below that (Pillow releases the GIL only inside the decode proper:
+    sixteen threads reached 4x one for JPEG, 1.2x for uncompressed TIFF).  In-memory images are all uploaded by the
+    first call, as before."""
+
+    PROCESS_MIN = 8
 
     def __init__(self, tracker, ctx, matching):
         self.tracker, self.ctx = tracker, ctx
@@ -130,19 +134,44 @@ class _FrameFeed:
                     first_use.setdefault((o, int(m)), i)
         self.jobs = sorted(first_use.items(), key=lambda kv: (kv[1], kv[0]))  # [((observer, image), first time step)]
         self.ntimes = len(matching)
-        self.pos = 0
-        self.pool = None
+        self.pos = 0  # jobs [0, pos) are on the device
+        self.done = [False] * len(self.jobs)
+        self.pool = None      # threads
         self.futures = None
+        self.procs = None     # ingest.DecodePool
+        self.submitted = 0
+        self.decoding = 0     # images queued with the decoders, not yet back
+        self.inflight = []    # (upload ticket, slot) of the copies enqueued from the page-locked ring, oldest first
         self.stats = tracker._feed_stats = dict(files=0, frames=len(self.jobs), decode_seconds=0.0, upload_seconds=0.0,
-                                                bytes=0, threads=0, waits=0, wait_seconds=0.0)
-        on_disk = [job for job, _ in self.jobs if getattr(tracker.observers[job[0]].images[job[1]], "array", None) is None]
+                                                bytes=0, threads=0, processes=0, waits=0, wait_seconds=0.0)
+        on_disk = [k for k, (job, _) in enumerate(self.jobs) if self._image(job).__dict__.get("array") is None]
+        self.on_disk = set(on_disk)
         self.stats["files"] = len(on_disk)
-        if len(on_disk) > 1:
+        cores = _usable_cores()
+        if len(on_disk) >= self.PROCESS_MIN and cores >= 4 and not os.environ.get("GLH_DECODE_THREADS"):
+            from . import ingest
+
+            slot = max(nbytes for _, _, nbytes in tracker._frame_dtypes())
+            want = max(2, min(cores - 1, len(on_disk)))
+            pool = tracker._decoders
+            if pool is None or not pool.alive() or pool.slot_bytes < slot or pool.n < want:
+                if pool is not None:
+                    pool.close()
+                pool = tracker._decoders = ingest.DecodePool(want, slot)
+            else:
+                pool.drain()
+            self.procs = pool
+            self.stats["processes"] = pool.n
+            self.stats["pinned_ring"] = bool(pool.pinned)
+        elif len(on_disk) > 1:
             from concurrent.futures import ThreadPoolExecutor
 
-            self.stats["threads"] = min(_usable_cores(), len(on_disk))
+            self.stats["threads"] = min(cores, len(on_disk))
             self.pool = ThreadPoolExecutor(max_workers=self.stats["threads"])
-            self.futures = [self.pool.submit(self._pixels, job) for job, _ in self.jobs]
+            self.futures = {k: self.pool.submit(self._pixels, self.jobs[k][0]) for k in on_disk}
+
+    def _image(self, job):
+        return self.tracker.observers[job[0]].images[job[1]]
 
     def _pixels(self, job):
         import time
@@ -152,38 +181,108 @@ class _FrameFeed:
         a = np.ascontiguousarray(obs.images[job[1]].read(cache=obs.cache))  # (dtype checked by the upload)
         return a, time.perf_counter() - t0
 
-    def _upload(self, k, wait):
+    def _to_device(self, k, a, seconds):
         import time
 
         job = self.jobs[k][0]
-        if self.futures is not None:
-            fut = self.futures[k]
-            if not wait and not fut.done():
-                return False
-            if not fut.done():
-                t0 = time.perf_counter()
-                fut.result()
-                self.stats["waits"] += 1
-                self.stats["wait_seconds"] += time.perf_counter() - t0
-            a, dt = fut.result()
-            self.futures[k] = None  # (the pixels are not kept here)
-        else:
-            a, dt = self._pixels(job)
-        self.stats["decode_seconds"] += dt
+        self.stats["decode_seconds"] += seconds
         t0 = time.perf_counter()
         self.ctx.observer_upload_frame_async(job[0], job[1], a)
         self.stats["upload_seconds"] += time.perf_counter() - t0
         self.stats["bytes"] += a.nbytes
         self.tracker._uploaded.add(job)
+        self.done[k] = True
+
+    def _wait(self, fn):
+        import time
+
+        t0 = time.perf_counter()
+        out = fn()
+        self.stats["waits"] += 1
+        self.stats["wait_seconds"] += time.perf_counter() - t0
+        return out
+
+    def _reclaim(self, wait_one=False):
+        """Slots whose host-to-device copy (from the page-locked ring) has finished go back to the decoders."""
+        while self.inflight and self.ctx.upload_done(self.inflight[0][0], wait=wait_one):
+            self.procs.release(self.inflight.pop(0)[1])
+            wait_one = False
+
+    def _pump_processes(self, until):
+        """Keep the decoders fed; upload what they have finished; block until jobs [pos, until] are on the device."""
+        import time
+
+        pool = self.procs
+        while True:
+            self._reclaim()
+            while self.submitted < len(self.jobs):  # (in the order of use; in-memory images go straight to the device)
+                k = self.submitted
+                if k not in self.on_disk:
+                    a, dt = self._pixels(self.jobs[k][0])
+                    self._to_device(k, a, dt)
+                elif pool.submit(k, self._image(self.jobs[k][0])):
+                    self.decoding += 1
+                else:
+                    break
+                self.submitted += 1
+            block = not all(self.done[self.pos:until + 1])  # (the decoders finish in any order)
+            if self.decoding == 0:
+                if block and self.inflight:  # (every slot is waiting for its copy: the oldest one first)
+                    self._wait(lambda: self._reclaim(wait_one=True))
+                    continue
+                return
+            got = self._wait(lambda: pool.result(True)) if block else pool.result(False)
+            if got is None:
+                return
+            self.decoding -= 1
+            k, view, slot, seconds = got
+            job = self.jobs[k][0]
+            if self.tracker.observers[job[0]].cache:  # (Observer.cache: the decoded pixels stay on the image, image.py:211-213)
+                self._image(job).array = np.array(view)
+            if pool.pinned:
+                self.stats["decode_seconds"] += seconds
+                t0 = time.perf_counter()
+                self.inflight.append((self.ctx.observer_upload_frame_pinned(job[0], job[1], view), slot))
+                self.stats["upload_seconds"] += time.perf_counter() - t0
+                self.stats["bytes"] += view.nbytes
+                self.tracker._uploaded.add(job)
+                self.done[k] = True
+            else:
+                self._to_device(k, view, seconds)  # (copied into pinned staging before the call returns)
+                pool.release(slot)
+            del view
+
+    def _upload(self, k, wait):
+        if self.done[k]:
+            return True
+        if self.futures is not None and k in self.futures:
+            fut = self.futures[k]
+            if not wait and not fut.done():
+                return False
+            a, dt = fut.result() if fut.done() else self._wait(fut.result)
+            del self.futures[k]  # (the pixels are not kept here)
+        else:
+            a, dt = self._pixels(self.jobs[k][0])
+        self._to_device(k, a, dt)
         return True
 
     def need(self, i):
         """Every frame of time steps <= i is resident (or on its way, ahead of the next launch); returns the last time
         step for which that holds."""
-        while self.pos < len(self.jobs) and self.jobs[self.pos][1] <= i:
-            self._upload(self.pos, True)
-            self.pos += 1
-        while self.pos < len(self.jobs) and self._upload(self.pos, self.futures is None):
+        last = -1
+        for k in range(self.pos, len(self.jobs)):
+            if self.jobs[k][1] > i:
+                break
+            last = k
+        if self.procs is not None:
+            self._pump_processes(last)
+        else:
+            for k in range(self.pos, last + 1):
+                self._upload(k, True)
+            k = max(self.pos, last + 1)
+            while k < len(self.jobs) and self._upload(k, self.futures is None):
+                k += 1
+        while self.pos < len(self.jobs) and self.done[self.pos]:
             self.pos += 1
         if self.pos >= len(self.jobs):
             self.close()
@@ -194,6 +293,17 @@ class _FrameFeed:
         if self.pool is not None:
             self.pool.shutdown(wait=False, cancel_futures=True)
             self.pool = None
+        if self.procs is not None:
+            while self.inflight:  # (the copies read the ring: its slots are free when they are over)
+                try:
+                    self._reclaim(wait_one=True)
+                except Exception:  # noqa: BLE001  (the context is gone: so are its copies)
+                    for _, slot in self.inflight:
+                        self.procs.release(slot)
+                    self.inflight = []
+            if self.pos < len(self.jobs):
+                self.procs.drain()  # (a run that ended early: nothing of it stays in the ring)
+            self.procs = None
 
 
 class Tracker:
@@ -242,6 +352,7 @@ class Tracker:
         self._ctx = None
         self._ctx_key = None
         self._feed = None
+        self._decoders = None  # ingest.DecodePool: processes that decode image files, kept between runs
         self._feed_stats = None  # decode / upload figures of the last run's frame feed (`_FrameFeed.stats`)
         self._uploaded = set()
         self._pool = None  # worker processes of track(parallel=N), kept between calls (glimpse_amd/parallel.py)
@@ -373,18 +484,18 @@ class Tracker:
         key = tuple(id(obs.images[0]) for obs in self.observers)
         if getattr(self, "_dtypes_key", None) != key:
             firsts = [np.asarray(obs.images[0].read(cache=obs.cache)) for obs in self.observers]
-            self._dtypes = [(a.dtype, 1 if a.ndim == 2 else a.shape[2]) for a in firsts]
+            self._dtypes = [(a.dtype, 1 if a.ndim == 2 else a.shape[2], a.nbytes) for a in firsts]
             self._dtypes_key = key
         return self._dtypes
 
     def _sixteen_bit(self):
         """Some observer's frames are uint16: no kernel takes those beyond 1117-pixel workspaces."""
-        return any(dt == np.uint16 for dt, _ in self._frame_dtypes())
+        return any(dt == np.uint16 for dt, _, _ in self._frame_dtypes())
 
     def _ranked_keys(self):
         """Some observer's frames are uint16 or float: the fused step ranks a tile's pixels and takes those frames
         while the workspaces are at most 255 pixels (the count of a tile's pixels must fit a 16-bit key)."""
-        return any(dt != np.uint8 for dt, _ in self._frame_dtypes())
+        return any(dt != np.uint8 for dt, _, _ in self._frame_dtypes())
 
     def _dim_limit(self, n_points):
         """The largest workspace side the automatic growth may ask for: what the kernels take (2000 pixels; 1117 for
@@ -397,7 +508,7 @@ class Tracker:
             free, _ = _lib.device_memory(self.device)
             P = max(1, n_points)
             per, fixed = 0.0, 0.0
-            for dt, channels in self._frame_dtypes():
+            for dt, channels, _ in self._frame_dtypes():
                 per += (14.0 + (16.0 if dt in (np.float32, np.float64) else 0.0)) * P
                 if dt == np.uint16:
                     fixed += 4.0 * (65535 * channels + 1) * P
@@ -797,27 +908,51 @@ class Tracker:
                                     for a, b in bounds)
         settings = dict(viewshed=self.viewshed, resample_method=self.resample_method, highpass=self.highpass,
                         interpolation=self.interpolation, max_search_dim=self.max_search_dim)
+        # where the history goes: one shared-memory block (tracks, times, 12) the workers write their rows into -- when the
+        # number of time steps is known here (datetimes given or the observers' own: what the workers will find too)
+        result = None
+        if gather:
+            try:
+                dts = self.datetimes if kw.get("datetimes") is None else \
+                    self.parse_datetimes(datetimes=kw["datetimes"], maxdt=kw.get("maxdt", datetime.timedelta(0)))
+                result = pool.result_block((ntracks, len(dts), 12))
+            except Exception:  # noqa: BLE001  (the workers raise it properly)
+                result = None
         jobs = []
         for w, (a, b) in enumerate(bounds):
             jobs.append(dict(tracker=settings, models=motion_models[a:b], np_seed=seeds[w], catch=ntracks >= 2,
-                             gather=gather, sizes=sizes, call=pool.calls, want_last=w == workers - 1,
+                             gather=gather, sizes=sizes, call=pool.calls, want_last=w == workers - 1, result=result,
+                             rows=(a, b),
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
+        t_ready = time.perf_counter()
+        replies = pool.call("track", jobs)
+        t_replied = time.perf_counter()
         parts = [{k: [parallel._import(x) for x in v] if isinstance(v, list) else parallel._import(v)
-                  for k, v in part.items()} for part in pool.call("track", jobs)]
+                  for k, v in part.items()} for part in replies]
+        t_imported = time.perf_counter()
 
         def cat(name):
             values = [part[name] for part in parts]
-            return None if values[0] is None else [row for v in values for row in v]
+            if values[0] is None:
+                return None
+            if all(isinstance(v, np.ndarray) for v in values) and len({v.shape[1:] for v in values}) == 1:
+                return np.concatenate(values, axis=0)
+            return [row for v in values for row in v]
 
         errors = cat("errors")
         transport = parts[0]["transport"] if gather else "host"
+        in_block = [part.get("in_block") for part in parts]
+        want_sigmas = not kw.get("return_covariances")
+        full = pool.result_array(result[1]) if result is not None and any(in_block) else None  # (tracks, times, 12)
         if transport == "rccl":
-            # worker 0 holds every worker's history: (T, sum P, 12) -> means / sigmas (P, T, 6); rows of a failed track
-            # are NaN from the frame where it failed (what the workers' own copies hold from their status words)
-            moments = parts[0]["gathered"]
-            means = np.ascontiguousarray(np.transpose(moments[:, :, 0:6], (1, 0, 2)))
-            sigmas = None if kw.get("return_covariances") else np.ascontiguousarray(np.transpose(moments[:, :, 6:12], (1, 0, 2)))
+            # worker 0 received every worker's history (T, sum P, 12) and wrote it into the block (or sent it, when there was
+            # no block); rows of a failed track are NaN from the frame where it failed -- what the workers' own copies hold
+            # from their status words is repeated here
+            if in_block[0] != "all":
+                full = np.ascontiguousarray(np.transpose(parts[0]["gathered"], (1, 0, 2)))
+            means = np.ascontiguousarray(full[:, :, 0:6])
+            sigmas = np.ascontiguousarray(full[:, :, 6:12]) if want_sigmas else None
             lo = 0
             for part, n in zip(parts, sizes):
                 for p, e in part.get("nan_from", ()):
@@ -826,9 +961,25 @@ class Tracker:
                         sigmas[lo + p, e:] = np.nan
                 lo += n
         else:
-            means, sigmas = cat("means"), cat("sigmas")
-            why = next((part["why_host"] for part in parts if part.get("why_host")), "")
+            mparts, sparts = [], []
+            for part, (a, b) in zip(parts, bounds):
+                if part.get("in_block") == "rows":
+                    mparts.append(np.ascontiguousarray(full[a:b, :, 0:6]))
+                    sparts.append(np.ascontiguousarray(full[a:b, :, 6:12]) if want_sigmas else None)
+                else:
+                    mparts.append(part["means"])
+                    sparts.append(part["sigmas"])
+
+            def join(values):
+                if values[0] is None:
+                    return None
+                if all(isinstance(v, np.ndarray) for v in values) and len({v.shape[1:] for v in values}) == 1:
+                    return np.concatenate(values, axis=0)
+                return [row for v in values for row in v]
+
+            means, sigmas = join(mparts), join(sparts)
             if gather:
+                why = next((part["why_host"] for part in parts if part.get("why_host")), "")
                 parallel.log.warning("Tracker.track(parallel=%d): no RCCL communicator (%s); the posterior history was "
                                      "collected through host memory", workers, why or "unavailable")
         if ntracks < 2 and errors[0] is not None:
@@ -844,7 +995,10 @@ class Tracker:
                                     contexts_made=[bool(part["context_made"]) for part in parts],
                                     worker_seconds=[part["seconds"] for part in parts],
                                     worker_track_seconds=[part["track_seconds"] for part in parts],
-                                    call_seconds=time.perf_counter() - t_start)
+                                    call_seconds=time.perf_counter() - t_start,
+                                    parent_seconds=dict(prepare=t_ready - t_start, workers=t_replied - t_ready,
+                                                        import_arrays=t_imported - t_replied,
+                                                        assemble=time.perf_counter() - t_imported))
         if kw.get("reduce_particles"):
             tracks.reduced = [r for part in parts for r in part["reduced"]]
         return tracks
@@ -858,6 +1012,9 @@ class Tracker:
         if getattr(self, "_feed", None) is not None:
             self._feed.close()
             self._feed = None
+        if getattr(self, "_decoders", None) is not None:
+            self._decoders.close()
+            self._decoders = None
         pool, self._pool = getattr(self, "_pool", None), None
         if pool is not None:
             pool.close()
@@ -872,9 +1029,10 @@ class Tracker:
 
     def __del__(self):
         try:
-            pool = getattr(self, "_pool", None)
-            if pool is not None:
-                pool.close()
+            for name in ("_pool", "_decoders"):
+                pool = getattr(self, name, None)
+                if pool is not None:
+                    pool.close()
         except Exception:  # noqa: BLE001
             pass
 

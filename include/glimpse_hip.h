@@ -159,6 +159,15 @@ int glh_observer_upload_frame(glh_ctx* ctx, int obs, int image, const uint8_t* p
  * `pixels` is copied to a pinned staging buffer before the call returns; the host-to-device copy runs
  * on a copy stream and every later call that reads frames is ordered after it on the device.      */
 int glh_observer_upload_frame_async(glh_ctx* ctx, int obs, int image, const uint8_t* pixels);
+/* Frame ingest without the staging copy (round 5): a host buffer the caller registers ONCE -- e.g. the shared-memory ring
+ * its decoder processes fill (glimpse_amd/ingest.py) -- is page-locked for the device, and glh_observer_upload_frame_pinned
+ * enqueues the host-to-device copy on the copy stream straight from `pixels`, which must lie inside a registered buffer and
+ * stay untouched until glh_upload_done reports the copy `*ticket` identifies as finished (`wait` != 0: blocks until it is).
+ * Ordering against the kernels is that of glh_observer_upload_frame_async.                                              */
+int glh_host_register(void* ptr, uint64_t bytes);
+int glh_host_unregister(void* ptr);
+int glh_observer_upload_frame_pinned(glh_ctx* ctx, int obs, int image, const uint8_t* pixels, int64_t* ticket);
+int glh_upload_done(glh_ctx* ctx, int64_t ticket, int wait, int* done);
 /* Same, from a buffer that is already on the device (no PCIe in the timed region).        */
 int glh_observer_set_frame_device(glh_ctx* ctx, int obs, int image, const void* dev_pixels);
 

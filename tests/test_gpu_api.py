@@ -509,7 +509,8 @@ def test_tracking_from_image_files_equals_tracking_from_arrays(golden, tmp_path)
         tracker = glimpse_amd.Tracker(observers, max_search_dim=128)
         got = tracker.track(models_from(g), tile_size=tile, rng="philox", seed=3)
         stats = dict(tracker._feed_stats)
-        assert stats["files"] == stats["frames"] == sum(len(obs.images) for obs in observers) and stats["threads"] >= 1
+        assert stats["files"] == stats["frames"] == sum(len(obs.images) for obs in observers)
+        assert stats["threads"] + stats["processes"] >= 1  # (a pool of decoder processes from eight files on)
         assert stats["bytes"] == sum(img.read(cache=False).nbytes for obs in observers for img in obs.images)
         np.testing.assert_array_equal(got.means, ref.means)
         np.testing.assert_array_equal(got.sigmas, ref.sigmas)

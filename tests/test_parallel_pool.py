@@ -103,3 +103,46 @@ def test_a_failing_worker_takes_the_call_down(monkeypatch):
             pool.call("digest", [None, None], timeout=30)
     finally:
         pool.close()
+
+
+def test_decoder_processes_fill_the_shared_ring(tmp_path):
+    """glimpse_amd/ingest.py: image files decoded by worker processes into the slots of one shared-memory ring -- the
+    pixels of Image.read (here with a camera at half the file's size: the nearest-neighbour resampling of image.py:188-193
+    happens in the decoder), any order of completion, a slot is reused once released, a missing file raises where its
+    result is asked for."""
+    PIL = pytest.importorskip("PIL.Image")
+    from glimpse_amd import ingest
+
+    rng = np.random.default_rng(4)
+    cam = glimpse_amd.Camera(imgsz=(160, 120), f=(200, 200))
+    half = glimpse_amd.Camera(imgsz=(80, 60), f=(100, 100))
+    images, want = [], []
+    for k in range(9):
+        a = rng.integers(0, 255, (120, 160) if k % 2 else (120, 160, 3), dtype=np.uint8)
+        path = tmp_path / f"f{k}.png"
+        PIL.fromarray(a).save(path)
+        img = glimpse_amd.Image(str(path), cam=half if k == 4 else cam, datetime=T0 + k * DAY)
+        images.append(img)
+        want.append(img.read(cache=False))
+    pool = ingest.DecodePool(3, 120 * 160 * 3, slots=4)
+    try:
+        got, queued = {}, 0
+        while len(got) < len(images):
+            while queued < len(images) and pool.submit(queued, images[queued]):
+                queued += 1
+            job, view, slot, seconds = pool.result()
+            got[job] = np.array(view)
+            assert seconds >= 0.0
+            pool.release(slot)
+        for k, a in enumerate(want):
+            np.testing.assert_array_equal(got[k], a)
+        assert got[4].shape == (60, 80, 3)
+        assert sorted(pool.free) == [0, 1, 2, 3] and all(img.array is None for img in images)
+        pool.submit(99, glimpse_amd.Image(str(tmp_path / "missing.png"), cam=cam, datetime=T0))
+        with pytest.raises(RuntimeError, match="decoding failed"):
+            pool.result()
+        assert pool.alive() and sorted(pool.free) == [0, 1, 2, 3]
+    finally:
+        name = pool.ring.name
+        pool.close()
+    assert not os.path.exists("/dev/shm/" + name.lstrip("/"))
