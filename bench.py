@@ -249,7 +249,7 @@ def pmc_traffic_source(wl, kernel):
             + (", " + table["_meta"]["collected"] if "_meta" in table and "collected" in table["_meta"] else "") + ")")
 
 
-SQ_COUNTER_FILES = ("r04_C3_sq_counters.json", "r03_C3_sq_counters.json")  # (the newest committed pass)
+SQ_COUNTER_FILES = ("r05_C3_sq_counters.json", "r04_C3_sq_counters.json", "r03_C3_sq_counters.json")  # (the newest committed pass)
 
 
 def sq_counters(wl):

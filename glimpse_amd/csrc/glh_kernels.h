@@ -197,13 +197,14 @@ __device__ __forceinline__ uint32_t viewshed_bits(const Surfaces& surf, double x
 // FAST: the surface samples in fast arithmetic (glh_math.h: raster_bilinear_fast), the scale by a Newton reciprocal.
 template <bool FAST = false>
 __device__ __forceinline__ double dem_log_likelihood(const double* m, const Surfaces& surf, double x, double y,
-                                                     double z, bool* oob, const RasterPatch* patches = nullptr) {
+                                                     double z, bool* oob, const RasterPatch* patches = nullptr,
+                                                     const RasterWin* wins = nullptr) {
   double zd, zs;
   // (both surfaces rasters on one grid, the sample inside their windows: the cell and the weights once for both)
   if (!(patches && m[20] != 0.0 && m[21] != 0.0 &&
-        raster_sample_pair<FAST>(surf.dem, surf.dem_sigma, surf.same_grid != 0, patches, patches + 1, x, y, zd, zs))) {
-    zd = dem_at<FAST>(m, surf, x, y, oob, patches);
-    zs = dem_sigma_at<FAST>(m, surf, x, y, oob, patches);
+        raster_sample_pair<FAST>(surf.dem, surf.dem_sigma, surf.same_grid != 0, patches, patches + 1, x, y, zd, zs, wins))) {
+    zd = dem_at<FAST>(m, surf, x, y, oob, patches, wins);
+    zs = dem_sigma_at<FAST>(m, surf, x, y, oob, patches, wins);
   }
   if (zs != 0.0) {
     const double d = zd - z;
@@ -325,7 +326,8 @@ __device__ __forceinline__ void evolve_cartesian_m(double* p, const double* m, c
 template <bool FAST = false, bool GRID = true, bool ZKNOWN = false>
 __device__ __forceinline__ void evolve_particle(double* p, const double* m, const double* n, double tau,
                                                 double tau2, const Surfaces& surf, bool* oob,
-                                                const RasterPatch* patches = nullptr, double z_known = 0.0) {
+                                                const RasterPatch* patches = nullptr, double z_known = 0.0,
+                                                const RasterWin* wins = nullptr) {
   const int kind = (int)m[18];
   if (kind == GLH_MOTION_CARTESIAN) {
     evolve_cartesian_m<FAST>(p, m, n, tau, tau2);
@@ -377,14 +379,14 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
     }
     return;
   }
-  double z_off = p[2] - (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches) : m[16]);
+  double z_off = p[2] - (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16]);
   if constexpr (FAST)
     z_off = glh_fma(m[19] * n[2], sqrt_nr(glh_fma(dx, dx, dy * dy)), z_off);
   else
     z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;
   p[1] += dy;
-  p[2] = (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches) : m[16]) + z_off;
+  p[2] = (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16]) + z_off;
   if constexpr (FAST) {
     p[3] = glh_fma(tau, a[0], p[3]);
     p[4] = glh_fma(tau, a[1], p[4]);

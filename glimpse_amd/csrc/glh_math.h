@@ -417,6 +417,13 @@ struct RasterPatch {
   int32_t full;          // w == h == GLH_PATCH_W: raster_sample_window serves this window
   int32_t pair;          // (window 0 only) ... and the dem_sigma window beside it lies on the same grid at the same origin
 };
+// What raster_window_axis needs of a window before it touches a node: its first coordinates and the cells per unit length.
+// Uniform over the workgroup: the fused kernel reads them once, into scalar registers, instead of from LDS for every
+// sample (an LDS read returns 16 bytes to each of 64 lanes whether or not they asked for the same address: a quarter of a
+// sample's LDS traffic, and a dependent round trip).
+struct RasterWin {
+  double x0, kx, y0, ky;
+};
 // where the window around (x, y) starts, and how many nodes it holds
 GLH_HD void raster_patch_origin(const RasterDev& r, double x, double y, int& i0, int& j0, int& w, int& h) {
   w = r.nx < GLH_PATCH_W ? r.nx : GLH_PATCH_W;
@@ -458,8 +465,8 @@ GLH_HD bool raster_in_window(int g, int o, int w, int n) {
 // Three dependent LDS round trips per sample (the window's origin and cell size, the guessed nodes, the cell's corners) and
 // one rarely taken branch: the first form of this -- the interval step as nested branches, every load behind its own
 // wait -- took six and fifteen exec-mask instructions per axis.
-GLH_HD bool raster_window_axis(const double* a, double k, double x, int& li, double& t) {
-  const double f = (x - a[0]) * k;
+GLH_HD bool raster_window_axis(const double* a, double g0, double k, double x, int& li, double& t) {
+  const double f = (x - g0) * k;
   const bool ok = f >= 1.0 && f < (double)(GLH_PATCH_W - 2);  // (NaN: false)
   int i = (int)fmin(fmax(f, 1.0), (double)(GLH_PATCH_W - 3));  // in [1, W - 3] whatever f is: the reads below stay inside
   double ga = a[2 * i], r = a[2 * i + 1];
@@ -477,11 +484,17 @@ GLH_HD bool raster_window_axis(const double* a, double k, double x, int& li, dou
 }
 // p1: the window of a second raster on the same grid at the same origin (PAIR), sampled with the same cell and weights
 template <bool PAIR>
-GLH_HD bool raster_sample_window(const RasterPatch* p0, const RasterPatch* p1, double x, double y, double& v0, double& v1) {
+GLH_HD bool raster_sample_window(const RasterPatch* p0, const RasterPatch* p1, double x, double y, double& v0, double& v1,
+                                 const RasterWin* win = nullptr) {
+#ifdef GLH_ABLATE_SAMPLE  // (diagnostic build: what the samples cost where they stand -- the value is not the raster's)
+  v0 = x * 1e-9 + y * 1e-9;
+  if constexpr (PAIR) v1 = 0.3 + x * 1e-12;
+  return true;
+#endif
   int li, lj;
   double tx, ty;
-  const bool okx = raster_window_axis(p0->ax, p0->fkx, x, li, tx);
-  const bool oky = raster_window_axis(p0->ay, p0->fky, y, lj, ty);
+  const bool okx = raster_window_axis(p0->ax, win ? win->x0 : p0->ax[0], win ? win->kx : p0->fkx, x, li, tx);
+  const bool oky = raster_window_axis(p0->ay, win ? win->y0 : p0->ay[0], win ? win->ky : p0->fky, y, lj, ty);
   const double* z = p0->z + lj * GLH_PATCH_W + li;
   v0 = raster_bilinear_fast(z[0], z[1], z[GLH_PATCH_W], z[GLH_PATCH_W + 1], tx, ty);
   if constexpr (PAIR) {
@@ -496,13 +509,23 @@ GLH_HD bool raster_sample_window(const RasterPatch* p0, const RasterPatch* p1, d
 // (or null); a sample whose interval and its neighbours lie inside is read from it -- same values, same arithmetic.
 // FAST: raster_bilinear_fast for order 1 (order 0 has one form).
 template <bool FAST = false>
-GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob, const RasterPatch* patch = nullptr) {
+GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, bool* oob, const RasterPatch* patch = nullptr,
+                            const RasterWin* win = nullptr) {  // win: the window's origin and cell size in registers, or null
   if constexpr (FAST) {
     if (patch && order == 1 && patch->full) {  // (uniform)
       double v, unused;
-      if (raster_sample_window<false>(patch, patch, x, y, v, unused)) return v;
+      if (raster_sample_window<false>(patch, patch, x, y, v, unused, win)) return v;
     }
+#ifdef GLH_ABLATE_COLD  // (diagnostic build: no general code behind the window -- what its inlined copies cost the hot path)
+    if (patch) {
+      *oob = true;
+      return NAN;
+    }
+#endif
   }
+  // (Tried in round 5: this general code as a real function called from the particle loops -- 20 .. 30 inlined copies of it
+  // make the raster instantiations 370 KB -- does not compile: a call inside divergent control flow ends in the backend's
+  // "illegal VGPR to SGPR copy", also when the whole wave makes the call.)
   if (!(x >= r.xmin && x <= r.xmax && y >= r.ymin && y <= r.ymax)) {
     *oob = true;
     return NAN;
@@ -542,9 +565,12 @@ GLH_HD double raster_sample(const RasterDev& r, double x, double y, int order, b
 // from the windows -- the caller then samples each raster on its own.  Same values, same arithmetic as raster_sample.
 template <bool FAST = false>
 GLH_HD bool raster_sample_pair(const RasterDev& r0, const RasterDev& r1, bool same_grid, const RasterPatch* p0,
-                               const RasterPatch* p1, double x, double y, double& v0, double& v1) {
+                               const RasterPatch* p1, double x, double y, double& v0, double& v1,
+                               const RasterWin* win = nullptr) {
   if constexpr (FAST) {
-    if (p0->pair && raster_sample_window<true>(p0, p1, x, y, v0, v1)) return true;  // (pair: uniform)
+    // (pair: uniform.  What the windows do not serve goes to the two single samples -- the same values: this function's
+    // general form below is the exact arithmetic's)
+    return p0->pair && raster_sample_window<true>(p0, p1, x, y, v0, v1, win);
   }
   const bool same = same_grid && r0.nx == r1.nx && r0.ny == r1.ny && r0.xmin == r1.xmin && r0.xmax == r1.xmax &&
                     r0.ymin == r1.ymin && r0.ymax == r1.ymax && p0->i0 == p1->i0 && p0->j0 == p1->j0 && p0->w == p1->w &&
@@ -580,14 +606,18 @@ struct Surfaces {
   int32_t pad_;
 };
 // (patches: windows of the dem [0] and the dem_sigma [1] raster, or null)
+// (wins: the two windows' RasterWin, or null)
 template <bool FAST = false>
-GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob, const RasterPatch* patches = nullptr) {
-  return m[20] != 0.0 ? raster_sample<FAST>(s.dem, x, y, 1, oob, patches) : m[16];
+GLH_HD double dem_at(const double* m, const Surfaces& s, double x, double y, bool* oob, const RasterPatch* patches = nullptr,
+                     const RasterWin* wins = nullptr) {
+  return m[20] != 0.0 ? raster_sample<FAST>(s.dem, x, y, 1, oob, patches, wins) : m[16];
 }
 template <bool FAST = false>
 GLH_HD double dem_sigma_at(const double* m, const Surfaces& s, double x, double y, bool* oob,
-                           const RasterPatch* patches = nullptr) {
-  return m[21] != 0.0 ? raster_sample<FAST>(s.dem_sigma, x, y, 1, oob, patches ? patches + 1 : nullptr) : m[17];
+                           const RasterPatch* patches = nullptr, const RasterWin* wins = nullptr) {
+  return m[21] != 0.0 ? raster_sample<FAST>(s.dem_sigma, x, y, 1, oob, patches ? patches + 1 : nullptr,
+                                            wins ? wins + 1 : nullptr)
+                      : m[17];
 }
 
 // Search box (tracker.py:580-603).  Returns 0 and fills box (l,t,r,b) when the box is

@@ -1011,6 +1011,22 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     }
     __syncthreads();
   }
+  // (code 2, fast arithmetic) the windows' origins and cell sizes in scalar registers: glh_math.h, RasterWin
+  RasterWin wins_v[2] = {};
+  const RasterWin* wins = nullptr;
+  if constexpr (GRID && FAST) {
+    auto uni = [](double v) -> double {
+      const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+      return __hiloint2double(hi, lo);
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const RasterPatch& p = s_patches.p[q];
+      wins_v[q].x0 = uni(p.ax[0]); wins_v[q].kx = uni(p.fkx);
+      wins_v[q].y0 = uni(p.ay[0]); wins_v[q].ky = uni(p.fky);
+    }
+    wins = wins_v;
+  }
   // the evolve step of particle k re-applied to its pre-evolve record x (phase E)
   // CartesianMotion with axyz_sigma[2] == 0 (uniform): the third normal only ever meets that zero
   const bool third = SURF || m[15] != 0.0;
@@ -1032,7 +1048,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         evolve_particle<FAST, GRID, true>(x, m, n, tau, tau2, a.surf, &oob, nullptr, z_parked);
 #else
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, k, N, n, true);
-        evolve_particle<FAST, GRID, false>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get());
+        evolve_particle<FAST, GRID, false>(x, m, n, tau, tau2, a.surf, &oob, s_patches.get(), 0.0, wins);
 #endif
       } else {
         // (with rasters the tangent models took the branch above, and the other models' step reads no surface: the copy
@@ -1104,7 +1120,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #endif
         evolve_noise(rng_mode, a.normals, a.seed, a.step, pt, a.pt_base, i, N, n, third);
         if constexpr (SURF)
-          evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &raster_oob, s_patches.get());
+          evolve_particle<FAST, GRID>(x, m, n, tau, tau2, a.surf, &raster_oob, s_patches.get(), 0.0, wins);
         else
           evolve_cartesian_m<FAST>(x, m, n, tau, tau2);
         if (i == 0) {
@@ -1113,12 +1129,14 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) bad |= isnan(x[k]);
+#ifndef GLH_ABLATE_ZP
         if (GLH_PT_ZPARK && GRID && tangent_pt) ZP[i] = x[2];  // (for the gather's re-evolution: evolve_loaded)
+#endif
         if (a.has_dem && motion_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
           if (GRID && gridded) {
-            ll = dem_log_likelihood<FAST>(m, a.surf, x[0], x[1], x[2], &raster_oob, s_patches.get());
+            ll = dem_log_likelihood<FAST>(m, a.surf, x[0], x[1], x[2], &raster_oob, s_patches.get(), wins);
           } else if (zs != 0.0) {
             const double d = m[16] - x[2];
             ll = (1.0 / (2.0 * (zs * zs))) * (d * d);
@@ -2015,18 +2033,29 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   // +-0 (profiles/ab_r04/r4j59_ab_gu1.txt).  The plain code has the registers for two (round 3: -1 % against one).
   // The 1 024-thread plain code (C4: one workgroup per CU, nothing else hides its latencies) takes three: -1.5 %, no scratch
   // (r4j71_ab_gu_plain.txt; C3 / C5 at 512 threads: one, two and three within noise).
-  constexpr int GU = SURF ? 1 : (TB >= 1024 ? GLH_PT_GU + 1 : GLH_PT_GU);
+#ifndef GLH_PT_GU_SURF
+#define GLH_PT_GU_SURF 1
+#endif
+  constexpr int GU = SURF ? GLH_PT_GU_SURF : (TB >= 1024 ? GLH_PT_GU + 1 : GLH_PT_GU);
   // The record index of a survivor, uin[source], is a memory load the record loads depend on: the words of the NEXT
   // iteration (source | copies from the rank table, record index from memory) are fetched while this iteration's
   // records are evolved (C4, whose 16-wave workgroup has its CU to itself: -0.8 %; C3 / C5: -0.2 .. -0.4 %).
   uint32_t sc_n[GU];
   int rec_n[GU];
+  double zp_n[GU];  // (tangent models over rasters: the parked height of the NEXT iteration's source -- a load from memory
+                    // whose address is known as early as the record index's; fetched with the records it was a second
+                    // exposed latency of every iteration of this one-record-in-flight loop)
   auto fetch_next = [&](int h0) {
 #pragma unroll
     for (int g = 0; g < GU; ++g) {
       const int h = h0 + g * TB;
       sc_n[g] = h < U ? usc[h] : 0u;
       rec_n[g] = COMMON || uin ? (int)uin[sc_n[g] & 0xffffu] : (int)(sc_n[g] & 0xffffu);
+#ifndef GLH_ABLATE_ZP
+      zp_n[g] = GLH_PT_ZPARK && GRID && tangent_pt ? ZP[sc_n[g] & 0xffffu] : 0.0;
+#else
+      zp_n[g] = 0.0;  // (diagnostic build: what the parked heights cost -- wrong results)
+#endif
     }
   };
   fetch_next(tid);
@@ -2040,7 +2069,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       cnt[g] = (int)(sc_n[g] >> 16);
       const double2* src = Pin2 + (size_t)rec_n[g] * rec_stride;
       v[g][0] = src[0]; v[g][1] = src[chunk_stride]; v[g][2] = src[2 * chunk_stride];
-      zp[g] = GLH_PT_ZPARK && GRID && tangent_pt ? ZP[lo[g]] : 0.0;
+      zp[g] = zp_n[g];
     }
     fetch_next(h0 + GU * TB);  // (beyond U: slot 0 of the tables, a valid address; never used)
     // the records are evolved, stored and summed ONE AFTER ANOTHER (compiler barrier): only the loads overlap, the

@@ -74,7 +74,7 @@ def main():
     # (a launch of k_point_step is what glh_track enqueues: with two streams, half of the points -- bench.py multiplies
     # by the launches of a frame)
     import datetime
-    table["_meta"] = {"collected": "round 4, " + datetime.date.today().isoformat(),
+    table["_meta"] = {"collected": "round 5, " + datetime.date.today().isoformat(),
                       "launch": "one k_point_step launch as glh_track enqueues it (two streams: half of the points)"}
     with open(table_path, "w") as f:
         json.dump(table, f, indent=1)
