@@ -42,6 +42,9 @@ namespace glh {
 #ifndef GLH_PT_ZPARK
 #define GLH_PT_ZPARK 1
 #endif
+#ifndef GLH_PT_LDS_BARRIERS_A
+#define GLH_PT_LDS_BARRIERS_A 0
+#endif
 
 constexpr int PT_BLK = 512;    // threads per workgroup (TB) for N <= 5120: two workgroups share a CU
 constexpr int PT_BLK_BIG = 1024;  // TB for larger N: c[N] alone is > half the LDS, one 16-wave workgroup per CU
@@ -1199,7 +1202,13 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         b[0] = r0; b[1] = r1; b[2] = r2m; b[3] = r3; b[4] = r4;
       }
     }
+#if GLH_PT_LDS_BARRIERS_A
+    // (round 5) LDS only: __syncthreads() also waits for this wave's outstanding memory operations -- here the template
+    // loads issued a few lines up precisely so that they travel WHILE the box is reduced, and the stores of phase A
+    pt_lds_barrier();
+#else
     __syncthreads();
+#endif
     PT_STAMP(18);
     if (tid < NOBS) {
       const int o = tid;
@@ -1239,7 +1248,11 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
       a.obs_status[slot] = st;
     }
     PT_STAMP(19);
+#if GLH_PT_LDS_BARRIERS_A
+    pt_lds_barrier();  // (the box and the status words just stored to memory are for the host: nobody here waits for them)
+#else
     __syncthreads();
+#endif
   }
 
   PT_STAMP(1);

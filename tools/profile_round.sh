@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box through gpurun): for every BASELINE configuration that fits one GPU the bench line,
 # the rocprofv3 kernel trace + stats of the same command, and the HBM traffic counters (separate --pmc passes, as
 # MI355X_MICROARCH.md prescribes); SQ counters for C3.  usage: tools/profile_round.sh r03
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 export GLH_FRAME_CACHE=/tmp/glhfc
