@@ -535,6 +535,72 @@ def test_tangent_models_over_rasters_with_three_observers(lib, math):
         assert (res[0]["p"][[0, 1, 3], :, 5] == 0.0).all()  # (the tangent models leave vz = 0)
 
 
+def test_fast_arithmetic_over_rasters_stays_within_rounding_of_exact(lib):
+    """The fast arithmetic's own forms of the surface samples (glh_math.h: raster_bilinear_fast / raster_sample_window --
+    reciprocal interval widths, fused multiply-adds, the sample served from the LDS window alone), of the tangent models'
+    step (Newton square root) and of the DEM term (Newton reciprocal) against the exact arithmetic -- scipy's bilinear form,
+    IEEE divisions, the goldens' arithmetic -- on the SAME host-fed draws: the first update's particles agree to rounding,
+    the posteriors of the whole sequence to 1e-7.  (Fused == staged in each arithmetic is tested above; this pins the
+    fast forms themselves, on the device's own reciprocal / square-root instructions.)  One and two observers, windows
+    in the raster's interior and -- the point in a corner of a small raster -- at its edge (the general code)."""
+    import glimpse_amd
+
+    # (observers, raster nodes, margin around the points: 57 x 49 -- windows in the raster's interior; 9 x 11 -- a raster smaller
+    # than a window; 14 x 13 barely covering the points -- whole windows clipped to the raster's edges, samples outside their
+    # served span)
+    for O, (nx, ny), pad in ((1, (57, 49), 60.0), (2, (57, 49), 60.0), (1, (9, 11), 3.0), (1, (14, 13), 3.0)):
+        cs = _multi_observer_case(max(O, 2), P=4)
+        P, N, T = cs["P"], cs["N"], cs["T"]
+        rng = np.random.default_rng(17 + O + nx)
+        xy = cs["params"][:, 0:2]
+        lo, hi = xy.min(axis=0) - pad, xy.max(axis=0) + pad
+        dem = glimpse_amd.Raster(0.03 * rng.standard_normal((ny, nx)), x=(lo[0], hi[0]), y=(hi[1], lo[1]))
+        dem_sigma = glimpse_amd.Raster(0.2 + 0.1 * rng.random((ny, nx)), x=(lo[0], hi[0]), y=(hi[1], lo[1]))
+        params = np.zeros((P, lib.MOTION_FULL_LEN))
+        params[:, :18] = cs["params"]
+        params[:, 18] = [2, 3, 0, 2]  # tangent Cartesian, tangent cylindrical, Cartesian (DEM term over rasters), tangent Cartesian
+        params[:, 19] = 0.05
+        params[:, 20:22] = 1.0
+        params[1, 4:7] = (0.15, 0.0, 0.0)
+        params[1, 7:10] = (0.05, 0.3, 0.0)
+        params[1, 13:16] = (0.02, 0.05, 0.0)
+        init = rng.standard_normal((P, N, 6))
+        ev = rng.standard_normal((T - 1, P, N, 3))
+        us = rng.random((T - 1, P))
+        res = {}
+        for math in ("exact", "fast"):
+            with lib.Context(P, N, O, max_tile=31, max_search_dim=160, max_frames=T) as ctx:
+                for o in range(O):
+                    ctx.observer_init(o, T, cs["imgsz"][0], cs["imgsz"][1], 1, cs["sigmas"][o])
+                    ctx.observer_set_cameras(o, np.tile(cs["cams"][o], (T, 1)))
+                    for t in range(T):
+                        ctx.observer_upload_frame(o, t, cs["frames"][o][t])
+                ctx.begin_sequence(P, N, (21, 21))
+                ctx.set_raster(lib.RASTER_DEM, dem)
+                ctx.set_raster(lib.RASTER_DEM_SIGMA, dem_sigma)
+                ctx.set_motion(params)
+                ctx.set_math(math)
+                ctx.set_frame(0)
+                ctx.init_particles(normals=init)
+                for o in range(O):
+                    ctx.init_templates(o, 0)
+                ctx.record_moments(0)
+                first = None
+                for i in range(1, T):
+                    ctx.step(i, 1.0, [i] * O, normals=ev[i - 1], u=us[i - 1])
+                    if i == 1:
+                        first = (ctx.get_particles(), ctx.get_weights())
+                    assert ctx.last_variant()[3] & 8  # (the instantiation with the raster samples)
+                assert (ctx.point_status() == 0).all()
+                res[math] = dict(first=first, m=ctx.get_moments(0, T))
+        # the first update: the same resampling decisions (the indices may differ where two cumulative weights are within
+        # rounding of a position -- not on these draws), states within rounding of each other
+        pe, pf = res["exact"]["first"][0], res["fast"]["first"][0]
+        same = (np.abs(pe - pf) <= 1e-9 * (1.0 + np.abs(pe))).all(axis=2)
+        assert same.mean() > 0.999, same.mean()
+        np.testing.assert_allclose(res["fast"]["m"], res["exact"]["m"], rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("math", ["exact", "fast"])
 @pytest.mark.parametrize("variant", [dict(highpass=(3, 3)), dict(highpass=(7, 5)), dict(highpass=(1, 3)),
                                      dict(interpolation=(1, 1)), dict(highpass=(3, 3), interpolation=(1, 1)),
