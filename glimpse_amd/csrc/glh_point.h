@@ -1089,6 +1089,10 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     uint32_t view_bits = 0u;
     const double zs = motion_term ? m[17] : 0.0;
     const bool gridded = GRID && motion_term && (m[20] != 0.0 || m[21] != 0.0);  // uniform: this point's surfaces are rasters
+    // (kernel arguments the loop tests for every particle, read once: where scalar registers are short the loop re-loaded
+    // them, and a scalar load is waited for with the counter the LDS reads share)
+    const bool with_viewshed = GRID && a.surf.viewshed.z != nullptr;
+    const bool with_term = a.has_dem != 0 && motion_term;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) u0[r] = 0.0;
     // software pipeline: the next particle's record is in flight while this one is evolved / projected
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
 #ifndef GLH_ABLATE_ZP
         if (GLH_PT_ZPARK && GRID && tangent_pt) ZP[i] = x[2];  // (for the gather's re-evolution: evolve_loaded)
 #endif
-        if (a.has_dem && motion_term) {
+        if (with_term) {
           // CartesianMotion.compute_log_likelihoods (motion.py:181-204) of the evolved particle
           double ll = 0.0;
           if (GRID && gridded) {
@@ -1146,7 +1150,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
           }
           if constexpr (!RECOMP) W[i] = ll;  // (RECOMP: phase C makes the term again from the re-evolved height)
         }
-        if (GRID && a.surf.viewshed.z) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
+        if (with_viewshed) view_bits |= viewshed_bits(a.surf, x[0], x[1]);
 #pragma unroll
         for (int o = 0; o < NOBS; ++o) {
           if (!live[o]) continue;
