@@ -54,14 +54,17 @@ atexit.register(_close_all)
 
 
 class DecodePool:
+    RING_BYTES = 512 << 20
+
     def __init__(self, n, slot_bytes, slots=None):
         from multiprocessing import resource_tracker
 
         resource_tracker.ensure_running()  # (one tracker for the parent and the decoders: see parallel.WorkerPool)
         ctx = mp.get_context("spawn")
         self.n, self.slot_bytes = n, int(slot_bytes)
-        self.slots = slots or 2 * n + 2
-        self.ring = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)
+        # two slots per decoder (one being filled, one on its way to the device) while the ring stays within RING_BYTES
+        self.slots = slots or max(4, min(2 * n + 2, self.RING_BYTES // max(1, self.slot_bytes)))
+        self.ring = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)  # (OSError: no room in /dev/shm)
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
         self.procs = [ctx.Process(target=_decode_main, args=(self.tasks, self.done, self.ring.name, self.slot_bytes),
                                   daemon=True) for _ in range(n)]

@@ -90,7 +90,11 @@ class SharedFrames:
 
         first = pixels(obs.images[0])
         n = len(obs.images)
-        shm = shared_memory.SharedMemory(create=True, size=max(1, n * first.nbytes))
+        try:
+            shm = shared_memory.SharedMemory(create=True, size=max(1, n * first.nbytes))
+        except OSError as e:
+            raise MemoryError(f"Tracker.track(parallel=...): no room in shared memory (/dev/shm) for an observer's "
+                              f"{n} frames of {first.nbytes} bytes: {e}") from e
         self.blocks.append(shm)
         block = np.ndarray((n,) + first.shape, first.dtype, buffer=shm.buf)
         block[0] = first

@@ -157,13 +157,17 @@ class _FrameFeed:
             if pool is None or not pool.alive() or pool.slot_bytes < slot or pool.n < want:
                 if pool is not None:
                     pool.close()
-                pool = tracker._decoders = ingest.DecodePool(want, slot)
+                try:
+                    pool = tracker._decoders = ingest.DecodePool(want, slot)
+                except OSError:  # (no room for the ring in shared memory: the threads below)
+                    pool = tracker._decoders = None
             else:
                 pool.drain()
-            self.procs = pool
-            self.stats["processes"] = pool.n
-            self.stats["pinned_ring"] = bool(pool.pinned)
-        elif len(on_disk) > 1:
+            if pool is not None:
+                self.procs = pool
+                self.stats["processes"] = pool.n
+                self.stats["pinned_ring"] = bool(pool.pinned)
+        if self.procs is None and len(on_disk) > 1:
             from concurrent.futures import ThreadPoolExecutor
 
             self.stats["threads"] = min(cores, len(on_disk))
