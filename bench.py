@@ -80,7 +80,7 @@ def parse_args(argv=None):
                          "of tracker.py:326-357 enqueued at once), 1 = one glh_step call per frame")
     ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2, 3, 4),
                     help="streams of glh_track's frame loop (glh_set_track_streams): 0 = the library's choice (two for "
-                         "batches of at least two rounds of workgroups per half), 1 = one launch per frame, 2 = two "
+                         "batches of more points than the chip has compute units), 1 = one launch per frame, 2 = two "
                          "half-batches on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the glimpse_amd.Tracker.track() leg (api_ms_per_step)")

@@ -56,6 +56,7 @@ SIGNATURES = {
     "glh_version": (_I, []),
     "glh_last_error": (C.c_char_p, []),
     "glh_device_count": (_I, [_P]),
+    "glh_device_compute_units": (_I, [_I, _P]),
     "glh_device_memory": (_I, [_I, _P, _P]),
     "glh_create": (_I, [_P, _P]),
     "glh_destroy": (_I, [_P]),
@@ -203,6 +204,12 @@ def host_unregister(address):
 def device_count():
     n = C.c_int(0)
     check(load().glh_device_count(C.byref(n)))
+    return n.value
+
+
+def device_compute_units(device_id=0):
+    n = C.c_int(0)
+    check(load().glh_device_compute_units(int(device_id), C.byref(n)))
     return n.value
 
 

@@ -320,6 +320,12 @@ extern "C" int glh_device_memory(int device_id, uint64_t* free_bytes, uint64_t* 
   return GLH_OK;
 }
 
+extern "C" int glh_device_compute_units(int device_id, int* count) {
+  if (!count) return fail(GLH_E_INVALID, "count is null");
+  HIPCHK(hipDeviceGetAttribute(count, hipDeviceAttributeMultiprocessorCount, device_id));
+  return GLH_OK;
+}
+
 extern "C" int glh_destroy(glh_ctx* c) {
   if (!c) return GLH_OK;
   (void)hipSetDevice(c->cfg.device_id);
@@ -1775,11 +1781,16 @@ extern "C" int glh_track(glh_ctx* c, int n_frames, const int32_t* frames, const 
   // -4 %; four ways: worse).  Same kernel, same per-point arithmetic: results are bit for bit those of one stream.
   int r2_bytes = 0;
   const bool fused_ok = c->fused && !c->have_active && !c->keep_sse && !c->have_extra && fused_plan(c, &r2_bytes);
-  const int slots = c->n_cus * (c->N > 10 * PT_BLK ? 1 : 2);  // workgroups the chip holds at once
+  // Automatic (round 5): two streams as soon as the batch has more points than the chip has compute units.  Round 4 asked
+  // for two full rounds of workgroups per half; but a launch ends with its slowest point (their lifetimes spread by 30 %),
+  // the halves' launches drift apart and fill each other's tails, and a batch of 1.5 rounds no longer runs a half-empty
+  // second one: same box, one -> two streams, C3 x 320 points -10.7 %, x 512 -9.4 %, x 768 -26 %, C5's per-GPU share (512
+  // points) -8.5 %, C4 x 384 -26 %, C2 x 512 -9 %; at one workgroup per CU or fewer (C2's 256 points: +2 %, C4 x 256: +-0)
+  // one stream (profiles/ab_r05/r5j23_streams_small.txt, r5j24_streams_threshold.txt).  Three streams: the same; four: worse.
   int ns = 1;
   if (fused_ok && !c->track_covariances) {
     if (c->track_streams >= 2) ns = c->track_streams;
-    else if (c->track_streams == 0 && c->P >= 2 * slots) ns = 2;
+    else if (c->track_streams == 0 && c->P > c->n_cus) ns = 2;
     if (const char* e = getenv("GLH_TRACK_STREAMS")) ns = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : ns;
     ns = std::min(ns, c->P);
   }

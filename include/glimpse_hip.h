@@ -131,6 +131,8 @@ int glh_device_count(int* count);
    workspaces by them (it re-runs a sequence with larger workspaces when a tile outgrows them, tracker.py has no such
    limit: its tiles live in host memory).                                                                              */
 int glh_device_memory(int device_id, uint64_t* free_bytes, uint64_t* total_bytes);
+/* Compute units of device `device_id`: what glh_track's automatic choice of streams compares a batch with.           */
+int glh_device_compute_units(int device_id, int* count);
 int glh_create(const glh_config* cfg, glh_ctx** out);
 int glh_destroy(glh_ctx* ctx);
 int glh_sync(glh_ctx* ctx);
@@ -285,8 +287,9 @@ int glh_track_covariances(glh_ctx* ctx, int on);
 /* Streams of glh_track's frame loop.  The tracks of the reference are independent (track/tracker.py:381-387 hands them
  * to a process pool); here the two halves of a large batch run their frame loops on two HIP streams, so that one
  * half's launch fills the compute units the other half's launch leaves idle while it drains and refills (bit for bit
- * the results of one stream).  0 (default) = automatic: two streams when each half is at least one full round of
- * workgroups; 1 = one stream; 2 = two streams whenever the fused step runs.                                           */
+ * the results of one stream).  0 (default) = automatic: two streams when the batch has more points than the device has
+ * compute units (a launch ends with its slowest point: the halves fill each other's tails); 1 = one stream; 2 = two
+ * streams whenever the fused step runs.                                                                                */
 int glh_set_track_streams(glh_ctx* ctx, int n);
 
 /* glh_step implementation: 1 (default) = the fused per-point kernel (weights + resample +

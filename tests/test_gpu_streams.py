@@ -48,3 +48,9 @@ def test_automatic_choice_follows_the_batch_size():
     wl = workloads.Workload("C3", n_frames=T, n_points=8, n_particles=256, imgsz=(512, 512))
     frames = [wl.frames(o) for o in range(wl.O)]
     assert _run(wl, frames, T, 0)["used"] == [1, 1]  # a handful of points: one launch per frame
+    # more points than the chip has compute units (256 on an MI355X): the two halves on two streams
+    cus = _lib.device_compute_units(0)
+    wl = workloads.Workload("C3", n_frames=T, n_points=cus + 8, n_particles=128, imgsz=(512, 512))
+    assert _run(wl, [wl.frames(0)], T, 0)["used"] == [2, 2]
+    wl = workloads.Workload("C3", n_frames=T, n_points=cus, n_particles=128, imgsz=(512, 512))
+    assert _run(wl, [wl.frames(0)], T, 0)["used"] == [1, 1]
