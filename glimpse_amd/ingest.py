@@ -124,12 +124,18 @@ class DecodePool:
     def release(self, slot):
         self.free.append(slot)
 
-    def drain(self):
-        """Forget everything in flight (a run that ended early): wait for the queued images, free their slots."""
+    def drain(self, timeout=60.0):
+        """Forget everything in flight (a run that ended early): wait for the queued images, free their slots.  A slot that
+        does not come back within `timeout` (its result was taken and never released) ends the pool: the next run makes
+        a new one."""
+        deadline = time.monotonic() + timeout
         while len(self.free) < self.slots and self.alive():
             try:
                 item = self.done.get(True, 0.05)
             except queue.Empty:
+                if time.monotonic() > deadline:
+                    self.close()
+                    return
                 continue
             self.free.append(item[1])
 

@@ -136,6 +136,84 @@ class SharedFrames:
         self.blocks = []
 
 
+class _ArrayRef:
+    """Stands in for a Raster's array while the Raster crosses a pipe: the pixels are in a shared-memory block."""
+
+    def __init__(self, name, shape, dtype):
+        self.name, self.shape, self.dtype = name, tuple(shape), dtype
+
+
+class SharedRasters:
+    """The arrays of the Rasters a parallel call sends along (a DEM, its uncertainty, the viewshed: tens of megabytes that
+    every model of a block references) in shared memory, once per array; `lent()` swaps them for references while the
+    jobs are pickled."""
+
+    def __init__(self):
+        self.blocks = {}  # id(array) -> (array kept alive, SharedMemory)
+
+    def ref(self, array):
+        key = id(array)
+        held = self.blocks.get(key)
+        if held is None or held[0] is not array:
+            a = np.ascontiguousarray(array)
+            shm = shared_memory.SharedMemory(create=True, size=max(1, a.nbytes))
+            np.ndarray(a.shape, a.dtype, buffer=shm.buf)[...] = a
+            held = self.blocks[key] = (array, shm, a.shape, a.dtype.str)
+        return _ArrayRef(held[1].name, held[2], held[3])
+
+    def lent(self, rasters):
+        """Context manager: inside it every Raster of `rasters` (arrays beyond _BIG only) holds an _ArrayRef."""
+        shared = self
+
+        class _Lend:
+            def __enter__(self):
+                self.saved = []
+                for r in rasters:
+                    a = getattr(r, "array", None)
+                    if isinstance(a, np.ndarray) and a.nbytes >= _BIG:
+                        self.saved.append((r, a))
+                        r.array = shared.ref(a)
+
+            def __exit__(self, *exc):
+                for r, a in self.saved:
+                    r.array = a
+
+        return _Lend()
+
+    def close(self):
+        for _, shm, _, _ in self.blocks.values():
+            try:
+                shm.close()
+                shm.unlink()
+            except (BufferError, FileNotFoundError, OSError):
+                pass
+        self.blocks = {}
+
+
+def _resolve_rasters(state, rasters):
+    """(worker) Rasters that arrived with an _ArrayRef get a read-only view of the shared block (attached once per block)."""
+    held = state.setdefault("raster_shm", {})
+    for r in rasters:
+        ref = getattr(r, "array", None)
+        if isinstance(ref, _ArrayRef):
+            if ref.name not in held:
+                held[ref.name] = shared_memory.SharedMemory(name=ref.name)
+            a = np.ndarray(ref.shape, np.dtype(ref.dtype), buffer=held[ref.name].buf)
+            a.flags.writeable = False
+            r.array = a
+
+
+def rasters_of(models, viewshed=None):
+    """The distinct Raster objects a block of motion models (and the Tracker's viewshed) brings."""
+    from .raster import Raster
+
+    seen = {}
+    for r in [viewshed] + [getattr(m, attr, None) for m in models for attr in ("dem", "dem_sigma")]:
+        if isinstance(r, Raster):
+            seen[id(r)] = r
+    return list(seen.values())
+
+
 def attach_observers(spec):
     """(worker) Observers whose images read from the shared blocks.  Returns (observers, blocks to keep alive)."""
     observers, keep = [], []
@@ -165,6 +243,7 @@ def _track_block(state, args):
     from .tracker import Tracker
 
     t0 = time.perf_counter()
+    _resolve_rasters(state, rasters_of(args["models"], args["tracker"].get("viewshed")))
     tracker = state.get("tracker")
     made = tracker is None
     if made:
@@ -254,7 +333,13 @@ def _result_block(state, spec):
     return np.ndarray(shape, np.float64, buffer=held[1].buf)
 
 
-_HANDLERS = {"track": _track_block, "digest": _frames_digest}
+def _rasters_digest(state, rasters):
+    """Diagnostic: crc32 of the arrays of the Rasters that came with the message (through shared memory when large)."""
+    _resolve_rasters(state, rasters)
+    return [(tuple(r.array.shape), zlib.crc32(np.ascontiguousarray(r.array).tobytes())) for r in rasters]
+
+
+_HANDLERS = {"track": _track_block, "digest": _frames_digest, "rasters": _rasters_digest}
 
 
 def _worker_main(conn, rank, world, device, token):
@@ -298,6 +383,11 @@ def _worker_main(conn, rank, world, device, token):
                 pass
         for shm in state["blocks"]:
             shm.close()
+        for shm in state.get("raster_shm", {}).values():
+            try:
+                shm.close()
+            except BufferError:
+                pass
 
 
 # ---- the pool (parent) ----------------------------------------------------------------------------
@@ -328,6 +418,7 @@ class WorkerPool:
         self.calls = 0
         self.frames = None  # SharedFrames the workers hold
         self.results = None  # shared-memory block the workers write the posterior history into
+        self.rasters = SharedRasters()  # arrays of the Rasters the calls send along
         self.procs, self.conns = [], []
         for rank in range(n):
             parent, child = ctx.Pipe()
@@ -437,6 +528,7 @@ class WorkerPool:
             except (BufferError, FileNotFoundError, OSError):
                 pass
             self.results = None
+        self.rasters.close()
         import shutil
 
         shutil.rmtree(sharding.FileStore.default_path(self.token), ignore_errors=True)

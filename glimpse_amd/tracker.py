@@ -930,7 +930,10 @@ class Tracker:
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
         t_ready = time.perf_counter()
-        replies = pool.call("track", jobs)
+        # (the arrays of the Rasters the models and the viewshed bring travel through shared memory, once: while the jobs
+        # are pickled the Rasters hold references instead)
+        with pool.rasters.lent(parallel.rasters_of(motion_models, self.viewshed)):
+            replies = pool.call("track", jobs)
         t_replied = time.perf_counter()
         parts = [{k: [parallel._import(x) for x in v] if isinstance(v, list) else parallel._import(v)
                   for k, v in part.items()} for part in replies]

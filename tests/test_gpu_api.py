@@ -366,6 +366,17 @@ def test_gridded_surfaces_end_to_end(golden):
         np.testing.assert_allclose(tracks.sigmas[ok], g[f"{name}_sigmas"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.particles[ok], g[f"{name}_particles"][ok], rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(tracks.weights[ok], g[f"{name}_weights"][ok], rtol=RTOL, atol=1e-290)
+        # the same tracks on two worker processes (device RNG: the parallel run draws what the single-process run draws);
+        # the surfaces' arrays reach the workers through shared memory (tests/test_parallel_pool.py)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            one = tracker.track(models, tile_size=(15, 15), rng="philox", seed=4)
+            two = tracker.track(models, tile_size=(15, 15), rng="philox", seed=4, parallel=2)
+        np.testing.assert_array_equal(two.means, one.means)
+        np.testing.assert_array_equal(two.sigmas, one.sigmas)
+        assert [type(e) for e in two.errors] == [type(e) for e in one.errors]
+        assert isinstance(dem.array, np.ndarray) and isinstance(viewshed.array, np.ndarray)
+        tracker.close()
 
 
 def test_motion_models_with_their_own_rasters(golden):

@@ -146,3 +146,32 @@ def test_decoder_processes_fill_the_shared_ring(tmp_path):
         name = pool.ring.name
         pool.close()
     assert not os.path.exists("/dev/shm/" + name.lstrip("/"))
+
+
+def test_raster_arrays_travel_through_shared_memory_once(pickled):
+    """The Rasters a parallel call sends along (a DEM and its uncertainty on every motion model, the viewshed): their arrays
+    go into shared memory once, the pipes carry references; the caller's Rasters have their arrays back after the call."""
+    rng = np.random.default_rng(2)
+    dem = glimpse_amd.Raster(rng.standard_normal((300, 400)), x=(0, 800), y=(600, 0))
+    small = glimpse_amd.Raster(np.ones((4, 5)), x=(0, 10), y=(8, 0))  # (below the threshold: pickled as it is)
+    models = [glimpse_amd.CartesianMotion(xy=(10.0 + k, 20.0), time_unit=DAY, dem=dem, dem_sigma=small, n=100,
+                                          xy_sigma=(0.2, 0.2), vxyz=(0.1, 0, 0), vxyz_sigma=(0.1, 0.1, 0)) for k in range(50)]
+    rasters = parallel.rasters_of(models, viewshed=None)
+    assert len(rasters) == 2 and any(r is dem for r in rasters)
+    pool = parallel.WorkerPool(2, [0, 0])
+    try:
+        want = [(r.array.shape, zlib.crc32(np.ascontiguousarray(r.array).tobytes())) for r in rasters]
+        for _ in range(2):
+            sent = sum(pickled)
+            with pool.rasters.lent(rasters):
+                assert isinstance(dem.array, parallel._ArrayRef) and isinstance(small.array, np.ndarray)
+                got = pool.call("rasters", [rasters, rasters])
+            assert got[0] == want and got[1] == want
+            assert isinstance(dem.array, np.ndarray) and dem.array.shape == (300, 400)
+            assert sum(pickled) - sent < 0.02 * dem.array.nbytes
+        assert len(pool.rasters.blocks) == 1  # (the second call found the block)
+        names = [held[1].name for held in pool.rasters.blocks.values()]
+    finally:
+        pool.close()
+    for name in names:
+        assert not os.path.exists("/dev/shm/" + name.lstrip("/"))
