@@ -2237,7 +2237,7 @@ __global__ __launch_bounds__(BLK) void k_spline_fit(SplineFitArgs a) {
     return;
   }
   if (spline_dense(ho, wo)) {
-    __shared__ double z1[GLH_SPL_DENSE_NINV / 2];  // ho * wo <= (ho^2 + wo^2) / 2
+    __shared__ double z1[GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX];
     spline_fit_dense<BLK>(z, z1, wo, ho, a.inv + spline_inverse_off(ho), a.inv + spline_inverse_off(wo));
     return;
   }

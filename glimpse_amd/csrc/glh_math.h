@@ -773,13 +773,17 @@ GLH_HD double knot_local(int i, int n) {
 }
 
 // interval q (0 <= q <= n-4) that holds local coordinate xl in [0, n-1]
-// The spline fit of a SMALL surface goes through the explicit inverses of the two collocation matrices
-// (glh_host.h: spline_inverse): small = both inverses fit in 512 doubles, i.e. one entry per thread of the fused
-// kernel and a few KB of LDS (sides up to 16 x 16, or e.g. 4 x 22).  Larger surfaces use the banded LU solves,
-// whose serial chains beat a dense product that has to stream its matrices from memory.
-constexpr int GLH_SPL_DENSE_MAX = 22;    // largest side that can satisfy the rule
-constexpr int GLH_SPL_DENSE_NINV = 512;  // ho^2 + wo^2 <= this
-GLH_HD bool spline_dense(int ho, int wo) { return ho * ho + wo * wo <= GLH_SPL_DENSE_NINV; }
+// The spline fit of a surface of up to GLH_SPL_DENSE_MAX coefficients a side goes through the explicit inverses of the two
+// collocation matrices (glh_host.h: spline_inverse): two dense products, every coefficient an independent dot product.
+// Larger surfaces use the banded LU solves -- two serial chains of n dependent steps per line.  Round 5 raised the bound
+// from "both inverses fit in 512 doubles" (16 x 16) to 40 x 40: phase stamps showed the banded fit at 15.7 k cycles for a
+// 19 x 20 surface against 3.2 k for the dense fit of an 11 x 11 one -- the points with the wider clouds, the slowest of
+// every launch, paid it (tools/experiments/slow_points.py).  Inverses of up to GLH_SPL_DENSE_NINV doubles (one entry per
+// thread of the fused kernel) are staged in LDS, larger ones are read from the table in memory (every workgroup reads the
+// same few: cache hits).
+constexpr int GLH_SPL_DENSE_MAX = 40;    // largest side fitted by explicit inverses
+constexpr int GLH_SPL_DENSE_NINV = 512;  // ho^2 + wo^2 <= this: the inverses are staged in LDS
+GLH_HD bool spline_dense(int ho, int wo) { return ho <= GLH_SPL_DENSE_MAX && wo <= GLH_SPL_DENSE_MAX; }
 GLH_HD int64_t spline_inverse_off(int n) {  // offset of the n x n inverse in the packed table (sizes 4 .. MAX)
   // sum_{m=4}^{n-1} m^2
   const int64_t k = n - 1;

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
     // small inverses (one entry per thread) are fetched before the SSD and parked in LDS after it, like the LU
     // factors of the larger surfaces: no memory latency inside the fit
     const int ninv = ho * ho + wo * wo;
-    const bool inv_lds = dense;  // (ninv <= 512 <= TB)
+    const bool inv_lds = dense && ninv <= GLH_SPL_DENSE_NINV;  // (<= TB: one entry per thread; larger ones stay in memory)
     const int l2 = dense ? 2 * zb + (inv_lds ? pt_align16(ninv * 8) : 0) : zb + pt_align16(5 * (ho + wo) * 8);
     const bool wide = SURF && ob.bits == 16;  // uniform: 16-bit frames (pt_tile_prep_wide), through the workspace branch
     const bool flt = SURF && ob.bits >= 32;   // uniform: float32 / float64 frames (glh_kernels.h: search_tile_from_boxf), likewise
@@ -1707,6 +1707,9 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
         PT_STAMP(4);
         if (!to_cells(Zl)) sample_all(Zl, std::false_type{});
       } else {
+        // (the surface stays in its HBM workspace; the scratch of a dense fit -- at most 40 x 40 doubles: fused_plan keeps
+        // that much of region 2 -- at the start of region 2, where everything is dead after the SSD)
+        if (dense) ws.Z1 = reinterpret_cast<double*>(r2);
         if (!linear) pt_spline_fit<TB>(ws, wo, ho);
         PT_STAMP(4);
         sample_all(ws.Z, std::false_type{});  // (a surface this large is beyond the cell form as well)

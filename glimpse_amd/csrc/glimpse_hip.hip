@@ -1517,7 +1517,10 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   // phase D/E: tree nodes | clast, then (over them) three rank tables of N uint16
   const int plan = std::max(pt_align16(c->nnodes * 8) + PT_BLK_BIG * 8, 3 * pt_align16(c->N * 2));
   // (the big-tile path parks the scratch surface of a dense spline fit behind the template tile)
-  const int r2_min = std::max(plan, pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_NINV / 2 * 8);
+  // (... and the scratch of a dense spline fit of the largest surface fitted that way, when that surface itself stays in its
+  // HBM workspace: glh_point.h, the last branch of the observer pass)
+  const int r2_min = std::max(plan, std::max(pt_small_bytes(c->tw, c->th, nb) + GLH_SPL_DENSE_NINV / 2 * 8,
+                                             pt_align16(GLH_SPL_DENSE_MAX * GLH_SPL_DENSE_MAX * 8)));
   // a 48 x 48 search tile of this template in LDS (what a ~2 px cloud needs)
   // (the template CDF lies over the search tile while the LUT is made: no bytes of its own)
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2;
