@@ -38,3 +38,8 @@ for k, n in enumerate(NAMES):
 a = st[:, 15:20]
 for label, x in (("A loop", a[:, 2] - a[:, 1]), ("A wait+reduce", a[:, 3] - a[:, 2]), ("A box", a[:, 4] - a[:, 3])):
     print(f"  {label:18s} all {np.median(x):8.0f}   slowest 5 % {np.median(x[slow]):8.0f}")
+print("  the three slowest points:")
+for p_ in np.argsort(tot)[-3:][::-1]:
+    tiles = ["%dx%d" % (bx[o][p_, 2] - bx[o][p_, 0], bx[o][p_, 3] - bx[o][p_, 1]) for o in range(wl.O)]
+    print(f"    point {p_}: lifetime {tot[p_]}, tiles {tiles}, phases " + " ".join(f"{n.split()[-1]}={d[p_, k]}" for k, n in enumerate(NAMES)))
+print("  the median point's tiles:", ["%dx%d" % (np.median(bx[o][:, 2] - bx[o][:, 0]), np.median(bx[o][:, 3] - bx[o][:, 1])) for o in range(wl.O)])
