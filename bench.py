@@ -1206,12 +1206,22 @@ def worker(args):
                 out["cpu_baseline_error"] = repr(e)
     if rank == 0:
         h = out["health"]
+        # The legs that lean on the operating system (worker and decoder processes, shared memory, image files in a
+        # temporary directory) report an exception under their own key and in `health.notes` -- a box without room in
+        # /dev/shm is not an unhealthy tracker --; a WRONG result of theirs is as fatal as any other.
+        host_legs = {k: v for k, v in out.get("secondary", {}).items() if k.startswith("C3_from_files")}
+        host_legs["api_parallel_2"] = out.get("api_parallel_2", {})
+        notes = [f"{k}: {v['error']}" for k, v in host_legs.items() if "error" in v]
+        if notes:
+            h["notes"] = notes
+        wrong = any(v.get("same_tracks_as_arrays") is False or v.get("same_as_single_process") is False
+                    for v in host_legs.values())
         if h["points_with_error_bits"] or h["observer_ok_fraction"] < 0.99 or not h["final_means_finite"] \
                 or h["gathered_moments_finite"] is False or out.get("api_last_means_finite") is False \
-                or "api_error" in out or "cpu_baseline_error" in out \
-                or "error" in out.get("api_parallel_2", {}) or out.get("api_parallel_2", {}).get("same_as_single_process") is False \
-                or any("error" in leg or leg.get("points_with_error_bits") or not leg.get("final_means_finite", True)
-                       or leg.get("observer_ok_fraction", 1.0) < 0.99 for leg in out.get("secondary", {}).values()):
+                or "api_error" in out or "cpu_baseline_error" in out or wrong \
+                or any(("error" in leg and k not in host_legs) or leg.get("points_with_error_bits")
+                       or not leg.get("final_means_finite", True) or leg.get("observer_ok_fraction", 1.0) < 0.99
+                       for k, leg in out.get("secondary", {}).items()):
             rc = 3
             out["health"]["verdict"] = "UNHEALTHY"
         _mark("done")
