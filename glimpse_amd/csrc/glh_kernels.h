@@ -379,14 +379,23 @@ __device__ __forceinline__ void evolve_particle(double* p, const double* m, cons
     }
     return;
   }
-  double z_off = p[2] - (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16]);
+  double z_old, z_new;
+  bool both = false;
+  if constexpr (FAST && GRID) {
+    // (fast arithmetic, the fused kernel's window: both samples at once -- the second usually in the first one's cell)
+    if (patches && m[20] != 0.0 && patches->full)
+      both = raster_sample_window2(patches, p[0], p[1], p[0] + dx, p[1] + dy, z_old, z_new, wins);
+  }
+  if (!both) z_old = GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16];
+  double z_off = p[2] - z_old;
   if constexpr (FAST)
     z_off = glh_fma(m[19] * n[2], sqrt_nr(glh_fma(dx, dx, dy * dy)), z_off);
   else
     z_off += m[19] * n[2] * sqrt(dx * dx + dy * dy);
   p[0] += dx;
   p[1] += dy;
-  p[2] = (GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16]) + z_off;
+  if (!both) z_new = GRID ? dem_at<FAST>(m, surf, p[0], p[1], oob, patches, wins) : m[16];
+  p[2] = z_new + z_off;
   if constexpr (FAST) {
     p[3] = glh_fma(tau, a[0], p[3]);
     p[4] = glh_fma(tau, a[1], p[4]);

@@ -504,6 +504,31 @@ GLH_HD bool raster_sample_window(const RasterPatch* p0, const RasterPatch* p1, d
   return okx & oky;  // (false: the values are of a clamped cell -- the caller samples the raster itself)
 }
 
+// ONE raster at TWO points through its window (the tangent models' step samples the surface under the particle before and
+// after the move, a fraction of a cell apart): the second point usually lies in the first one's cell -- g[i] < x <= g[i + 1]
+// on both axes, the very test that defines the interval -- and then takes its corners, coordinates and reciprocal widths:
+// no guess, no node reads.  Otherwise it is sampled on its own.  The same values as two calls of raster_sample_window.
+GLH_HD bool raster_sample_window2(const RasterPatch* p, double xa, double ya, double xb, double yb, double& va, double& vb,
+                                  const RasterWin* win = nullptr) {
+  int li, lj;
+  double tx, ty;
+  const bool okx = raster_window_axis(p->ax, win ? win->x0 : p->ax[0], win ? win->kx : p->fkx, xa, li, tx);
+  const bool oky = raster_window_axis(p->ay, win ? win->y0 : p->ay[0], win ? win->ky : p->fky, ya, lj, ty);
+  const double* z = p->z + lj * GLH_PATCH_W + li;
+  const double z00 = z[0], z10 = z[1], z01 = z[GLH_PATCH_W], z11 = z[GLH_PATCH_W + 1];
+  va = raster_bilinear_fast(z00, z10, z01, z11, tx, ty);
+  if (!(okx & oky)) return false;
+  // (the cell's own coordinates again: (x - g) * r and t agree only to rounding, so the test is made on g itself)
+  const double gxa = p->ax[2 * li], rxa = p->ax[2 * li + 1], gxb = p->ax[2 * li + 2];
+  const double gya = p->ay[2 * lj], rya = p->ay[2 * lj + 1], gyb = p->ay[2 * lj + 2];
+  if ((int)(gxa < xb) & (int)(xb <= gxb) & (int)(gya < yb) & (int)(yb <= gyb)) {
+    vb = raster_bilinear_fast(z00, z10, z01, z11, (xb - gxa) * rxa, (yb - gya) * rya);
+    return true;
+  }
+  double unused;
+  return raster_sample_window<false>(p, p, xb, yb, vb, unused, win);
+}
+
 // order 1: bilinear (RegularGridInterpolator method 'linear'); order 0: 'nearest'.  Sets *oob when the
 // point is outside the raster's outer limits (the reference raises ValueError there).  `patch`: a window of THIS raster
 // (or null); a sample whose interval and its neighbours lie inside is read from it -- same values, same arithmetic.
