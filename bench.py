@@ -693,7 +693,7 @@ def from_files_leg(wl, frames, n_frames, seed, device, fmt, compute_only_seconds
             "decode_bound_seconds": st["decode_seconds"] / max(1, st["threads"] + st.get("processes", 0)),
             "upload_staging_seconds": st["upload_seconds"],
             "upload_staging_GBps": st["bytes"] / max(st["upload_seconds"], 1e-9) / 1e9,
-            "frame_loop_waited_for_decoders_seconds": st["wait_seconds"],
+            "frame_loop_waited_for_decoders_seconds": st["wait_seconds"], "glh_track_calls": st.get("track_calls"),
             "compute_only_call_seconds": compute_only_seconds,
             "gpu_idle_share": max(0.0, 1.0 - compute_only_seconds / wall),
             "same_tracks_as_arrays": same and same_again,

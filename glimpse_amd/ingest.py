@@ -22,6 +22,7 @@ import numpy as np
 
 def _decode_main(tasks, done, ring_name, slot_bytes):
     """One decoder process: (job, image, slot) -> the image's pixels at its camera size in ring[slot]."""
+    os.environ["GLH_POOL_CHILD"] = "1"
     ring = shared_memory.SharedMemory(name=ring_name)
     try:
         while True:
@@ -59,6 +60,10 @@ class DecodePool:
     def __init__(self, n, slot_bytes, slots=None):
         from multiprocessing import resource_tracker
 
+        from .parallel import _in_child, without_main
+
+        if _in_child():
+            raise RuntimeError("a glimpse_amd worker process tried to start image decoders")
         resource_tracker.ensure_running()  # (one tracker for the parent and the decoders: see parallel.WorkerPool)
         ctx = mp.get_context("spawn")
         self.n, self.slot_bytes = n, int(slot_bytes)
@@ -68,8 +73,9 @@ class DecodePool:
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
         self.procs = [ctx.Process(target=_decode_main, args=(self.tasks, self.done, self.ring.name, self.slot_bytes),
                                   daemon=True) for _ in range(n)]
-        for p in self.procs:
-            p.start()
+        with without_main():  # (the decoders never run the caller's main script: parallel.without_main)
+            for p in self.procs:
+                p.start()
         self.free = list(range(self.slots))
         # The ring page-locked for the device (hipHostRegister): the parent then uploads a slot without the copy into a
         # staging buffer (glh_observer_upload_frame_pinned).  Without a device (or if the driver refuses) the slots are

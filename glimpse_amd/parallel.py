@@ -35,6 +35,46 @@ log = logging.getLogger("glimpse_amd")
 _BIG = 1 << 16  # arrays of a reply beyond this many bytes travel through shared memory, not the pipe
 
 
+class without_main:
+    """Context manager: processes started inside it (spawn) do NOT import the parent's `__main__` module again.
+
+    multiprocessing's spawn re-runs the main script in every child (as `__mp_main__`) so that objects defined there can be
+    unpickled; a script without an `if __name__ == "__main__":` guard then runs whole in every child -- tracking, starting
+    pools of its own, opening the GPU fifteen times.  The decoder processes of a run from image files are started by a plain
+    `Tracker.track()` call: nobody expects to guard a script for that, and nothing they receive is defined in `__main__`.
+    The workers of `track(parallel=N)` skip the import too unless a motion model or a `reduce_particles` function comes from
+    `__main__` (then the script needs its guard, as every multiprocessing program does)."""
+
+    def __enter__(self):
+        import multiprocessing.spawn as spawn
+
+        self._spawn, self._orig = spawn, spawn.get_preparation_data
+
+        def prep(name):
+            d = self._orig(name)
+            d.pop("init_main_from_path", None)
+            d.pop("init_main_from_name", None)
+            return d
+
+        spawn.get_preparation_data = prep
+
+    def __exit__(self, *exc):
+        self._spawn.get_preparation_data = self._orig
+
+
+class _with_main:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+def _in_child():
+    """This process is a worker / decoder of glimpse_amd: it must not start pools of its own."""
+    return os.environ.get("GLH_POOL_CHILD") == "1"
+
+
 # ---- arrays through shared memory -----------------------------------------------------------------
 def _export(a):
     """ndarray -> a picklable handle (the bytes in a shared-memory block the receiver unlinks); small arrays as they are."""
@@ -344,7 +384,7 @@ _HANDLERS = {"track": _track_block, "digest": _frames_digest, "rasters": _raster
 
 def _worker_main(conn, rank, world, device, token):
     """The loop of one worker process."""
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), GLH_RENDEZVOUS_TOKEN=token,
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), GLH_RENDEZVOUS_TOKEN=token, GLH_POOL_CHILD="1",
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     store = sharding.FileStore(sharding.FileStore.default_path(token), rank, world) if world > 1 else None
     state = {"group": sharding.Group(rank, world, rank, store), "device": device, "observers": None, "blocks": []}
@@ -406,8 +446,12 @@ class WorkerPool:
     """`n` persistent worker processes.  `call(kind, [args per worker])` sends one message to every worker and returns
     their replies in order; a worker that dies or raises takes the call down with a RuntimeError (and the pool with it)."""
 
-    def __init__(self, n, devices):
+    def __init__(self, n, devices, import_main=False):
+        if _in_child():
+            raise RuntimeError("a glimpse_amd worker process tried to start workers of its own: the main script runs again "
+                               "in every worker -- put it behind `if __name__ == '__main__':`")
         ctx = mp.get_context("spawn")  # fresh interpreters: the parent may have initialised the GPU runtime
+        self.import_main = bool(import_main)
         # ONE resource tracker for the parent and the workers (started here, before they are: they inherit it): a block made
         # on one side and unlinked on the other is then registered and unregistered in the same place
         from multiprocessing import resource_tracker
@@ -423,7 +467,8 @@ class WorkerPool:
         for rank in range(n):
             parent, child = ctx.Pipe()
             p = ctx.Process(target=_worker_main, args=(child, rank, n, devices[rank], self.token), daemon=True)
-            p.start()
+            with (_with_main() if self.import_main else without_main()):
+                p.start()
             child.close()
             self.procs.append(p)
             self.conns.append(parent)

@@ -724,6 +724,7 @@ class Tracker:
                         while j + 1 <= min(hi, through) and common(j + 1):
                             j += 1
                         ctx.track(list(range(i, j + 1)), taus[i - 1:j], [images_of(k) for k in range(i, j + 1)], seed=seed)
+                        feed.stats["track_calls"] = feed.stats.get("track_calls", 0) + 1
                         deferred.append((i, j))
                         i = j + 1
                         continue
@@ -894,11 +895,15 @@ class Tracker:
         t_start = time.perf_counter()
         ntracks = len(motion_models)
         ndev = max(1, _lib.device_count())
+        # (objects defined in the caller's main script can only be unpickled by workers that run that script again -- which
+        # then needs its `if __name__ == "__main__":` guard; everything else starts workers that do not)
+        from_main = any(getattr(type(m), "__module__", "") == "__main__" for m in motion_models) or \
+            getattr(kw.get("reduce_particles"), "__module__", "") == "__main__"
         pool = getattr(self, "_pool", None)
-        if pool is None or pool.n != workers or not pool.alive():
+        if pool is None or pool.n != workers or not pool.alive() or (from_main and not pool.import_main):
             if pool is not None:
                 pool.close()
-            pool = self._pool = parallel.WorkerPool(workers, [w % ndev for w in range(workers)])
+            pool = self._pool = parallel.WorkerPool(workers, [w % ndev for w in range(workers)], import_main=from_main)
         shared = pool.share(self.observers)
         mask = None if observer_mask is None else np.asarray(observer_mask, dtype=bool)
         seeds = np.random.randint(0, 2 ** 31 - 1, size=workers) if rng == "numpy" else [None] * workers

@@ -175,3 +175,32 @@ def test_raster_arrays_travel_through_shared_memory_once(pickled):
         pool.close()
     for name in names:
         assert not os.path.exists("/dev/shm/" + name.lstrip("/"))
+
+
+def test_pools_do_not_run_an_unguarded_main_script_again(tmp_path):
+    """A script WITHOUT `if __name__ == "__main__":` that starts decoders and workers at its top level: multiprocessing's
+    spawn would run it again in every child (each starting pools of its own); glimpse_amd's children skip the import of
+    the parent's main module (parallel.without_main), so the script runs exactly once."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "unguarded.py"
+    marker = tmp_path / "ran.txt"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+with open({str(marker)!r}, "a") as f:
+    f.write("run\\n")
+from glimpse_amd import ingest, parallel
+pool = ingest.DecodePool(2, 1 << 16, slots=4)
+assert pool.alive()
+pool.close()
+workers = parallel.WorkerPool(2, [0, 0])
+assert workers.call("rasters", [[], []]) == [[], []]
+workers.close()
+print("done")
+""")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith("done")
+    assert marker.read_text() == "run\n"
