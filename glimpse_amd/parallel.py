@@ -115,10 +115,14 @@ class SharedFrames:
             self.close()
             raise
         self.key = self.key_of(observers)  # (after the reads: a cached read has put its array on the image)
+        # the key is made of object identities: the objects stay alive as long as the key is compared with (an array freed
+        # and another allocated at its address would otherwise pass for the one that was shared)
+        self._alive = [(obs, list(obs.images), [getattr(img, "array", None) for img in obs.images]) for obs in observers]
 
     @staticmethod
     def key_of(observers):
-        """What the shared copy is a copy OF: the image objects (and their pixel arrays), in order."""
+        """What the shared copy is a copy OF: the image objects (and their pixel arrays), in order.  (Pixels changed IN
+        PLACE are not seen: `Tracker.forget_frames()` makes the next parallel call share the frames again.)"""
         return tuple((id(obs), obs.sigma, tuple((id(img), id(getattr(img, "array", None))) for img in obs.images))
                      for obs in observers)
 
@@ -174,6 +178,7 @@ class SharedFrames:
             except (FileNotFoundError, OSError):
                 pass
         self.blocks = []
+        self._alive = []
 
 
 class _ArrayRef:

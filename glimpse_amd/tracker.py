@@ -1016,8 +1016,12 @@ class Tracker:
         return tracks
 
     def forget_frames(self):
-        """The next run reads and uploads every frame again (the files or arrays behind the images have changed)."""
+        """The next run reads and uploads every frame again (the files or arrays behind the images have changed); the
+        next parallel run shares them with its workers again."""
         self._uploaded = set()
+        pool = getattr(self, "_pool", None)
+        if pool is not None and pool.frames is not None:
+            pool.frames.key = None
 
     def close(self):
         """Release the device contexts and the worker processes of `track(parallel=N)` (they are kept between calls)."""

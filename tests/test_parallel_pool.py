@@ -65,6 +65,12 @@ def test_frames_reach_the_workers_through_shared_memory_only(pickled):
         assert pool.share(observers) is True
         digest = pool.call("digest", [None, None])[1]
         assert digest[0][2][1] == zlib.crc32(observers[0].images[1].array.tobytes())
+        # pixels changed IN PLACE are not noticed by themselves; after Tracker.forget_frames() (the key is dropped) they are
+        observers[1].images[0].array[...] = 7
+        assert pool.share(observers) is False
+        pool.frames.key = None
+        assert pool.share(observers) is True
+        assert pool.call("digest", [None, None])[0][1][2][0] == zlib.crc32(observers[1].images[0].array.tobytes())
         # the caller's images keep their own arrays (the workers got copies of the objects without pixels)
         assert all(img.array is not None and img.array.flags.writeable for obs in observers for img in obs.images)
     finally:
