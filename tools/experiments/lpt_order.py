@@ -61,7 +61,31 @@ def main():
               "random": np.random.default_rng(0).permutation(P),
               # the caller's order dealt alternately to the two halves (what an interleaved split of the streams would run,
               # but with each half contiguous in memory)
-              "evens, odds": np.concatenate([ids[0::2], ids[1::2]])}
+              "evens, odds": np.concatenate([ids[0::2], ids[1::2]]),
+              # blocks of 64 neighbours dealt alternately: the streams balanced, neighbours still dispatched together
+              "blocks of 64": np.concatenate([ids.reshape(-1, 64)[0::2].ravel(), ids.reshape(-1, 64)[1::2].ravel()])
+              if P % 128 == 0 else ids,
+              "blocks of 256": np.concatenate([ids.reshape(-1, 256)[0::2].ravel(), ids.reshape(-1, 256)[1::2].ravel()])
+              if P % 512 == 0 else ids,
+              # sorted but NOT dealt: the slow half on one stream, the fast half on the other
+              "slow half, fast half": desc}
+    if os.environ.get("LPT_ONLY"):
+        orders = {k: v for k, v in orders.items() if k in os.environ["LPT_ONLY"].split(";")}
+    # each half alone on one stream: are the halves of the caller's order equally expensive?
+    for label, (lo, hi) in (("first half alone", (0, half)), ("second half alone", (half, P))):
+        w = wl.slice(lo, hi)
+        c = context(w)
+        c.set_track_streams(1)
+        ts = []
+        for rep in range(3):
+            start(c, w)
+            fr = list(range(1, T))
+            t0 = time.perf_counter()
+            c.track(fr, [1.0] * len(fr), [[j] * w.O for j in fr], seed=1)
+            c.sync()
+            ts.append(1e3 * (time.perf_counter() - t0) / (T - 1))
+        c.close()
+        print(f"  {label:22s} {min(ts[1:]):.4f} ms/frame (one stream, {hi - lo} points)", flush=True)
     # ONE context alive at a time: every context brings its own two streams, and the streams of a process share a few
     # hardware queues -- with four contexts alive the last one's two streams shared a queue (first version of this script:
     # "random" 17 .. 65 % slower, an artefact)
@@ -82,7 +106,7 @@ def main():
             c.close()
     for label in orders:
         t = sorted(times[label])
-        print(f"  {label:14s} median {t[len(t) // 2]:.4f} ms/frame  min {t[0]:.4f} max {t[-1]:.4f}", flush=True)
+        print(f"  {label:22s} median {t[len(t) // 2]:.4f} ms/frame  min {t[0]:.4f} max {t[-1]:.4f}", flush=True)
 
 
 if __name__ == "__main__":
