@@ -31,6 +31,9 @@ namespace glh {
 // Two observers, plain code (round 5, experiment -DGLH_PT_RECOMP=1): observer 1's coordinates and the DEM term are not
 // parked in memory between phase A and phase C (32 + 16 bytes per particle-frame through the uv scratch and the weights
 // scratch) -- phase C re-evolves the particle from its pre-evolve record, like the gather does, and projects it again.
+#ifndef GLH_PT_PRIO
+#define GLH_PT_PRIO 0
+#endif
 #ifndef GLH_PT_RECOMP
 #define GLH_PT_RECOMP 0
 #endif
@@ -1260,6 +1263,24 @@ __global__ __launch_bounds__(TB, MINW) void k_point_step(PointArgs a) {
   }
 
   PT_STAMP(1);
+#if GLH_PT_PRIO
+  {
+    // experiment (round 5): a workgroup whose search tiles are large -- the slow point a launch of one round ends with --
+    // takes issue priority over its neighbour on the compute unit for the rest of its life
+    int area = 0, nok = 0;
+#pragma unroll
+    for (int o = 0; o < NOBS; ++o)
+      if (s_status[o] == GLH_OBS_OK) {
+        area += (s_box[o][2] - s_box[o][0]) * (s_box[o][3] - s_box[o][1]);
+        ++nok;
+      }
+    area = __builtin_amdgcn_readfirstlane(area);
+    const int base = __builtin_amdgcn_readfirstlane(nok) * (a.tw + 8) * (a.th + 8);
+    if (area * 2 > base * 4) __builtin_amdgcn_s_setprio(3);
+    else if (area * 2 > base * 3) __builtin_amdgcn_s_setprio(2);
+    else if (area * 4 > base * 5) __builtin_amdgcn_s_setprio(1);
+  }
+#endif
   // ---------------- B + C per observer, in the reference's order (tracker.py:139-146) ----------
   bool outside = false;
   const bool w_here = NOBS == 1 && !a.has_dem;  // uniform: phase C of observer 0 writes weights, not log likelihoods
