@@ -606,7 +606,7 @@ def api_leg(wl, frames, n_frames, seed, device, max_search_dim):
             "shared_frame_bytes": info["shared_frame_bytes"],
             "same_as_single_process": bool(np.array_equal(par.means, tracks.means, equal_nan=True)
                                            and np.array_equal(par.sigmas, tracks.sigmas, equal_nan=True)),
-            "note": "overhead = the call's wall time beyond the slower worker's own Tracker.track(): pickled models out, "
+            "note": "overhead = the call's wall time beyond the slower worker's own Tracker.track(): parameter tables out, "
                     "errors / warnings and the history back; on ONE GPU the two workers share the device, so the call "
                     "cannot be faster than the single-process one"}
     except Exception as e:  # noqa: BLE001

@@ -50,6 +50,8 @@ def params_table(models):
     """[P][GLH_MOTION_FULL_LEN] table of glh_set_motion for a list of motion models: `fill_params` of every model,
     column by column when all of them are Cartesian / Cylindrical models (thousands of rows per run: one NumPy
     concatenation per parameter instead of a dozen slice assignments per model)."""
+    if isinstance(models, ModelBlock):
+        return models.table
     P = len(models)
     table = np.zeros((P, 24))
     kinds = set(map(type, models))
@@ -84,6 +86,60 @@ def params_table(models):
     for row, model in zip(table, models):
         model.fill_params(row)
     return table
+
+
+class _RowView:
+    """What the batched Tracker reads of ONE model of a `ModelBlock` (it never calls a device model's methods)."""
+
+    __slots__ = ("xy", "n", "time_unit", "dem", "dem_sigma", "KIND", "TANGENT")
+
+    def __init__(self, block, i):
+        row = block.table[i]
+        self.xy = row[0:2]
+        self.n, self.time_unit = block.n, block.time_unit
+        self.dem = block.dem if row[20] else float(row[16])
+        self.dem_sigma = block.dem_sigma if row[21] else float(row[17])
+        self.KIND = int(row[18])
+        self.TANGENT = self.KIND in (2, 3)
+
+
+class ModelBlock:
+    """A block of DEVICE motion models that share one batch (one particle count, one time unit, at most one gridded dem
+    and one gridded dem_sigma: `tracker._batches`) as ONE parameter table: everything the batched Tracker uses of them
+    (`params_table`, the rasters, n, time_unit).  `Tracker.track(parallel=N)` hands its workers their tracks in this
+    form -- thousands of model objects cost more to pickle and unpickle than their tracks take to run (4 096
+    CartesianMotion objects: 25 ms; their table: 0.8 MB in one piece).  A read-only sequence: an index gives a view of
+    that model's parameters (not a model: no methods), a slice another block."""
+
+    def __init__(self, table, n, time_unit, dem=None, dem_sigma=None):
+        self.table = np.ascontiguousarray(table, dtype=np.float64)
+        self.n, self.time_unit = int(n), time_unit
+        self.dem, self.dem_sigma = dem, dem_sigma  # the Raster of the rows flagged in columns 20 / 21, or None
+
+    @classmethod
+    def from_models(cls, models):
+        """Of a list of device models that `tracker._batches` holds in one batch."""
+        table = params_table(models)
+        rasters = []
+        for col, attr in ((20, "dem"), (21, "dem_sigma")):
+            rows = np.nonzero(table[:, col])[0]
+            rasters.append(getattr(models[int(rows[0])], attr) if len(rows) else None)
+        return cls(table, models[0].n, models[0].time_unit, *rasters)
+
+    def __len__(self):
+        return len(self.table)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return ModelBlock(self.table[i], self.n, self.time_unit, self.dem, self.dem_sigma)
+        return _RowView(self, int(i))
+
+    def __iter__(self):
+        return (_RowView(self, i) for i in range(len(self.table)))
+
+    def raster(self, attr):
+        """The Raster some row uses as its `attr` ("dem" / "dem_sigma"), or None."""
+        return getattr(self, attr) if self.table[:, 20 if attr == "dem" else 21].any() else None
 
 
 class Motion:

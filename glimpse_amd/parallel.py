@@ -7,7 +7,8 @@ The reference maps `process` over the tracks on `parallel` CPU processes.  Here 
   context each on GPU (worker mod device count), kept between `track` calls -- a second call finds its context, its
   uploaded frames and its workspaces in place;
 * the observers' frames travel ONCE, through `multiprocessing.shared_memory` blocks the workers map (never pickled:
-  what crosses the pipes is the motion models, a few arguments, and per-track errors / warnings);
+  what crosses the pipes is the tracks' parameter table -- `motion.ModelBlock`; the model objects themselves only for
+  blocks that are not one device batch --, a few arguments, and per-track errors / warnings);
 * every worker tracks a contiguous block of the tracks with `point_offset` = its first track (the device RNG is keyed
   on the global track index: the parallel run draws what the single-process run draws);
 * the posterior history [T][P][12] and the status words are collected on worker 0 with ONE exchange -- the grouped
@@ -250,10 +251,15 @@ def _resolve_rasters(state, rasters):
 
 def rasters_of(models, viewshed=None):
     """The distinct Raster objects a block of motion models (and the Tracker's viewshed) brings."""
+    from .motion import ModelBlock
     from .raster import Raster
 
     seen = {}
-    for r in [viewshed] + [getattr(m, attr, None) for m in models for attr in ("dem", "dem_sigma")]:
+    if isinstance(models, ModelBlock):
+        brought = [models.dem, models.dem_sigma]
+    else:
+        brought = [getattr(m, attr, None) for m in models for attr in ("dem", "dem_sigma")]
+    for r in [viewshed] + brought:
         if isinstance(r, Raster):
             seen[id(r)] = r
     return list(seen.values())
@@ -539,7 +545,12 @@ class WorkerPool:
 
     def result_array(self, shape):
         """A COPY of the block's contents as (tracks, times, 12)."""
-        return np.array(np.ndarray(shape, np.float64, buffer=self.results.buf))
+        return np.array(self.result_view(shape))
+
+    def result_view(self, shape):
+        """The block's contents as (tracks, times, 12) WITHOUT a copy: to be read and dropped before the next call (the
+        workers write into the same pages) and before the pool is closed."""
+        return np.ndarray(shape, np.float64, buffer=self.results.buf)
 
     def share(self, observers):
         """The workers see these observers' frames (shared once; again only when the image objects changed)."""

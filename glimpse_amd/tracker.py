@@ -21,7 +21,7 @@ import warnings as _warnings
 import numpy as np
 
 from . import _lib
-from .motion import (CartesianMotion, CylindricalMotion, TangentCartesianMotion, TangentCylindricalMotion,
+from .motion import (CartesianMotion, CylindricalMotion, ModelBlock, _RowView, TangentCartesianMotion, TangentCylindricalMotion,
                      params_table)
 from .raster import Raster
 from .timeutil import _US, _offsets_us, nearest_in_sorted  # noqa: F401  (re-exported)
@@ -47,7 +47,7 @@ def _on_device(model):
     """The four motion models of the reference are initialised and evolved on the device.  Anything else -- a
     subclass that overrides them, or any object with the interface of motion.py:13-89 -- is a user-defined model: its
     own initialize_particles / evolve_particles / compute_log_likelihoods run on the host, as the user wrote them."""
-    return type(model) in _DEVICE_MODELS
+    return type(model) in _DEVICE_MODELS or isinstance(model, _RowView)
 
 
 _GET_N = operator.attrgetter("n")
@@ -72,6 +72,8 @@ def _batches(models):
     parameters of the point and mix freely); a user-defined model is a run of its own."""
     # the usual batch -- thousands of device models with one particle count and constant surfaces -- is recognised by
     # sets built at C speed; anything else takes the loop below
+    if isinstance(models, ModelBlock):  # (made of one batch: motion.ModelBlock)
+        return [0]
     models = list(models)
     if models and set(map(type, models)) <= set(_DEVICE_MODELS) and len(set(map(_GET_N, models))) == 1 \
             and not _any_raster(models, "dem") and not _any_raster(models, "dem_sigma"):
@@ -544,13 +546,19 @@ class Tracker:
         s_h = np.sqrt(np.max(t[:, 2:4], axis=1) ** 2 + (free * sv) ** 2 + (0.5 * free ** 2 * sa) ** 2)
         s_z = np.sqrt(t[:, 17] ** 2 + (free * (vs[:, 2] + t[:, 19] * sv)) ** 2 + (0.5 * free ** 2 * as_[:, 2]) ** 2)
         z0 = t[:, 16].copy()
-        for p, m in enumerate(motion_models):
-            if isinstance(m.dem, Raster):
-                z = m.dem.sample(np.atleast_2d(np.asarray(m.xy, dtype=float)), bounds_error=False)[0]
-                z0[p] = z if np.isfinite(z) else 0.0
-            if isinstance(m.dem_sigma, Raster):
-                z = m.dem_sigma.sample(np.atleast_2d(np.asarray(m.xy, dtype=float)), bounds_error=False)[0]
-                s_z[p] = np.hypot(s_z[p], z if np.isfinite(z) else 0.0)
+        # rows over gridded surfaces (columns 20 / 21): the surface under the starting point, ONE sample call per Raster
+        for col, attr in ((20, "dem"), (21, "dem_sigma")):
+            by_raster = {}
+            for p in np.nonzero(t[:, col])[0]:
+                r = getattr(motion_models[int(p)], attr)
+                by_raster.setdefault(id(r), (r, []))[1].append(int(p))
+            for r, rows in by_raster.values():
+                z = np.asarray(r.sample(t[rows, 0:2], bounds_error=False), dtype=float)
+                z = np.where(np.isfinite(z), z, 0.0)
+                if attr == "dem":
+                    z0[rows] = z
+                else:
+                    s_z[rows] = np.hypot(s_z[rows], z)
         P = len(motion_models)
         base = np.column_stack((t[:, 0:2], z0))
         pts = np.concatenate((base, base + np.column_stack((s_h, np.zeros(P), np.zeros(P))),
@@ -583,6 +591,9 @@ class Tracker:
         """One gridded dem, one dem_sigma (shared by every model of the batch that uses a raster: `_batches` splits the
         tracks accordingly) and the viewshed."""
         for which, attr in ((_lib.RASTER_DEM, "dem"), (_lib.RASTER_DEM_SIGMA, "dem_sigma")):
+            if isinstance(motion_models, ModelBlock):
+                ctx.set_raster(which, motion_models.raster(attr))
+                continue
             rasters = {}
             if _any_raster_safe(motion_models, attr):  # (checked on the attribute types first: thousands of models)
                 rasters = {id(getattr(m, attr)): getattr(m, attr) for m in motion_models
@@ -600,10 +611,11 @@ class Tracker:
         params = dict(motion_models=motion_models, datetimes=datetimes, maxdt=maxdt, tile_size=tile_size,
                       observer_mask=observer_mask, return_covariances=return_covariances,
                       return_particles=return_particles, reduce_particles=reduce_particles, parallel=parallel)
-        time_unit = motion_models[0].time_unit
-        if len(set(map(_GET_TIME_UNIT, motion_models))) > 1:  # (equal timedeltas hash alike: one pass at C speed)
+        block = isinstance(motion_models, ModelBlock)  # (a worker's tracks as one parameter table: checked where it was made)
+        time_unit = motion_models.time_unit if block else motion_models[0].time_unit
+        if not block and len(set(map(_GET_TIME_UNIT, motion_models))) > 1:  # (equal timedeltas hash alike: one pass at C speed)
             raise ValueError("Motion models must have equal time units")
-        if not set(map(type, motion_models)) <= set(_DEVICE_MODELS):
+        if not block and not set(map(type, motion_models)) <= set(_DEVICE_MODELS):
             for model in motion_models:
                 if not _on_device(model) and not (callable(getattr(model, "initialize_particles", None))
                                                   and callable(getattr(model, "evolve_particles", None))):
@@ -927,9 +939,13 @@ class Tracker:
                 result = pool.result_block((ntracks, len(dts), 12))
             except Exception:  # noqa: BLE001  (the workers raise it properly)
                 result = None
+        # what a worker gets of its tracks: ONE parameter table when the block is one device batch (`gather`: every block
+        # is) -- thousands of model objects cost more to pickle and unpickle than their tracks take to run --, the model
+        # objects otherwise
         jobs = []
         for w, (a, b) in enumerate(bounds):
-            jobs.append(dict(tracker=settings, models=motion_models[a:b], np_seed=seeds[w], catch=ntracks >= 2,
+            models = ModelBlock.from_models(motion_models[a:b]) if gather else motion_models[a:b]
+            jobs.append(dict(tracker=settings, models=models, np_seed=seeds[w], catch=ntracks >= 2,
                              gather=gather, sizes=sizes, call=pool.calls, want_last=w == workers - 1, result=result,
                              rows=(a, b),
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
@@ -956,7 +972,8 @@ class Tracker:
         transport = parts[0]["transport"] if gather else "host"
         in_block = [part.get("in_block") for part in parts]
         want_sigmas = not kw.get("return_covariances")
-        full = pool.result_array(result[1]) if result is not None and any(in_block) else None  # (tracks, times, 12)
+        # (a view of the shared block: means / sigmas below are the copies that leave this function)
+        full = pool.result_view(result[1]) if result is not None and any(in_block) else None  # (tracks, times, 12)
         if transport == "rccl":
             # worker 0 received every worker's history (T, sum P, 12) and wrote it into the block (or sent it, when there was
             # no block); rows of a failed track are NaN from the frame where it failed -- what the workers' own copies hold
@@ -972,6 +989,10 @@ class Tracker:
                     if sigmas is not None:
                         sigmas[lo + p, e:] = np.nan
                 lo += n
+        elif full is not None and all(tag == "rows" for tag in in_block):
+            # every worker wrote its rows into the block: one copy out of it per array
+            means = np.ascontiguousarray(full[:, :, 0:6])
+            sigmas = np.ascontiguousarray(full[:, :, 6:12]) if want_sigmas else None
         else:
             mparts, sparts = [], []
             for part, (a, b) in zip(parts, bounds):
@@ -990,10 +1011,10 @@ class Tracker:
                 return [row for v in values for row in v]
 
             means, sigmas = join(mparts), join(sparts)
-            if gather:
-                why = next((part["why_host"] for part in parts if part.get("why_host")), "")
-                parallel.log.warning("Tracker.track(parallel=%d): no RCCL communicator (%s); the posterior history was "
-                                     "collected through host memory", workers, why or "unavailable")
+        if gather and transport != "rccl":
+            why = next((part["why_host"] for part in parts if part.get("why_host")), "")
+            parallel.log.warning("Tracker.track(parallel=%d): no RCCL communicator (%s); the posterior history was "
+                                 "collected through host memory", workers, why or "unavailable")
         if ntracks < 2 and errors[0] is not None:
             raise errors[0]
         self.particles, self.weights = parts[-1]["last_particles"], parts[-1]["last_weights"]

@@ -210,3 +210,46 @@ print("done")
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().endswith("done")
     assert marker.read_text() == "run\n"
+
+
+def test_a_block_of_models_travels_as_one_parameter_table():
+    """motion.ModelBlock: what `Tracker.track(parallel=N)` sends a worker instead of thousands of model objects -- the
+    parameter table the batched Tracker reads, the rasters, n and the time unit; views of single models for the few
+    places that look one up."""
+    import pickle
+
+    from glimpse_amd import tracker as tracker_module
+    from glimpse_amd.motion import ModelBlock, params_table
+
+    rng = np.random.default_rng(5)
+    dem = glimpse_amd.Raster(rng.standard_normal((30, 40)), x=(0, 80), y=(60, 0))
+    models = []
+    for k in range(40):
+        cls = (glimpse_amd.CartesianMotion, glimpse_amd.CylindricalMotion, glimpse_amd.TangentCartesianMotion,
+               glimpse_amd.TangentCylindricalMotion)[k % 4]
+        kw = dict(xy=(10.0 + k, 20.0), time_unit=DAY, dem=dem if k % 3 == 0 else 5.0, dem_sigma=0.25 * (k % 5), n=64,
+                  xy_sigma=(0.2, 0.3))
+        kw.update([dict(vxyz=(0.1 * k, 0, 0), vxyz_sigma=(0.1, 0.1, 0)), dict(vrthz=(0.1 * k, 0.2, 0), vrthz_sigma=(0.1, 0.1, 0)),
+                   dict(vxy=(0.1 * k, 0), vxy_sigma=(0.1, 0.1), slope_sigma=0.1),
+                   dict(vrth=(0.1 * k, 0.2), vrth_sigma=(0.1, 0.1), slope_sigma=0.2)][k % 4])
+        models.append(cls(**kw))
+    assert tracker_module._batches(models) == [0]
+    block = ModelBlock.from_models(models)
+    assert len(block) == 40 and tracker_module._batches(block) == [0]
+    np.testing.assert_array_equal(params_table(block), params_table(models))
+    assert block.raster("dem") is dem and block.raster("dem_sigma") is None
+    assert parallel.rasters_of(block) == [dem] and parallel.rasters_of(models) == [dem]
+    back = pickle.loads(pickle.dumps(block))
+    np.testing.assert_array_equal(back.table, block.table)
+    assert back.n == 64 and back.time_unit == DAY and isinstance(back.dem, glimpse_amd.Raster)
+    for k in (0, 1, 7, 39):
+        view, m = block[k], models[k]
+        assert view.n == m.n and view.time_unit == m.time_unit and view.TANGENT == m.TANGENT and view.KIND == m.KIND
+        assert (view.dem is dem) == (m.dem is dem) and (view.dem is dem or view.dem == m.dem)
+        assert view.dem_sigma == m.dem_sigma and tuple(view.xy) == tuple(m.xy)
+        assert tracker_module._on_device(view)
+    part = block[10:25]
+    np.testing.assert_array_equal(part.table, params_table(models[10:25]))
+    assert [v.KIND for v in part] == [m.KIND for m in models[10:25]]
+    constant = ModelBlock.from_models([m for m in models if m.dem is not dem])
+    assert constant.raster("dem") is None and parallel.rasters_of(constant) == []
