@@ -334,8 +334,10 @@ def _track_block(state, args):
         if any(group.store.get(f"ctxchg.{call}.{r}") == b"1" for r in range(group.world)):
             if state.get("attached") == "rccl" and not changed:
                 ctx.comm_destroy()
-            state["attached"] = group.attach(ctx)
-            state["why_host"] = getattr(group, "why_host", "")
+            # (workers that share a GPU cannot make a communicator -- ncclCommInitRank refuses a device twice --: the parent
+            # says so and the attempt, a second or two of RCCL bootstrap at the first call, is not made)
+            state["attached"] = group.attach(ctx, "host" if args.get("host_only") else None)
+            state["why_host"] = args.get("host_only") or getattr(group, "why_host", "")
         else:
             group._ctx = ctx
         state["ctx_id"] = id(ctx)

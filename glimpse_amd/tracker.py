@@ -942,11 +942,13 @@ class Tracker:
         # what a worker gets of its tracks: ONE parameter table when the block is one device batch (`gather`: every block
         # is) -- thousands of model objects cost more to pickle and unpickle than their tracks take to run --, the model
         # objects otherwise
+        host_only = "" if workers <= ndev else f"{workers} workers share {ndev} GPU{'s' if ndev > 1 else ''}"
         jobs = []
         for w, (a, b) in enumerate(bounds):
             models = ModelBlock.from_models(motion_models[a:b]) if gather else motion_models[a:b]
             jobs.append(dict(tracker=settings, models=models, np_seed=seeds[w], catch=ntracks >= 2,
                              gather=gather, sizes=sizes, call=pool.calls, want_last=w == workers - 1, result=result,
+                             host_only=host_only,
                              rows=(a, b),
                              kw=dict(kw, observer_mask=None if mask is None else mask[a:b], rng=rng, seed=seed,
                                      point_offset=point_offset + a)))
