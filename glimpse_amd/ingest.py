@@ -69,7 +69,13 @@ class DecodePool:
         self.n, self.slot_bytes = n, int(slot_bytes)
         # two slots per decoder (one being filled, one on its way to the device) while the ring stays within RING_BYTES
         self.slots = slots or max(4, min(2 * n + 2, self.RING_BYTES // max(1, self.slot_bytes)))
-        self.ring = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)  # (OSError: no room in /dev/shm)
+        from .parallel import shm_room
+
+        while self.slots > 4 and not shm_room(self.slots * self.slot_bytes):
+            self.slots -= 1
+        if not shm_room(self.slots * self.slot_bytes):  # (the caller decodes in threads instead)
+            raise OSError(f"/dev/shm has no room for a ring of {self.slots} frames of {self.slot_bytes} bytes")
+        self.ring = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
         self.procs = [ctx.Process(target=_decode_main, args=(self.tasks, self.done, self.ring.name, self.slot_bytes),
                                   daemon=True) for _ in range(n)]

@@ -77,9 +77,21 @@ def _in_child():
 
 
 # ---- arrays through shared memory -----------------------------------------------------------------
+def shm_room(nbytes):
+    """/dev/shm has room for a block of `nbytes` (and a margin).  A shared-memory block is a sparse file on a tmpfs: making
+    it never fails, WRITING beyond what the tmpfs holds is a SIGBUS that kills the writer (a container's default /dev/shm is
+    64 MB) -- so the room is looked at before every block is made."""
+    try:
+        st = os.statvfs("/dev/shm")
+    except OSError:
+        return True  # (no /dev/shm to look at: the block's creation decides)
+    return st.f_bavail * st.f_frsize >= int(nbytes) + (8 << 20)
+
+
 def _export(a):
-    """ndarray -> a picklable handle (the bytes in a shared-memory block the receiver unlinks); small arrays as they are."""
-    if not isinstance(a, np.ndarray) or a.nbytes < _BIG or a.dtype == object:
+    """ndarray -> a picklable handle (the bytes in a shared-memory block the receiver unlinks); small arrays as they are
+    (and large ones too, through the pipe, when shared memory has no room for them)."""
+    if not isinstance(a, np.ndarray) or a.nbytes < _BIG or a.dtype == object or not shm_room(a.nbytes):
         return a
     a = np.ascontiguousarray(a)
     shm = shared_memory.SharedMemory(create=True, size=a.nbytes)
@@ -136,6 +148,8 @@ class SharedFrames:
         first = pixels(obs.images[0])
         n = len(obs.images)
         try:
+            if not shm_room(n * first.nbytes):
+                raise OSError("the tmpfs is too small")
             shm = shared_memory.SharedMemory(create=True, size=max(1, n * first.nbytes))
         except OSError as e:
             raise MemoryError(f"Tracker.track(parallel=...): no room in shared memory (/dev/shm) for an observer's "
@@ -202,6 +216,8 @@ class SharedRasters:
         held = self.blocks.get(key)
         if held is None or held[0] is not array:
             a = np.ascontiguousarray(array)
+            if not shm_room(a.nbytes):
+                return array  # (no room: the array is pickled with its Raster)
             shm = shared_memory.SharedMemory(create=True, size=max(1, a.nbytes))
             np.ndarray(a.shape, a.dtype, buffer=shm.buf)[...] = a
             held = self.blocks[key] = (array, shm, a.shape, a.dtype.str)
@@ -535,6 +551,8 @@ class WorkerPool:
     def result_block(self, shape):
         """(name, shape) of a float64 shared-memory block of at least this shape, kept between calls (grown on demand)."""
         nbytes = int(np.prod(shape)) * 8
+        if (self.results is None or self.results.size < nbytes) and not shm_room(nbytes):
+            return None  # (no room: the workers send their histories with their replies)
         if self.results is None or self.results.size < nbytes:
             if self.results is not None:
                 try:

@@ -253,3 +253,25 @@ def test_a_block_of_models_travels_as_one_parameter_table():
     assert [v.KIND for v in part] == [m.KIND for m in models[10:25]]
     constant = ModelBlock.from_models([m for m in models if m.dem is not dem])
     assert constant.raster("dem") is None and parallel.rasters_of(constant) == []
+
+
+def test_no_block_is_made_that_dev_shm_cannot_hold(monkeypatch):
+    """A shared-memory block is a sparse file: writing past what /dev/shm holds is a SIGBUS, not an exception.  Every block
+    is therefore checked against the free space first; without room the frames refuse (MemoryError), the decoders refuse
+    (OSError: the Tracker then decodes in threads), reply arrays and raster arrays go through the pipes."""
+    from glimpse_amd import ingest
+
+    assert parallel.shm_room(1 << 10) is True
+    assert parallel.shm_room(1 << 60) is False
+    monkeypatch.setattr(parallel, "shm_room", lambda nbytes: False)
+    big = np.zeros((300, 400))
+    assert parallel._export(big) is big
+    with pytest.raises(MemoryError, match="no room in shared memory"):
+        parallel.SharedFrames(_observers(np.random.default_rng(1), n=2))
+    with pytest.raises(OSError, match="no room"):
+        ingest.DecodePool(2, 1 << 16)
+    shared = parallel.SharedRasters()
+    assert shared.ref(big) is big and not shared.blocks
+    pool = parallel.WorkerPool.__new__(parallel.WorkerPool)
+    pool.results = None
+    assert pool.result_block((10, 10, 12)) is None
