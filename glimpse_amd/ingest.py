@@ -20,13 +20,21 @@ from multiprocessing import shared_memory
 import numpy as np
 
 
-def _decode_main(tasks, done, ring_name, slot_bytes):
-    """One decoder process: (job, image, slot) -> the image's pixels at its camera size in ring[slot]."""
+def _decode_main(tasks, done, ring_name, slot_bytes, parent):
+    """One decoder process: (job, image, slot) -> the image's pixels at its camera size in ring[slot].  `parent`: the pid
+    of the process that owns the pool."""
     os.environ["GLH_POOL_CHILD"] = "1"
     ring = shared_memory.SharedMemory(name=ring_name)
     try:
         while True:
-            item = tasks.get()
+            try:
+                item = tasks.get(timeout=5.0)
+            except queue.Empty:
+                # (a queue never reports its writer's death -- every process that holds it is a writer: a decoder whose
+                # parent was killed would wait here for ever)
+                if os.getppid() != parent:
+                    break
+                continue
             if item is None:
                 break
             job, img, slot = item
@@ -77,7 +85,8 @@ class DecodePool:
             raise OSError(f"/dev/shm has no room for a ring of {self.slots} frames of {self.slot_bytes} bytes")
         self.ring = shared_memory.SharedMemory(create=True, size=self.slots * self.slot_bytes)
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
-        self.procs = [ctx.Process(target=_decode_main, args=(self.tasks, self.done, self.ring.name, self.slot_bytes),
+        self.procs = [ctx.Process(target=_decode_main,
+                                  args=(self.tasks, self.done, self.ring.name, self.slot_bytes, os.getpid()),
                                   daemon=True) for _ in range(n)]
         with without_main():  # (the decoders never run the caller's main script: parallel.without_main)
             for p in self.procs:

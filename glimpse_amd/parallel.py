@@ -417,11 +417,13 @@ def _worker_main(conn, rank, world, device, token):
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     store = sharding.FileStore(sharding.FileStore.default_path(token), rank, world) if world > 1 else None
     state = {"group": sharding.Group(rank, world, rank, store), "device": device, "observers": None, "blocks": []}
+    orphan = False
     try:
         while True:
             try:
                 msg = conn.recv()
             except (EOFError, OSError):
+                orphan = True  # (the parent is gone without a "stop": nobody else removes the rendezvous directory)
                 break
             kind, args = msg
             if kind == "stop":
@@ -457,6 +459,10 @@ def _worker_main(conn, rank, world, device, token):
                 shm.close()
             except BufferError:
                 pass
+        if orphan:  # (every rank: one that starts late makes the directory again)
+            import shutil
+
+            shutil.rmtree(sharding.FileStore.default_path(token), ignore_errors=True)
 
 
 # ---- the pool (parent) ----------------------------------------------------------------------------

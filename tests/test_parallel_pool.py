@@ -275,3 +275,40 @@ def test_no_block_is_made_that_dev_shm_cannot_hold(monkeypatch):
     pool = parallel.WorkerPool.__new__(parallel.WorkerPool)
     pool.results = None
     assert pool.result_block((10, 10, 12)) is None
+
+
+def test_decoders_and_workers_end_when_their_parent_is_killed(tmp_path):
+    """The parent of a pool dies without a word (SIGKILL): the workers see their pipe close, the decoders -- whose queue
+    never reports a dead writer -- notice that they have been adopted, and all of them end."""
+    import subprocess
+    import sys
+    import time
+
+    script = tmp_path / "killed.py"
+    script.write_text(f"""
+import os, signal, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from glimpse_amd import ingest, parallel
+if __name__ == "__main__":
+    pool = ingest.DecodePool(2, 1 << 16, slots=4)
+    workers = parallel.WorkerPool(2, [0, 0])
+    print(" ".join(str(v) for v in [p.pid for p in pool.procs + workers.procs] + [os.getpid()]), flush=True)
+    os.kill(os.getpid(), signal.SIGKILL)
+""")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    pids = [int(v) for v in out.stdout.split()]
+    assert len(pids) == 5 and out.returncode == -9
+    pids, parent_pid = pids[:4], pids[4]
+
+    def alive(pid):
+        try:
+            with open(f"/proc/{pid}/stat") as f:
+                return f.read().split(") ")[-1][0] != "Z"
+        except OSError:
+            return False
+
+    deadline = time.monotonic() + 30.0
+    while any(alive(p) for p in pids) and time.monotonic() < deadline:
+        time.sleep(0.25)
+    assert not any(alive(p) for p in pids), [p for p in pids if alive(p)]
+    assert not [name for name in os.listdir("/dev/shm") if name.startswith("glh_rdzv_pool_%d_" % parent_pid)]
