@@ -44,3 +44,10 @@ class NoTermMotion(DriftMotion):
 
     def compute_log_likelihoods(self, particles):
         return None
+
+
+def shape_and_weight(particles, weights):
+    """A `reduce_particles` function the worker processes of `track(parallel=N)` can import (not a lambda)."""
+    import numpy as np
+
+    return particles.shape, float(np.nansum(weights))

@@ -627,6 +627,42 @@ def test_parallel_workers_reproduce_the_single_process_run(golden):
     assert glimpse_amd.Tracker._parse_parallel(False, 10) == 0 and glimpse_amd.Tracker._parse_parallel(8, 3) == 3
 
 
+def test_parallel_workers_with_blocks_that_are_not_one_batch(golden):
+    """`track(parallel=2)` when a worker's tracks are NOT one device batch -- ragged particle counts, a user-defined motion
+    model among them: the workers get the model objects themselves (not a parameter table) and hand their host results over;
+    with the device RNG (keyed on the global track index) the ragged run equals the single-process run value for value,
+    `reduce_particles` runs in the workers, errors come back in track order."""
+    from tests import custom_motion as cm
+
+    g = golden("g15_ragged.npz")
+    cam = camera_from(g["cam"])
+    images = [glimpse_amd.Image("synthetic", cam=cam, datetime=T0 + i * DAY, array=f) for i, f in enumerate(g["frames"])]
+    tracker = glimpse_amd.Tracker([glimpse_amd.Observer(images, sigma=0.3)], max_search_dim=128)
+    models = [glimpse_amd.CartesianMotion(xy=xy, time_unit=DAY, dem=0.0, dem_sigma=0.0, n=int(n), xy_sigma=(0.2, 0.2),
+                                          vxyz=(0.15, 0, 0), vxyz_sigma=(0.2, 0.2, 0.0), axyz=(0, 0, 0),
+                                          axyz_sigma=(0.05, 0.05, 0.0)) for xy, n in zip(g["xy"], g["n_particles"])]
+    assert len(set(int(n) for n in g["n_particles"])) > 1
+    reduce = cm.shape_and_weight
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        serial = tracker.track(models, tile_size=(15, 15), rng="philox", seed=2, reduce_particles=reduce)
+        par = tracker.track(models, tile_size=(15, 15), rng="philox", seed=2, reduce_particles=reduce, parallel=2)
+        assert par.transport == "host" and par.parallel_info["workers"] == 2
+        assert [type(e) for e in par.errors] == [type(e) for e in serial.errors]
+        for a, b in zip(par.means, serial.means):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(par.sigmas, serial.sigmas):
+            np.testing.assert_array_equal(a, b)
+        assert par.reduced == serial.reduced
+        # a user-defined model among the tracks: its methods run on the host of whichever worker has it
+        mixed = [models[0], cm.SpeedPriorMotion(tuple(g["xy"][1]), DAY, n=150), models[2], models[4]]
+        np.random.seed(4)
+        out = tracker.track(mixed, tile_size=(15, 15), parallel=2)
+        assert [e is None for e in out.errors] == [True] * 4
+        assert all(np.isfinite(np.asarray(m)).all() for m in out.means) and len(out.means) == 4
+    tracker.close()
+
+
 def test_user_defined_motion_models_reproduce_reference(golden):
     """Motion models the library does not know (the duck type of motion.py:13-89) in one Tracker.track call with a
     built-in one: their own initialize / evolve / log-likelihood methods run on the host, everything between them on
