@@ -13,10 +13,14 @@
 #error "define PT_TB, PT_PPT, PT_NOBS, PT_SURF, PT_FAST, PT_CON"
 #endif
 
+#ifndef PT_MINW
+#define PT_MINW 4  // waves per SIMD the register allocation aims at (128 VGPRs; 6 -- an experiment -- would be 80)
+#endif
+
 #define GLH_PT_NAME_X(TB, PPT, NOBS, S, F, C) GLH_PT_NAME(TB, PPT, NOBS, S, F, C)
 
 namespace glh {
 const void* GLH_PT_NAME_X(PT_TB, PT_PPT, PT_NOBS, PT_SURF, PT_FAST, PT_CON)() {
-  return (const void*)k_point_step<PT_TB, PT_PPT, 4, PT_NOBS, PT_SURF, (bool)PT_FAST, (bool)PT_CON>;
+  return (const void*)k_point_step<PT_TB, PT_PPT, PT_MINW, PT_NOBS, PT_SURF, (bool)PT_FAST, (bool)PT_CON>;
 }
 }  // namespace glh

@@ -1526,7 +1526,11 @@ static bool fused_plan(const glh_ctx* c, int* r2_bytes, int mode = -1) {
   const int typical = pt_small_bytes(c->tw, c->th, nb) + 48 * pt_search_ld(48) * 4 + pt_keys_count(48, 48) * 2;
   // (a context with rasters runs the instantiations that keep windows of them in static LDS)
   const int patch = c->rasters[0].z || c->rasters[1].z || c->rasters[2].z ? PT_PATCH_LDS : 0;
-  const int lds_half = PT_LDS_HALF - patch, lds_max = PT_LDS_MAX - patch;
+  // experiment (GLH_PT_LDS_HALF=bytes): another bound for the dynamic LDS of a workgroup that shares its compute unit --
+  // 49 152 lets THREE 512-thread workgroups in (with a build at 6 waves per SIMD: -DPT_MINW=6)
+  int lds_shared = PT_LDS_HALF;
+  if (const char* e = getenv("GLH_PT_LDS_HALF")) lds_shared = std::max(16 * 1024, std::min(atoi(e), PT_LDS_HALF));
+  const int lds_half = lds_shared - patch, lds_max = PT_LDS_MAX - patch;
   int r2;
   if (cN + std::max(r2_min, typical) <= lds_half)
     r2 = lds_half - cN;
