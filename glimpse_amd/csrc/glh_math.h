@@ -138,6 +138,15 @@ GLH_HD double glh_fma(double a, double b, double c) {
   return fma(a, b, c);
 #endif
 }
+// k / n, correctly rounded -- the quotient an IEEE division gives, bit for bit -- for integers 0 <= k <= n <= 65 536 with
+// rn = 1.0 / n (one division per n): q = RN(k rn) is within an ulp, the residual k - q n is exact in one fused multiply-add,
+// and the correction rounds to the quotient (Markstein).  All 2.1e9 pairs compared with the division on the host
+// (tests/hostcheck: hc_count_fraction_exhaustive); three instructions where the division takes a dozen and a v_rcp_f64.
+GLH_HD double count_fraction(int k, double n, double rn) {
+  const double dk = (double)k;
+  const double q = dk * rn;
+  return glh_fma(glh_fma(-q, n, dk), rn, q);
+}
 GLH_HD double rcp_nr(double x) {  // 1 / x: v_rcp_f64 + two Newton steps (<= 1 ulp for normal x)
 #if defined(__HIP_DEVICE_COMPILE__)
   double y = __builtin_amdgcn_rcp(x);

@@ -603,6 +603,8 @@ __device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, con
   // helpers.match_cdf (helpers.py:489-493) = np.interp(count / n, template quantiles, template values) for a pixel and
   // for its median: the interval search is made once per pixel, into jt[count] (equal counts write equal intervals), and
   // starts from an index of the quantiles by 1/256 steps (acc, over the bucket table: dead)
+  // (count / n: np.cumsum(counts) / a.size, the division made once -- glh_math.h: count_fraction gives its quotients)
+  const double dn = (double)n, rn = 1.0 / dn;
   uint16_t* acc = reinterpret_cast<uint16_t*>(tab);
   for (int i = tid; i <= 256; i += TB) {
     const int j = np_interp_find((double)i * (1.0 / 256.0), cq, hist_n);
@@ -612,7 +614,7 @@ __device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, con
   for (int idx = tid; idx < n; idx += TB) {
     const int r = udiv(by_w, idx), c = idx - r * w;
     const int k = keys[r * wp + c];
-    const double x = (double)k / (double)n;  // np.cumsum(counts) / a.size
+    const double x = count_fraction(k, dn, rn);  // np.cumsum(counts) / a.size
     const int s256 = min(255, (int)(x * 256.0));
     // xp[acc[s]] <= s / 256 <= x < (s + 1) / 256 < xp[acc[s + 1] + 1]: the interval of x lies between them
     jt[k] = (uint16_t)np_interp_find(x, cq, hist_n, acc[s256], min(hist_n - 1, acc[s256 + 1] + 1));
@@ -625,7 +627,7 @@ __device__ __forceinline__ void pt_counts_finish(const int* box, int hist_n, con
   pt_highpass_write<TB, true>(ws, keys, wp, w, h, hp_rx, hp_ry, n, PtPackPair{});
   auto value_of = [&](int k) -> double {
     const int j = jt[k];
-    return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, (double)k / (double)n, cq, cv, hist_n);
+    return np_interp_at(j == 0xffff ? NP_INTERP_LEFT : j, count_fraction(k, dn, rn), cq, cv, hist_n);
   };
   const int ld = ws.ld;
   for (int idx = tid; idx < n; idx += TB) {

@@ -234,6 +234,17 @@ int hc_raster_patch(const double* z, int nx, int ny, const double* gx, const dou
   }
   return hits;
 }
+// glh_math.h: count_fraction(k, n, 1 / n) against the IEEE quotient k / n for every 0 <= k <= n, n_lo <= n <= n_hi: the
+// number of pairs that differ
+long long hc_count_fraction_exhaustive(int n_lo, int n_hi) {
+  long long bad = 0;
+  for (int n = n_lo; n <= n_hi; ++n) {
+    const double dn = (double)n, rn = 1.0 / dn;
+    for (int k = 0; k <= n; ++k)
+      if (count_fraction(k, dn, rn) != (double)k / dn) ++bad;
+  }
+  return bad;
+}
 // the fast-arithmetic form of the same samples (raster_bilinear_fast): without and with the window, [m][2]; and the pair form
 void hc_raster_patch_fast(const double* z, int nx, int ny, const double* gx, const double* gy, int sx, int sy, double xmin,
                           double xmax, double ymin, double ymax, double cx, double cy, const double* xy, int m, double* values) {

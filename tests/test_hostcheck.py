@@ -273,6 +273,15 @@ def test_raster_interval_is_the_clipped_searchsorted(hc):
         assert hc.hc_raster_uniform(p(g), len(g), C.c_double(g[0] - d / 2), C.c_double(g[-1] + d / 2)) == 0
 
 
+def test_count_fraction_is_the_ieee_quotient_for_every_count(hc):
+    """glh_math.h: count_fraction -- k / n in three instructions (a multiplication by 1 / n and a fused residual correction)
+    in the tile stage of 16-bit and float frames, where k is a pixel's cumulative count and n the tile's pixel count: bit
+    for bit the IEEE division for EVERY pair 0 <= k <= n <= 65 536 (2.1e9 of them: tiles of the fused step have fewer
+    than 65 536 pixels)."""
+    hc.hc_count_fraction_exhaustive.restype = C.c_longlong
+    assert hc.hc_count_fraction_exhaustive(1, 65536) == 0
+
+
 def test_raster_window_serves_the_same_samples(hc):
     """A window of a raster around a point (glh_math.h: RasterPatch -- the fused kernel keeps one per surface in LDS): the
     samples it serves are bit for bit the raster's own, for either orientation of the array, at the raster's edges and
